@@ -1,0 +1,327 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures in tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to
+the GPU box).  Imports the reference's Python with import-time stubs for the
+third-party modules that are absent here (cv2, rawpy, ...), feeds it seeded
+inputs and stores inputs + outputs as small .npz / .json fixtures.  No reference
+source text is stored -- only data.
+
+    python tests/golden/make_golden.py            # regenerate everything
+
+Versions the fixtures were captured with: python 3.10.12, numpy 2.2.6,
+scipy 1.15.3, torch 2.10.0 (CPU).
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+
+
+def _stub(name, fns=()):
+    m = types.ModuleType(name)
+    for f in fns:
+        setattr(m, f, lambda *a, **k: None)
+    sys.modules[name] = m
+    return m
+
+
+def import_reference():
+    _stub('cv2', ['setNumThreads'])
+    _stub('torchsummary'); _stub('exifread'); _stub('h5py')
+    _stub('natsort').natsort = None
+    _stub('rawpy').enhance = _stub('rawpy.enhance')
+    _stub('skimage').metrics = _stub('skimage.metrics', ['peak_signal_noise_ratio', 'structural_similarity'])
+    sys.path.insert(0, REF)
+    import torch  # noqa
+    import archs, data_process, losses  # noqa
+    import utils.isp_ops as isp
+    import data_process.process  # noqa
+    proc = sys.modules['data_process.process']   # a function named `process` shadows the attribute
+    import base_trainer
+    return archs, proc, isp, losses, data_process, base_trainer
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def probes(t, n=64):
+    """Checksums + strided probe elements of a tensor (keeps fixtures small)."""
+    a = np.asarray(t, dtype=np.float32).reshape(-1)
+    idx = np.linspace(0, a.size - 1, min(n, a.size)).astype(np.int64)
+    return dict(sum=float(a.astype(np.float64).sum()),
+                l2=float(np.sqrt((a.astype(np.float64) ** 2).sum())),
+                idx=idx, val=a[idx])
+
+
+# ------------------------------------------------------------------ G1 pack / unpack
+def gen_pack(isp):
+    out = {}
+    rng = np.random.default_rng(1234)
+    cases = []
+    for (H, W) in [(16, 24), (64, 64)]:
+        for (wp, bl) in [(16383, 512), (1023, 64)]:
+            raw = rng.integers(0, wp + 40, size=(H, W), dtype=np.uint16)
+            for norm in (True, False):
+                for clip in (True, False):
+                    for bias_on in (False, True):
+                        bias = np.array([-0.08113494, -0.04906388, -0.9408157, -1.2048522]) if bias_on else np.array([0, 0, 0, 0])
+                        tag = f'H{H}W{W}wp{wp}n{int(norm)}c{int(clip)}b{int(bias_on)}'
+                        packed = isp.raw2bayer(raw, wp=wp, bl=bl, norm=norm, clip=clip, bias=bias)
+                        out[tag + '_raw'] = raw
+                        out[tag + '_packed'] = packed
+                        out[tag + '_bias'] = bias
+                        cases.append(dict(tag=tag, H=H, W=W, wp=wp, bl=bl, norm=norm, clip=clip))
+            # unpack of an arbitrary float image (includes <0 and >1 values)
+            pf = (rng.random((4, H // 2, W // 2), dtype=np.float32) * 1.2 - 0.1).astype(np.float32)
+            out[f'unpack_H{H}W{W}wp{wp}_in'] = pf
+            out[f'unpack_H{H}W{W}wp{wp}_out'] = isp.bayer2raw(pf, wp=wp, bl=bl)
+            # round trip property on in-range data
+            raw_in = rng.integers(bl, wp + 1, size=(H, W), dtype=np.uint16)
+            rt = isp.bayer2raw(isp.raw2bayer(raw_in, wp=wp, bl=bl, norm=True, clip=False), wp=wp, bl=bl)
+            out[f'rt_H{H}W{W}wp{wp}_in'] = raw_in
+            out[f'rt_H{H}W{W}wp{wp}_out'] = rt
+    # index maps of the other four helpers
+    b = rng.integers(0, 65535, size=(12, 20), dtype=np.uint16)
+    out['maps_bayer'] = b
+    out['maps_rggb'] = isp.bayer2rggb(b)
+    out['maps_rggb_back'] = isp.rggb2bayer(isp.bayer2rggb(b))
+    out['maps_rows'] = isp.bayer2rows(b)
+    out['maps_rows_back'] = isp.rows2bayer(isp.bayer2rows(b))
+    np.savez_compressed(os.path.join(HERE, 'pack_small.npz'), **out)
+    # full-size crop: hash only (input regenerated from the seed in the test)
+    big = {}
+    for (wp, bl) in [(16383, 512), (1023, 64)]:
+        raw = np.random.default_rng(99 + wp).integers(0, wp + 1, size=(1024, 1024), dtype=np.uint16)
+        p = isp.raw2bayer(raw, wp=wp, bl=bl, norm=True, clip=True)
+        big[f'wp{wp}'] = dict(seed=99 + wp, wp=wp, bl=bl, in_sha=sha(raw), packed_sha=sha(p),
+                              unpack_sha=sha(isp.bayer2raw(p, wp=wp, bl=bl)))
+    json.dump(dict(cases=cases, big=big), open(os.path.join(HERE, 'pack_meta.json'), 'w'), indent=1)
+
+
+# ------------------------------------------------------------------ G2 param samplers
+def _plain(d):
+    return {k: (np.asarray(v).tolist()) for k, v in d.items()}
+
+
+def gen_params(proc):
+    res = {}
+    calls = [('max', dict(camera_type='SonyA7S2')),
+             ('max', dict(camera_type='IMX686')),
+             ('max', dict(camera_type='SonyA7S2', ratio=100, iso=1600)),
+             ('max', dict(camera_type='IMX686', iso=6400)),
+             ('max', dict(camera_type='NikonD850')),
+             ('plain', dict(camera_type='SonyA7S2')),
+             ('plain', dict(camera_type='CRVD')),
+             ('plain', dict(camera_type='CRVD', ln_ratio=True)),
+             ('plain', dict(camera_type='SonyA7S2', ln_ratio=True))]
+    for seed in (0, 1, 2):
+        for i, (kind, kw) in enumerate(calls):
+            np.random.seed(seed)
+            fn = proc.sample_params_max if kind == 'max' else proc.sample_params
+            # two consecutive draws pin the order and count of host RNG calls
+            a = fn(**kw); b = fn(**kw)
+            res[f's{seed}_c{i}'] = dict(kind=kind, kw=kw, first=_plain(a), second=_plain(b))
+    errs = {}
+    for cam in ('IMX686', 'NikonD850'):
+        try:
+            np.random.seed(0); proc.sample_params(camera_type=cam); errs[cam] = None
+        except Exception as e:  # reference quirk: KeyError('uReadk')
+            errs[cam] = type(e).__name__
+    tables = {cam: _plain(proc.get_camera_noisy_params(cam)) for cam in
+              ('NikonD850', 'IMX686', 'SonyA7S2_lowISO', 'SonyA7S2_highISO', 'CRVD')}
+    spec = {}
+    for iso in [50, 64, 80, 100, 125, 160, 200, 250, 320, 400, 500, 640, 800, 1000, 1250, 1600, 2000, 2500,
+                3200, 4000, 5000, 6400, 8000, 10000, 12800, 16000, 20000, 25600]:
+        spec[f'SonyA7S2:{iso}'] = _plain(proc.get_specific_noise_params('SonyA7S2', iso))
+    for iso in (100, 6400):
+        spec[f'IMX686:{iso}'] = _plain(proc.get_specific_noise_params('IMX686', iso))
+    json.dump(dict(samples=res, errors=errs, tables=tables, specific=spec),
+              open(os.path.join(HERE, 'params.json'), 'w'), indent=1)
+
+
+# ------------------------------------------------------------------ G3 sampler
+def gen_noise(proc):
+    import torch
+    # (a) seeded, bit-reproducible small cases: pins oracle/noise_np.py to the reference
+    out = {}
+    meta = []
+    rng = np.random.default_rng(7)
+    y = (rng.random((4, 16, 24), dtype=np.float32) ** 2).astype(np.float32)
+    out['y'] = y
+    np.random.seed(3)
+    P = [proc.sample_params_max('SonyA7S2'), proc.sample_params_max('IMX686', iso=6400),
+         proc.sample_params('SonyA7S2')]
+    P[2]['bias'] = np.array([0.5, -0.25, 0.125, 1.0])   # exercise 'd'
+    for pi, p in enumerate(P):
+        for code in ('p', 'pr', 'prq', 'pgrq', 'pg', 'pb', 'r', 'prqd' if pi else 'pq'):
+            for ori in (False, True):
+                for clip in (False, True):
+                    for mfm in (1, 4):
+                        tag = f'np_p{pi}_{code}_o{int(ori)}c{int(clip)}m{mfm}'
+                        np.random.seed(11)
+                        z = proc.generate_noisy_obs(y.copy(), noise_code=code, param=dict(p), MultiFrameMean=mfm,
+                                                    ori=ori, clip=clip)
+                        out[tag] = z
+                        meta.append(dict(tag=tag, kind='np', p=pi, code=code, ori=ori, clip=clip, mfm=mfm))
+        for code in ('p', 'pr', 'prq', 'pb', 'pbrq'):
+            for ori in (False, True):
+                for clip in (False, True):
+                    tag = f'th_p{pi}_{code}_o{int(ori)}c{int(clip)}'
+                    pt = {k: torch.from_numpy(np.array(v, np.float32)) for k, v in p.items()}
+                    torch.manual_seed(11)
+                    z = proc.generate_noisy_torch(torch.from_numpy(y.copy()), noise_code=code, param=pt, ori=ori, clip=clip)
+                    out[tag] = z.numpy()
+                    meta.append(dict(tag=tag, kind='th', p=pi, code=code, ori=ori, clip=clip, mfm=1))
+    np.savez_compressed(os.path.join(HERE, 'noise_seeded.npz'), **out)
+    # numpy-2 promotion (NEP 50) distinguishes python scalars (weak) from np.float64
+    # scalars (strong): record each parameter's type so tests rebuild it exactly.
+    ptypes = [{k: type(v).__name__ for k, v in p.items()} for p in P]
+    json.dump(dict(cases=meta, params=[_plain(p) for p in P], ptypes=ptypes),
+              open(os.path.join(HERE, 'noise_seeded.json'), 'w'), indent=1)
+
+    # (b) statistical goldens: flat patches, moments + integer-DN histograms of the
+    # reference's own draws (both numpy and torch paths).
+    st = {}
+    smeta = []
+    C, H, W = 4, 256, 256
+    cams = [('SonyA7S2_low', dict(K=float(np.exp(0.42228)), sigGs=float(np.exp(0.82966 * 0.42228 + 1.49343)),
+                                  sigTL=float(np.exp(0.74043 * 0.42228 + 0.86182)), lam=-0.026,
+                                  sigR=float(np.exp(0.78782 * 0.42228 - 0.34227)), q=1 / 2 ** 14, wp=16383, bl=512,
+                                  bias=np.zeros(4))),
+            ('SonyA7S2_high', dict(K=float(np.exp(2.51606)), sigGs=float(np.exp(0.82878 * 2.51606 + 0.44162)),
+                                   sigTL=float(np.exp(0.74901 * 2.51606 - 0.12348)), lam=-0.025,
+                                   sigR=float(np.exp(0.62945 * 2.51606 - 1.51040)), q=1 / 2 ** 14, wp=16383, bl=512,
+                                   bias=np.zeros(4))),
+            ('IMX686_6400', dict(K=8.74253, sigGs=14.30362, sigTL=12.8901, lam=0.015, sigR=0.9, q=1 / 2 ** 10,
+                                 wp=1023, bl=64, bias=np.array([-0.08113494, -0.04906388, -0.9408157, -1.2048522])))]
+    for cname, base in cams:
+        ratios = (100.0, 300.0) if 'Sony' in cname else (1.0, 8.0)
+        for ratio in ratios:
+            for yl in (0.0, 1e-3, 0.02, 0.2, 1.0):
+                for kind, code in (('np', 'p'), ('np', 'pr'), ('np', 'pgrq'), ('np', 'prq'), ('th', 'prq'), ('th', 'pb')):
+                    p = dict(base, ratio=ratio)
+                    y = np.full((C, H, W), yl, np.float32)
+                    if kind == 'np':
+                        np.random.seed(5)
+                        z = proc.generate_noisy_obs(y, noise_code=code, param=dict(p), ori=True, clip=False)
+                    else:
+                        torch.manual_seed(5)
+                        pt = {k: torch.from_numpy(np.array(v, np.float32)) for k, v in p.items()}
+                        z = proc.generate_noisy_torch(torch.from_numpy(y), noise_code=code, param=pt, ori=True, clip=False).numpy()
+                    dn = z.astype(np.float64) * (p['wp'] - p['bl'])          # back to DN (ori=True: no *ratio)
+                    lo = -p['bl'] * (p['wp'] - p['bl']) / p['wp']
+                    tag = f'{cname}_r{int(ratio)}_y{yl:g}_{kind}_{code}'
+                    edges = np.arange(np.floor(lo) - 1.5, np.floor(lo) - 1.5 + 1025, 1.0)
+                    edges = edges * (max(1.0, (dn.max() - lo) / 1000.0))       # widen bins for bright patches
+                    hist, _ = np.histogram(dn, bins=edges)
+                    st[tag + '_hist'] = hist.astype(np.int32)
+                    st[tag + '_edges'] = edges.astype(np.float64)
+                    rowmean = dn.mean(axis=2)
+                    st[tag + '_mom'] = np.array([dn.mean(), dn.var(), rowmean.var(), dn.min(), dn.max(),
+                                                 ((dn - dn.mean()) ** 3).mean()], np.float64)
+                    smeta.append(dict(tag=tag, cam=cname, ratio=ratio, y=yl, kind=kind, code=code))
+    np.savez_compressed(os.path.join(HERE, 'noise_stats.npz'), **st)
+    json.dump(dict(cases=smeta, cams={c: _plain(b) for c, b in cams}, shape=[C, H, W]),
+              open(os.path.join(HERE, 'noise_stats.json'), 'w'), indent=1)
+
+
+# ------------------------------------------------------------------ G4/G5 networks
+def gen_nets(archs, losses):
+    import torch
+    sys.path.insert(0, REPO)
+    from oracle import net_torch as O
+    torch.set_num_threads(8)
+    for arch, cls, shapes_fn in (('unet', archs.UNetSeeInDark, O.unet_param_shapes),
+                                 ('resunet', archs.ResUnet, O.resunet_param_shapes)):
+        for res in (False, True):
+            args = dict(nframes=1, res=res, nf=8, in_nc=4, out_nc=4)
+            net = cls(args)
+            shapes = shapes_fn(nf=8)
+            assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == shapes, 'state_dict contract drifted'
+            assert list(net.state_dict().keys()) == list(shapes.keys())
+            sd = O.init_state(shapes, seed=42)
+            net.load_state_dict(sd)
+            g = torch.Generator().manual_seed(1)
+            x = torch.rand(2, 4, 64, 48, generator=g, requires_grad=True)
+            t = torch.rand(2, 4, 64, 48, generator=g)
+            y = net(x)
+            loss = losses.Unet_Loss()(y.clamp(0, 1), t)
+            loss.backward()
+            out = {'x': x.detach().numpy(), 't': t.numpy(), 'y': y.detach().numpy(), 'loss': np.float64(loss.item()),
+                   'dx': x.grad.numpy()}
+            if not res:
+                for k, v in sd.items():
+                    out['w:' + k] = v.numpy()
+            for k, p in net.named_parameters():
+                pr = probes(p.grad.numpy(), 128)
+                out['g:' + k + ':idx'] = pr['idx']; out['g:' + k + ':val'] = pr['val']
+                out['g:' + k + ':sum'] = np.array([pr['sum'], pr['l2']])
+            # G5: three Adam steps on the fixed pair
+            opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+            ls = []
+            for it in range(3):
+                opt.zero_grad()
+                pred = net(x.detach())
+                l = losses.Unet_Loss()(pred.clamp(0, 1), t)
+                l.backward(); opt.step()
+                with torch.no_grad():
+                    ps = losses.PSNR_Loss(pred.clamp(0, 1), t.clamp(0, 1))
+                ls.append([l.item(), ps.item()])
+            out['train_losses'] = np.array(ls, np.float64)
+            for k, p in net.named_parameters():
+                pr = probes(p.detach().numpy(), 32)
+                out['w3:' + k + ':val'] = pr['val']; out['w3:' + k + ':sum'] = np.array([pr['sum'], pr['l2']])
+            np.savez_compressed(os.path.join(HERE, f'{arch}_nf8_res{int(res)}.npz'), **out)
+        # full-size single crop, nf=32, weights regenerated from the seed in the test
+        args = dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4)
+        net = cls(args)
+        sd = O.init_state(shapes_fn(nf=32), seed=7)
+        net.load_state_dict(sd)
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand(1, 4, 512, 512, generator=g)
+        with torch.no_grad():
+            y = net(x)
+        pr = probes(y.numpy(), 4096)
+        wsha = sha(np.concatenate([v.numpy().reshape(-1) for v in sd.values()]))
+        np.savez_compressed(os.path.join(HERE, f'{arch}_nf32_512.npz'), idx=pr['idx'], val=pr['val'],
+                            sums=np.array([pr['sum'], pr['l2']]), chan_sum=y.numpy().astype(np.float64).sum(axis=(0, 2, 3)),
+                            x_sha=np.array(sha(x.numpy())), w_sha=np.array(wsha))
+
+
+# ------------------------------------------------------------------ G6/G7 misc
+def gen_misc(base_trainer, losses, data_process):
+    import torch
+    steps = np.arange(0, 401)
+    lr = np.array([base_trainer.get_cos_lr(int(s), period=200, peak=10, lr=1e-4) for s in steps])
+    lr2 = np.array([base_trainer.get_cos_lr(int(s), period=1000, peak=20, lr=2e-4, ratio=0.2) for s in steps * 5])
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(3, 4, 32, 32, generator=g); b = (a + 0.05 * torch.randn(3, 4, 32, 32, generator=g)).clamp(0, 1)
+    ps4 = losses.PSNR_Loss(a, b).item(); ps3 = losses.PSNR_Loss(a[0], b[0]).item()
+    src = b[:1].clone(); src[0, 0, :4, :4] = 1.0
+    ic = data_process.IlluminanceCorrect()(a[:1] * 1.3 - 0.1, src)
+    np.savez_compressed(os.path.join(HERE, 'misc.npz'), lr_steps=steps, lr=lr, lr2=lr2, psnr_a=a.numpy(), psnr_b=b.numpy(),
+                        psnr4=np.float64(ps4), psnr3=np.float64(ps3), ic_src=src.numpy(), ic_out=ic.numpy())
+
+
+def main():
+    archs, proc, isp, losses, data_process, base_trainer = import_reference()
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc']
+    if 'pack' in which: gen_pack(isp)
+    if 'params' in which: gen_params(proc)
+    if 'noise' in which: gen_noise(proc)
+    if 'nets' in which: gen_nets(archs, losses)
+    if 'misc' in which: gen_misc(base_trainer, losses, data_process)
+    print('golden fixtures written to', HERE)
+
+
+if __name__ == '__main__':
+    main()
