@@ -1,0 +1,27 @@
+// Library-level entry points of libpnnp_hip.so.
+#include "common.h"
+
+extern "C" {
+
+int pnnp_version(void) { return 100; }   // 0.1.0
+
+const char* pnnp_error_string(int code) {
+    switch (code) {
+        case PNNP_OK: return "ok";
+        case PNNP_E_INVALID: return "invalid argument";
+        case PNNP_E_UNSUPPORTED: return "unsupported configuration";
+        case PNNP_E_LAUNCH: return "kernel launch failed";
+        case PNNP_E_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}
+
+int pnnp_device_cus(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
+    return p.multiProcessorCount;
+}
+
+}  // extern "C"

@@ -1,0 +1,212 @@
+// Physics-based raw noise sampler: one fused HBM-streaming kernel per batch of crops.
+//   generate_noisy_obs   data_process/process.py:591-631   (mode OBS)
+//   generate_noisy_torch data_process/process.py:634-673   (mode TORCH)
+//
+//   z = clip((shot + read + row + quant + bias) / (wp-bl), lo, 1) [* ratio]
+//   shot  = Poisson(mfm*y'/K) * K / mfm        y' = y*(wp-bl)/ratio         ('p')
+//         = y' + N(0,1)*sqrt(max(y'/K,1e-10))*K/mfm                         (OBS without 'p')
+//   read  = N(0,1)*sigGs/mfm   or Tukey-lambda(lam)*sigTL/mfm ('g', OBS only)
+//   row   = N(0,1)*sigR/mfm, ONE draw per (packed channel, row), broadcast along W
+//   quant = U(-.5,.5) DN (OBS)  or  (U(0,1)-.5)*q*(wp-bl) (TORCH)
+//
+// RNG: Philox4x32-10, key = (seed_lo, seed_hi ^ offset_hi),
+//      counter = (element-in-crop, crop_base+b, slot, offset_lo).  Slot 0 feeds the first
+//      Poisson attempt (lanes x,y) and the read-noise Box-Muller pair (lanes z,w); slot 1
+//      the quantisation uniform; slots 2.. further PTRS rejection rounds; slot 0x40000000
+//      with element = c*H+h is the row draw.  The sample therefore depends only on
+//      (seed, offset, global crop index, element) -- not on batch size, grid or GPU count.
+// Poisson: lam < 10 sequential inversion; lam >= 10 Hoermann's PTRS transformed rejection
+// (exact, no Gaussian approximation).  Specification: oracle/pnnp_oracle.c.
+//
+// Thread layout: one thread owns 4 consecutive pixels of a row (float4 load/store, fully
+// coalesced); the row-noise normal is drawn once by the first lane of each run of lanes that
+// share a row and broadcast inside the wavefront (ballot + shuffle), never per pixel.
+#include "common.h"
+
+namespace {
+
+struct Philox {
+    uint32_t k0, k1;
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+// 23 random bits + 1/2 ulp: exact in fp32, in [2^-24, 1-2^-24]
+__device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+
+__device__ __forceinline__ float box_muller(uint32_t a, uint32_t b) {
+    const float u1 = u01(a), u2 = u01(b);
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+}
+
+struct Ctx {
+    uint32_t k0, k1, crop, off;
+};
+
+__device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
+    if (!(lam > 0.f)) return 0.f;
+    if (lam < 10.f) {
+        const float u = u01(r0);
+        float p = expf(-lam), s = p, k = 0.f;
+        while (u > s && k < 200.f) { k += 1.f; p *= lam / k; s += p; }
+        return k;
+    }
+    const float slam = sqrtf(lam), loglam = logf(lam);
+    const float b = 0.931f + 2.53f * slam;
+    const float a = -0.059f + 0.02483f * b;
+    const float inv_alpha = 1.1239f + 1.1328f / (b - 3.4f);
+    const float vr = 0.9277f - 3.6224f / (b - 2.f);
+    uint32_t x0 = r0, x1 = r1;
+    uint4 extra = make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < 64; ++it) {
+        if (it > 0) {
+            if (it & 1) { extra = philox4x32_10(elem, c.crop, 1u + ((it + 1) >> 1), c.off, c.k0, c.k1); x0 = extra.x; x1 = extra.y; }
+            else { x0 = extra.z; x1 = extra.w; }
+        }
+        const float U = u01(x0) - 0.5f, V = u01(x1);
+        const float us = 0.5f - fabsf(U);
+        const float k = floorf((2.f * a / us + b) * U + lam + 0.43f);
+        if (us >= 0.07f && V <= vr) return k;
+        if (k < 0.f || (us < 0.013f && V > us)) continue;
+        if (logf(V) + logf(inv_alpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.f)) return k;
+    }
+    return floorf(lam + 0.5f);
+}
+
+__device__ __forceinline__ float tukey_lambda(float u, float lam) {
+    if (lam == 0.f) return logf(u / (1.f - u));
+    return (powf(u, lam) - powf(1.f - u, lam)) / lam;
+}
+
+__global__ void __launch_bounds__(256)
+noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H, int W,
+                    const float* __restrict__ params, unsigned flags, float mfm,
+                    uint32_t k0, uint32_t k1, uint32_t off, uint32_t crop_base) {
+    const int wq = (W + 3) >> 2;
+    const int64_t rows = (int64_t)B * C * H;
+    const int64_t total = rows * wq;
+    const bool torch_mode = flags & PNNP_NOISE_MODE_TORCH;
+    const bool use_p = flags & PNNP_NOISE_P, use_g = flags & PNNP_NOISE_G, use_r = flags & PNNP_NOISE_R;
+    const bool use_q = flags & PNNP_NOISE_Q, use_d = flags & PNNP_NOISE_D, use_b = flags & PNNP_NOISE_B;
+    const bool extras = torch_mode || !use_b;        // OBS: 'b' removes read, row, quant and bias
+    const int lane = threadIdx.x & 63;
+    // grid-stride with the SAME trip count for all lanes of a wave (shuffles below)
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t iters = (total + stride - 1) / stride;
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t t = t0 + it * stride;
+        const bool live = t < total;
+        const int64_t tt = live ? t : total - 1;
+        const int xq = (int)(tt % wq);
+        const int64_t row = tt / wq;                     // (b*C + c)*H + h
+        const int h = (int)(row % H);
+        const int c = (int)((row / H) % C);
+        const int b = (int)(row / ((int64_t)H * C));
+        const float* P = params + (int64_t)b * PNNP_NPARAM;
+        const float K = P[PNNP_P_K], ratio = P[PNNP_P_RATIO], wp = P[PNNP_P_WP], bl = P[PNNP_P_BL];
+        const float span = wp - bl;
+        Ctx ctx{k0, k1, crop_base + (uint32_t)b, off};
+
+        // ---- row noise: one draw per run of lanes sharing `row`, broadcast in-wave
+        float row_noise = 0.f;
+        if (use_r && extras) {
+            const int64_t prev = __shfl_up(row, 1);
+            const bool leader = (lane == 0) || (prev != row);
+            float n = 0.f;
+            if (leader) {
+                const uint4 r = philox4x32_10((uint32_t)(c * H + h), ctx.crop, 0x40000000u, off, k0, k1);
+                n = box_muller(r.x, r.y);
+            }
+            const unsigned long long leaders = __ballot(leader);
+            const unsigned long long upto = leaders & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+            const int src = 63 - __clzll(upto);
+            n = __shfl(n, src);
+            row_noise = __fdiv_rn(__fmul_rn(n, P[PNNP_P_SIGR]), mfm);
+        }
+        if (!live) continue;
+
+        const int nx = min(4, W - 4 * xq);
+        const int64_t base = row * W + 4 * xq;
+        float v[4];
+        if (nx == 4 && ((((uintptr_t)(y + base)) & 15) == 0)) {
+            const float4 q = *reinterpret_cast<const float4*>(y + base);
+            v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = i < nx ? y[base + i] : 0.f;
+        }
+        const float sig_read = __fdiv_rn(use_g ? P[PNNP_P_SIGTL] : P[PNNP_P_SIGGS], mfm);
+        const float qscale = torch_mode ? __fmul_rn(P[PNNP_P_Q], span) : 1.0f;
+        const float bias = (use_d && extras) ? P[PNNP_P_BIAS0 + (c & 3)] : 0.f;
+        const float lo = (flags & PNNP_NOISE_CLIP) ? 0.f : -__fdiv_rn(bl, wp);
+        const uint32_t e0 = (uint32_t)((c * H + h) * (int64_t)W + 4 * xq);
+        float o[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t elem = e0 + i;
+            const uint4 r = philox4x32_10(elem, ctx.crop, 0u, off, k0, k1);
+            float yy = __fmul_rn(v[i], span);
+            yy = __fdiv_rn(yy, ratio);
+            float shot;
+            if (use_p) {
+                const float lam = __fdiv_rn(__fmul_rn(mfm, yy), K);
+                shot = __fdiv_rn(__fmul_rn(poisson_f32(lam, elem, ctx, r.x, r.y), K), mfm);
+            } else {
+                const float n = box_muller(r.x, r.y);
+                const float s = sqrtf(fmaxf(__fdiv_rn(yy, K), 1e-10f));
+                shot = __fadd_rn(yy, __fdiv_rn(__fmul_rn(__fmul_rn(n, s), K), mfm));
+            }
+            float acc = shot;
+            if (!use_b) {
+                const float rd = use_g ? tukey_lambda(u01(r.z), P[PNNP_P_LAM]) : box_muller(r.z, r.w);
+                acc = __fadd_rn(acc, __fmul_rn(rd, sig_read));
+            }
+            if (extras) {
+                if (use_r) acc = __fadd_rn(acc, row_noise);
+                if (use_q) {
+                    const uint4 rq = philox4x32_10(elem, ctx.crop, 1u, off, k0, k1);
+                    acc = __fadd_rn(acc, __fmul_rn(u01(rq.x) - 0.5f, qscale));
+                }
+                if (use_d) acc = __fadd_rn(acc, bias);
+            }
+            float z = __fdiv_rn(acc, span);
+            z = fminf(fmaxf(z, lo), 1.f);
+            if (!(flags & PNNP_NOISE_ORI)) z = __fmul_rn(z, ratio);
+            o[i] = z;
+        }
+        if (nx == 4 && ((((uintptr_t)(out + base)) & 15) == 0)) {
+            *reinterpret_cast<float4*>(out + base) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            for (int i = 0; i < nx; ++i) out[base + i] = o[i];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, int H, int W,
+                                     const float* params, unsigned flags, float mfm, uint64_t seed,
+                                     uint64_t offset, uint32_t crop_base, void* stream) {
+    if (!y || !out || !params || B < 0 || C < 0 || H < 0 || W < 0 || !(mfm > 0.f)) return PNNP_E_INVALID;
+    if ((flags & PNNP_NOISE_MODE_TORCH) && (flags & PNNP_NOISE_G)) return PNNP_E_UNSUPPORTED;   // process.py:654
+    if ((flags & PNNP_NOISE_MODE_TORCH) && !(flags & PNNP_NOISE_P)) return PNNP_E_UNSUPPORTED;  // process.py:651
+    if ((int64_t)C * H * W >= (1ll << 32)) return PNNP_E_INVALID;
+    const int64_t total = (int64_t)B * C * H * ((W + 3) / 4);
+    if (total == 0) return PNNP_OK;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
+    hipLaunchKernelGGL(noise_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                       y, out, B, C, H, W, params, flags, mfm, k0, k1, (uint32_t)offset, crop_base);
+    return pnnp_launch_status();
+}

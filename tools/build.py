@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Build libpnnp_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, 'pnnp_amd', 'csrc')
+OBJ = os.path.join(SRC, '_build')
+OUT = os.path.join(REPO, 'pnnp_amd', 'libpnnp_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+          '-I', os.path.join(REPO, 'include')]
+# per-file extra flags: the sampler keeps every float32 rounding explicit (matches oracle/pnnp_oracle.c)
+EXTRA = {'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off']}
+
+
+def newer(a, deps):
+    return not os.path.exists(a) or any(os.path.getmtime(d) > os.path.getmtime(a) for d in deps)
+
+
+def build(verbose=True, force=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(SRC) if f.endswith('.hip'))
+    hdrs = [os.path.join(SRC, f) for f in os.listdir(SRC) if f.endswith('.h')] + [os.path.join(REPO, 'include', 'pnnp_hip.h')]
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, s[:-4] + '.o')
+        if force or newer(o, [os.path.join(SRC, s)] + hdrs):
+            jobs.append([HIPCC] + COMMON + EXTRA.get(s, []) + ['-c', os.path.join(SRC, s), '-o', o])
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(OBJ, s[:-4] + '.o') for s in srcs]
+    if force or jobs or newer(OUT, objs):
+        run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    return OUT
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)
+    print('built', OUT)
