@@ -82,9 +82,83 @@ enum {
 #define PNNP_NOISE_ORI 0x100u   /* ori=True: do not multiply by ratio                 */
 #define PNNP_NOISE_CLIP 0x200u  /* clip=True: clamp to [0,1] instead of [-bl/wp,1]    */
 #define PNNP_NOISE_MODE_TORCH 0x1000u /* quirks of generate_noisy_torch (else _obs)   */
+#define PNNP_NOISE_POST_MAX1 0x2000u  /* then min(z,1): Trainer.preprocess clamp, trainer_SID.py:481-485 */
+#define PNNP_NOISE_POST_MIN0 0x4000u  /* then max(z,0) (clip other than HALF_CLIP)     */
 int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, int H, int W,
                           const float* params, unsigned flags, float mfm /* sqrt(MultiFrameMean) */,
                           uint64_t seed, uint64_t offset, uint32_t crop_base, void* stream);
+
+/* ---------------------------------------------------------------- denoiser layers (NHWC fp32)
+ * What the archs/ modules of the reference do through torch.nn (archs/Unet.py:16-99,
+ * archs/ResUnet.py:15-88, archs/modules.py:130-197).  Arithmetic: fp32 operands and fp32
+ * accumulation on the matrix cores (v_mfma_f32_32x32x2_f32 == an fmaf chain), so results
+ * differ from the reference only by summation order.
+ *
+ * Weights are consumed in a packed, kernel-friendly order produced on the device from the
+ * parameter tensors (which keep the reference's state_dict layout):
+ *   Conv2d  [Cout][Cin][k][k] -> fwd   [taps][Cin/4][Cout][4]   (Cin*taps*Cout floats)
+ *                             -> dgrad [taps][Cout/4][Cin][4]   (flipped taps)
+ *   ConvTranspose2d [Cin][Cout][2][2] -> fwd 4 x [Cin/4][Cout][4], dgrad [(4*Cout)/4][Cin][4]
+ * Channel counts must be multiples of 4 (weights, gradients) / 8 (activations read as K).
+ */
+int pnnp_pack_conv_weight_f32(const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
+                              int Cout, int Cin, int taps, int Cin_pad, int Cout_pad, void* stream);
+int pnnp_pack_convt_weight_f32(const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
+                               int Cin, int Cout, void* stream);
+
+/* y = act(conv(cat[x1,x2]) + bias (+ residual)); taps 9 (3x3, pad 1) or 1 (1x1); x2 null when
+ * there is no concat (the cat of archs/Unet.py:75,80,85,90 is never materialised).
+ * act: 0 none, 1 LeakyReLU(0.2), 2 ReLU. */
+int pnnp_conv_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* w_packed,
+                      const float* bias, const float* residual, float* y, int B, int H, int W,
+                      int Cout, int taps, int act, void* stream);
+/* backward-data: g = dL/d(pre-activation output) -> dx1 (and dx2 for a concat layer).
+ * mask_i/mode_i: multiply by the activation derivative of the tensor that produced x_i
+ * (mask = that saved activation; mode 1 LeakyReLU', 2 ReLU', 0/null none); accum_i: dx_i +=. */
+int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
+                           float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                           float* dx2, int C2, const float* mask2, int mode2, int accum2,
+                           int B, int H, int W, int taps, void* stream);
+/* backward-weight: dW [Cout][C1+C2][taps] (+ dbias [Cout]); workspace from the query below. */
+int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps);
+int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps);
+/* *_cs = channels per pixel of that tensor (>= the channels used: the 4-channel boundary
+ * tensors travel zero-padded to 8 channels). */
+int pnnp_conv_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
+                             const float* x2, int x2_cs, int C2,
+                             float* dW, float* dbias /*or null*/, int B, int H, int W, int taps,
+                             int accumulate, float* workspace, int64_t workspace_floats, void* stream);
+/* ConvTranspose2d(Cin, Cout, 2, stride=2): x [B][H][W][Cin] <-> y [B][2H][2W][Cout]. */
+int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
+                          int B, int H, int W, int Cout, void* stream);
+int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, float* dx, int Cin,
+                               const float* mask, int mode, int B, int H, int W, void* stream);
+int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Cout, float* dW,
+                                 float* dbias_unused, int B, int H, int W, int accumulate,
+                                 float* workspace, int64_t workspace_floats, void* stream);
+/* MaxPool2d(2) (archs/Unet.py:57-69); backward routes to the first maximum of each window,
+ * multiplies by act'(x) and optionally accumulates into gx (skip-connection gradient). */
+int pnnp_maxpool2_fwd_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
+int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
+                          int act_mode, int accumulate, void* stream);
+/* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);
+ * the NCHW result can add a residual (arch 'res' flag, archs/Unet.py:95-98). */
+int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
+int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual /*or null*/, float* dst,
+                          int B, int C, int H, int W, int Cp, void* stream);
+/* out[c] (+)= sum over pixels (bias gradient of a ConvTranspose2d); workspace >= 256*C floats */
+int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int accumulate,
+                         float* workspace, void* stream);
+/* loss = mean|clamp(pred,0,1) - hr| (trainer_SID.py:99, losses/base_loss.py:92-107) on NCHW
+ * tensors; loss_out[0] = loss, loss_out[1+b] = sum_b (clamp(pred)-clamp(hr))^2 for PSNR_Loss
+ * (losses/__init__.py:4-15); grad_nhwc (or null) = dL/dpred as [B][H][W][Cp].
+ * workspace >= 128*B floats. */
+int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc, float* loss_out,
+                           int B, int C, int H, int W, int Cp, float* workspace, void* stream);
+/* torch.optim.Adam step (trainer_SID.py:44,101) over a flat parameter buffer; step is 1-based;
+ * grad_scale is applied to g first (1/world_size after a sum all-reduce). */
+int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                       float beta2, float eps, int step, float grad_scale, void* stream);
 
 #ifdef __cplusplus
 }

@@ -120,8 +120,11 @@ static float poisson(float lam, uint32_t elem, const ctx_t* c, uint32_t r0, uint
 }
 
 static float tukey(float u, float lam) {
-    if (lam == 0.f) return logf(u / (1.f - u));
-    return (powf(u, lam) - powf(1.f - u, lam)) / lam;
+    /* Tukey-lambda quantile (u^lam - (1-u)^lam)/lam (scipy.stats.tukeylambda ppf), written
+       with expm1 so small |lam| does not cancel catastrophically in float32 */
+    const float lu = logf(u), l1u = log1pf(-u);
+    if (lam == 0.f) return lu - l1u;
+    return (expm1f(lam * lu) - expm1f(lam * l1u)) / lam;
 }
 
 /* y, out: [B][C][H][W]; params: [B][NPARAM].  Mirrors pnnp_noise_sample_f32 (include/pnnp_hip.h). */
@@ -179,6 +182,8 @@ void pnnp_oracle_noise_sample(const float* y, float* out, int B, int C, int H, i
                     float z = acc / span;
                     z = z < lo ? lo : (z > 1.f ? 1.f : z);
                     if (!(flags & F_ORI)) z = z * ratio;
+                    if (flags & 0x4000u) z = z < 0.f ? 0.f : z;    /* trainer_SID.py:481-485 clamp */
+                    if (flags & 0x2000u) z = z > 1.f ? 1.f : z;
                     out[i] = z;
                 }
             }

@@ -1,0 +1,307 @@
+"""UNetSeeInDark on hand-written HIP kernels (reference: archs/Unet.py:4-99).
+
+The module keeps the reference's constructor (``args`` dict), attribute names and
+``state_dict`` layout (46 tensors, ``conv{1..9}_{1,2}``, ``upv{6..9}``, ``conv10_1``) so
+released checkpoints load unchanged and ``initialize_weights`` / ``load_weights`` work on
+it.  The nn.Conv2d / nn.ConvTranspose2d children only own parameters: ``forward`` runs the
+whole network through libpnnp_hip.so (NHWC fp32 activations, fp32 MFMA) and backward is a
+hand-sequenced pass over the same kernels, exposed to autograd as one Function so
+``loss.backward(); optimizer.step()`` of the reference trainer works as is.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import PnnpError
+
+LRELU, RELU = 1, 2
+
+
+class FlatParams:
+    """All parameters (and their gradients) of a module as views of two flat fp32 buffers,
+    16-byte aligned per tensor: one fused Adam launch and one (bucketed) all-reduce."""
+
+    def __init__(self, module):
+        self.module = module
+        self.flat = None
+        self.grad = None
+        self.slices = {}
+
+    def ensure(self, device):
+        ps = list(self.module.named_parameters())
+        ok = self.flat is not None and self.flat.device == device and all(
+            p.data_ptr() == self.flat.data_ptr() + 4 * self.slices[n][0] for n, p in ps)
+        if ok:
+            return
+        off = 0
+        self.slices = {}
+        for n, p in ps:
+            self.slices[n] = (off, p.numel())
+            off += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(off, dtype=torch.float32, device=device)
+        grad = torch.zeros(off, dtype=torch.float32, device=device)
+        for n, p in ps:
+            o, k = self.slices[n]
+            flat[o:o + k].copy_(p.data.reshape(-1).to(device=device, dtype=torch.float32))
+            p.data = flat[o:o + k].view(p.shape)
+            p.grad = None
+        self.flat, self.grad = flat, grad
+
+    def grad_view(self, name, shape):
+        o, k = self.slices[name]
+        return self.grad[o:o + k].view(shape)
+
+
+class _Bufs:
+    """Activation / gradient buffers for one input shape, allocated once and reused."""
+
+    def __init__(self):
+        self.t = {}
+
+    def get(self, name, shape, device):
+        b = self.t.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
+            b = torch.empty(shape, dtype=torch.float32, device=device)
+            self.t[name] = b
+        return b
+
+
+class UNetEngine:
+    """Forward / backward schedule of UNetSeeInDark over the C-ABI layer kernels."""
+
+    def __init__(self, module):
+        self.m = module
+        self.params = FlatParams(module)
+        self.bufs = {}
+        self.packed = {}
+        self.saved = None
+        nf = module.nf
+        self.ch = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        if nf % 8:
+            raise PnnpError('UNetSeeInDark on HIP needs nf % 8 == 0')
+        self.cin = module.in_nc * module.nframes
+        self.cin_pad = (self.cin + 7) // 8 * 8
+        self.cout = module.out_nc
+        self.cout_pad = (self.cout + 7) // 8 * 8
+
+    # ------------------------------------------------------------------ weights
+    def _conv_names(self):
+        return ['conv%d_%d' % (i, j) for i in range(1, 10) for j in (1, 2)] + ['conv10_1']
+
+    def pack_weights(self, need_dgrad):
+        """Re-pack every layer's weights into the kernels' K-major order (device side,
+        a few tiny launches); called once per forward because the optimiser has moved them."""
+        dev = self.params.flat.device
+        P = dict(self.m.named_parameters())
+        for name in self._conv_names():
+            w = P[name + '.weight']
+            co, ci, kh, kw = w.shape
+            taps = kh * kw
+            cip = self.cin_pad if name == 'conv1_1' else ci
+            cop = self.cout_pad if name == 'conv10_1' else co
+            key = (name, dev)
+            if key not in self.packed:
+                self.packed[key] = (torch.empty(taps * cip * co, dtype=torch.float32, device=dev),
+                                    torch.empty(taps * cop * ci, dtype=torch.float32, device=dev))
+            f, d = self.packed[key]
+            ops.pack_conv_weight(w, f, d if need_dgrad else None, cin_pad=cip, cout_pad=cop)
+        for name in ('upv6', 'upv7', 'upv8', 'upv9'):
+            w = P[name + '.weight']
+            key = (name, dev)
+            if key not in self.packed:
+                self.packed[key] = (torch.empty(w.numel(), dtype=torch.float32, device=dev),
+                                    torch.empty(w.numel(), dtype=torch.float32, device=dev))
+            f, d = self.packed[key]
+            ops.pack_convt_weight(w, f, d if need_dgrad else None)
+
+    def _w(self, name):
+        return self.packed[(name, self.params.flat.device)]
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, train):
+        if not x.is_cuda:
+            raise PnnpError('UNetSeeInDark.forward: input must be a CUDA tensor (pnnp_amd has no CPU path)')
+        x = x.contiguous().float()
+        B, Cin, H, W = x.shape
+        if Cin != self.cin or H % 16 or W % 16:
+            raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
+        dev = x.device
+        self.params.ensure(dev)
+        self.pack_weights(need_dgrad=train)
+        bufs = self.bufs.setdefault((B, H, W, dev), _Bufs())
+        P = dict(self.m.named_parameters())
+        ch = self.ch
+        g = lambda n, s: bufs.get(n, s, dev)
+        a = {}
+        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad)
+
+        def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
+            y = out if out is not None else g(name, (B, h, w, cout))
+            return ops.conv_fwd(src, src2, self._w(name)[0], P[name + '.bias'], y, cout, taps, act)
+
+        hs = [H >> i for i in range(5)]
+        ws = [W >> i for i in range(5)]
+        cur = a['x8']
+        for lvl in range(5):               # encoder: conv{l}_1, conv{l}_2, pool
+            i = lvl + 1
+            a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
+            a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
+            if lvl < 4:
+                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])))
+                cur = a[f'p{i}']
+        cur = a['c5']
+        for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
+            lvl = 9 - i
+            u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
+            a[f'u{i}'] = u
+            a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
+            a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
+            cur = a[f'c{i}']
+        o = conv('conv10_1', a['c9'], None, H, W, self.cout, act=0, taps=1, out=g('o', (B, H, W, self.cout)))
+        out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
+        if train:
+            self.saved = (a, (B, H, W, dev))
+        return out
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, g_out8, need_dx=False, accumulate=False, on_ready=None):
+        """g_out8: dL/d(out) as NHWC [B,H,W,cout_pad] (zero padded).  Fills the flat gradient
+        buffer.  ``on_ready(offset)`` is called as soon as flat_grad[offset:] is final (layers
+        finish in exactly the reverse of the flat parameter order) so a data-parallel reducer
+        can start all-reducing the tail while the rest of the backward pass still runs."""
+        a, (B, H, W, dev) = self.saved
+        bufs = self.bufs[(B, H, W, dev)]
+        ch = self.ch
+        gb = lambda n, s: bufs.get('g_' + n, s, dev)
+        G = self.params.grad_view
+        P = dict(self.m.named_parameters())
+        acc = 1 if accumulate else 0
+        hs = [H >> i for i in range(5)]
+        ws = [W >> i for i in range(5)]
+        wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, W),), dev)
+
+        def done(name):
+            if on_ready is not None:
+                on_ready(self.params.slices[name + '.weight'][0])
+
+        def wgrad(name, gpre, cout, x1, c1, x2=None, taps=9):
+            ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
+                                G(name + '.bias', (cout,)), taps, wsf, accumulate=acc)
+            done(name)
+
+        # conv10_1 (1x1, no activation); its input c9 is a LeakyReLU output
+        wgrad('conv10_1', g_out8, self.cout, a['c9'], ch[0], taps=1)
+        g_cur = gb('c9', a['c9'].shape)
+        ops.conv_bwd_data(g_out8, self._w('conv10_1')[1], g_cur, mask1=a['c9'], mode1=LRELU, taps=1)
+        for i in range(9, 5, -1):          # decoder, top-down
+            lvl = 9 - i
+            wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
+            g_a = gb(f'c{i}a', a[f'c{i}a'].shape)
+            ops.conv_bwd_data(g_cur, self._w(f'conv{i}_2')[1], g_a, mask1=a[f'c{i}a'], mode1=LRELU)
+            skip = a[f'c{lvl + 1}']
+            wgrad(f'conv{i}_1', g_a, ch[lvl], a[f'u{i}'], ch[lvl], x2=skip)
+            g_u = gb(f'u{i}', a[f'u{i}'].shape)
+            g_skip = gb(f'c{lvl + 1}', skip.shape)
+            ops.conv_bwd_data(g_a, self._w(f'conv{i}_1')[1], g_u, dx2=g_skip, mask2=skip, mode2=LRELU)
+            below = a['c5'] if i == 6 else a[f'c{i - 1}']
+            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc)
+            ops.channel_sum(g_u, G(f'upv{i}.bias', (ch[lvl],)), wsf, accumulate=acc)
+            done(f'upv{i}')
+            g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
+            ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
+        dx = None
+        for i in range(5, 0, -1):          # encoder, bottom-up
+            lvl = i - 1
+            wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
+            g_a = gb(f'c{i}a', a[f'c{i}a'].shape)
+            ops.conv_bwd_data(g_cur, self._w(f'conv{i}_2')[1], g_a, mask1=a[f'c{i}a'], mode1=LRELU)
+            if i > 1:
+                src = a[f'p{i - 1}']
+                wgrad(f'conv{i}_1', g_a, ch[lvl], src, ch[lvl - 1])
+                g_p = gb(f'p{i - 1}', src.shape)
+                ops.conv_bwd_data(g_a, self._w(f'conv{i}_1')[1], g_p)
+                g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
+                ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1)
+            else:
+                wgrad('conv1_1', g_a, ch[0], a['x8'], self.cin)
+                if need_dx:
+                    raise PnnpError('gradient w.r.t. the network input is not implemented on the HIP path')
+        return dx
+
+    def _ws_floats(self, B, H, W):
+        ch = self.ch
+        need = 256 * max(ch)
+        for lvl in range(5):
+            h, w = H >> lvl, W >> lvl
+            c = ch[lvl]
+            cin = self.cin if lvl == 0 else ch[lvl - 1]
+            need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, cin, 9),
+                       ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9))
+            if lvl < 4:
+                need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lvl + 1], c, 4))
+        need = max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
+        return need
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine, train, *params):
+        # autograd.Function.forward runs with grad mode off: `train` is decided by the caller
+        ctx.engine = engine
+        ctx.x_needs = x.requires_grad
+        return engine.forward(x, train)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e = ctx.engine
+        if e.saved is None:
+            raise PnnpError('backward without a training-mode forward')
+        B, _, H, W = grad_out.shape
+        bufs = e.bufs[(B, H, W, grad_out.device)]
+        g8 = ops.nchw_to_nhwc(grad_out.contiguous().float(), bufs.get('g_out8', (B, H, W, e.cout_pad), grad_out.device), e.cout_pad)
+        e.backward(g8, need_dx=ctx.x_needs)
+        # autograd may keep (or accumulate in place into) what we return, and the flat buffer
+        # is overwritten by the next backward: hand out copies on this compatibility path
+        grads = []
+        for n, p in e.m.named_parameters():
+            grads.append(e.params.grad_view(n, p.shape).clone() if p.requires_grad else None)
+        return (None, None, None) + tuple(grads)
+
+
+class UNetSeeInDark(nn.Module):
+    """Drop-in for archs/Unet.py:4-99 (same ``args`` keys: nframes, res, nf, in_nc, out_nc)."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.nframes = args['nframes']
+        self.cf = args['nframes'] // 2
+        self.res = args['res']
+        nf = self.nf = args['nf']
+        self.in_nc = args['in_nc']
+        self.out_nc = args['out_nc']
+        c = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        prev = self.in_nc * self.nframes
+        for lvl in range(5):
+            setattr(self, f'conv{lvl + 1}_1', nn.Conv2d(prev, c[lvl], kernel_size=3, stride=1, padding=1))
+            setattr(self, f'conv{lvl + 1}_2', nn.Conv2d(c[lvl], c[lvl], kernel_size=3, stride=1, padding=1))
+            prev = c[lvl]
+        for i in range(6, 10):
+            lvl = 9 - i
+            setattr(self, f'upv{i}', nn.ConvTranspose2d(c[lvl + 1], c[lvl], 2, stride=2))
+            setattr(self, f'conv{i}_1', nn.Conv2d(c[lvl + 1], c[lvl], kernel_size=3, stride=1, padding=1))
+            setattr(self, f'conv{i}_2', nn.Conv2d(c[lvl], c[lvl], kernel_size=3, stride=1, padding=1))
+        self.conv10_1 = nn.Conv2d(nf, self.out_nc, kernel_size=1, stride=1)
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            object.__setattr__(self, '_engine', UNetEngine(self))
+        return self._engine
+
+    def forward(self, x):
+        params = list(self.parameters())
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _UNetFn.apply(x, self.engine, train, *params)

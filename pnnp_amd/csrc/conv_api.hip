@@ -1,0 +1,149 @@
+// C-ABI entry points of the convolution stack: weight re-packing and the named
+// forward / backward-data operations built on the implicit-GEMM kernel (conv_igemm.hip).
+#include "igemm.h"
+
+int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s);
+
+namespace {
+
+// dst[((t*K/4 + k/4)*N + n)*4 + k%4] = src[off + k*sk + n*sn + tap(t)*st],  tap(t) = flip ? T-1-t : t
+// rows k >= Kvalid are zero (channel padding of the 4-channel network input / output).
+__global__ void __launch_bounds__(256)
+pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int K, int N,
+                    int64_t sk, int64_t sn, int64_t st, int64_t off, int flip, int Kvalid) {
+    const int64_t total = (int64_t)T * K * N;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int kr = (int)(i & 3);
+        int64_t r = i >> 2;
+        const int n = (int)(r % N); r /= N;
+        const int kq = (int)(r % (K >> 2));
+        const int t = (int)(r / (K >> 2));
+        const int k = kq * 4 + kr;
+        const int ts = flip ? T - 1 - t : t;
+        dst[i] = k < Kvalid ? src[off + k * sk + n * sn + ts * st] : 0.f;
+    }
+}
+
+int pack_launch(const float* src, float* dst, int T, int K, int N, int64_t sk, int64_t sn, int64_t st, int64_t off,
+                int flip, void* stream, int Kvalid = 1 << 30) {
+    if (!src || !dst || T <= 0 || K <= 0 || N <= 0 || (K & 3)) return PNNP_E_INVALID;
+    const int64_t total = (int64_t)T * K * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, T, K, N, sk, sn, st, off, flip, Kvalid);
+    return pnnp_launch_status();
+}
+
+void base_args(IgemmArgs& a) {
+    a = IgemmArgs{};
+    a.in_mul = 1; a.out_mul = 1;
+    a.n_split = 1 << 30;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Conv2d weight [Cout][Cin][kh][kw] (kh*kw = taps: 9 or 1)
+//   forward pack  [tap][Cin/4][Cout][4]                      (K = Cin, N = Cout)
+//   dgrad pack    [tap'][Cout/4][Cin][4], tap' = taps-1-tap  (K = Cout, N = Cin; flipped kernel)
+//   Cin_pad / Cout_pad (>= Cin / Cout, multiples of 4): K rows beyond the real channel count are
+//   zero, so the 4-channel network input / output can travel as 8-channel NHWC tensors.
+int pnnp_pack_conv_weight_f32(const float* w, float* fwd, float* dgrad, int Cout, int Cin, int taps,
+                              int Cin_pad, int Cout_pad, void* stream) {
+    if (Cin_pad < Cin || Cout_pad < Cout) return PNNP_E_INVALID;
+    int rc = PNNP_OK;
+    if (fwd) rc = pack_launch(w, fwd, taps, Cin_pad, Cout, taps, (int64_t)Cin * taps, 1, 0, 0, stream, Cin);
+    if (rc == PNNP_OK && dgrad) rc = pack_launch(w, dgrad, taps, Cout_pad, Cin, (int64_t)Cin * taps, taps, 1, 0, 1, stream, Cout);
+    return rc;
+}
+
+// ConvTranspose2d weight [Cin][Cout][2][2]
+//   forward pack  4 slices s=(a,c): [s][Cin/4][Cout][4]              (per slice K = Cin, N = Cout)
+//   dgrad pack    [(s*Cout + co)/4][Cin][4]                          (K = 4*Cout, N = Cin)
+int pnnp_pack_convt_weight_f32(const float* w, float* fwd, float* dgrad, int Cin, int Cout, void* stream) {
+    int rc = PNNP_OK;
+    for (int s = 0; s < 4 && rc == PNNP_OK; ++s) {
+        if (fwd) rc = pack_launch(w, fwd + (int64_t)s * Cin * Cout, 1, Cin, Cout, (int64_t)Cout * 4, 4, 0, s, 0, stream);
+        if (rc == PNNP_OK && dgrad)
+            rc = pack_launch(w, dgrad + (int64_t)s * Cout * Cin, 1, Cout, Cin, 4, (int64_t)Cout * 4, 0, s, 0, stream);
+    }
+    return rc;
+}
+
+// y = act(conv3x3(cat[x1, x2]) + bias)    archs/Unet.py:55-92 ; NHWC fp32, pad 1, stride 1.
+//   x2 may be null (C2 = 0).  taps = 9 (3x3) or 1 (1x1).  act: 0 none, 1 LeakyReLU(0.2), 2 ReLU.
+//   residual (optional, NHWC [B][H][W][Cout]) is added before the activation.
+int pnnp_conv_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* w_packed, const float* bias,
+                      const float* residual, float* y, int B, int H, int W, int Cout, int taps, int act, void* stream) {
+    if (!x1 || !w_packed || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    a.seg[0] = IgemmSeg{x1, C1, 0, 0, 0};
+    a.nseg = 1;
+    if (x2) { a.seg[1] = IgemmSeg{x2, C2, 0, 0, 0}; a.nseg = 2; }
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = w_packed; a.Ntot = Cout;
+    a.dst[0] = y; a.dst_cs[0] = Cout;
+    a.bias = bias; a.act = act; a.addsrc = residual;
+    return pnnp_igemm_launch(a, taps, C1, as_stream(stream));
+}
+
+// backward-data of the layer above: g = dL/d(pre-activation output) [B][H][W][Cout] ->
+//   dx1 [..][C1] (and dx2 [..][C2] for a concat layer).  Each destination may be multiplied by the
+//   activation derivative of the tensor that produced it (mask = that saved activation,
+//   mode 1 LeakyReLU', 2 ReLU') and may accumulate (+=).  w_dgrad from pnnp_pack_conv_weight_f32.
+int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
+                           float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                           float* dx2, int C2, const float* mask2, int mode2, int accum2,
+                           int B, int H, int W, int taps, void* stream) {
+    if (!g || !w_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = w_dgrad; a.Ntot = C1 + (dx2 ? C2 : 0);
+    a.dst[0] = dx1; a.dst_cs[0] = C1; a.mask[0] = mask1; a.mask_mode[0] = mask1 ? mode1 : 0; a.accum[0] = accum1;
+    if (dx2) {
+        a.n_split = C1;                              // destination is chosen per output column (lane)
+        a.dst[1] = dx2; a.dst_cs[1] = C2; a.mask[1] = mask2; a.mask_mode[1] = mask2 ? mode2 : 0; a.accum[1] = accum2;
+    }
+    return pnnp_igemm_launch(a, taps, Cout, as_stream(stream));
+}
+
+// ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47
+//   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  four 1x1 GEMMs, one per output sub-pixel (a,c).
+int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
+                          int B, int H, int W, int Cout, void* stream) {
+    if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    for (int s = 0; s < 4; ++s) {
+        IgemmArgs a; base_args(a);
+        a.seg[0] = IgemmSeg{x, Cin, 0, 0, 0};
+        a.nseg = 1;
+        a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W;
+        a.OH = 2 * H; a.OW = 2 * W; a.out_mul = 2; a.out_yoff = s >> 1; a.out_xoff = s & 1;
+        a.w = w_packed + (int64_t)s * Cin * Cout; a.Ntot = Cout;
+        a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias;
+        const int rc = pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
+        if (rc != PNNP_OK) return rc;
+    }
+    return PNNP_OK;
+}
+
+// backward-data of ConvTranspose2d: g [B][2H][2W][Cout] -> dx [B][H][W][Cin] (x act'(mask))
+int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, float* dx, int Cin,
+                               const float* mask, int mode, int B, int H, int W, void* stream) {
+    if (!g || !w_dgrad || !dx || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    for (int s = 0; s < 4; ++s) a.seg[s] = IgemmSeg{g, Cout, 0, s >> 1, s & 1};
+    a.nseg = 4; a.in_mul = 2;
+    a.IH = 2 * H; a.IW = 2 * W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = w_dgrad; a.Ntot = Cin;
+    a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+    return pnnp_igemm_launch(a, 1, Cout, as_stream(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// HBM-bound companions of the convolution stack: layout changes at the network boundary,
+// 2x2 max-pool (forward / backward fused with the LeakyReLU derivative), the clamp + L1 loss
+// with its gradient, channel sums (bias gradients) and a fused Adam step.
+//   reference: archs/Unet.py:57-69 (MaxPool2d(2)), trainer_SID.py:99 (L1 on pred.clamp(0,1)),
+//   losses/__init__.py:4-15 (PSNR_Loss), trainer_SID.py:44,101 (Adam).
+#include "common.h"
+
+namespace {
+
+int grid1d(int64_t n, int cap = 256 * 8) {
+    int64_t b = (n + 255) / 256;
+    if (b > cap) b = cap;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// [B][C][H][W] -> [B][H][W][Cp], channels >= C zero-filled (Cp multiple of 4).
+__global__ void __launch_bounds__(256)
+nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int Cp) {
+    const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw * (Cp / 4);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % (Cp / 4));
+        const int64_t p = i / (Cp / 4);
+        const int64_t b = p / hw, s = p % hw;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int c = 4 * cq + k;
+            v[k] = c < C ? src[(b * C + c) * hw + s] : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + p * Cp + 4 * cq) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+}
+
+// [B][H][W][Cp] -> [B][C][H][W] (+ residual NCHW, archs/Unet.py:95-98)
+__global__ void __launch_bounds__(256)
+nhwc_to_nchw_kernel(const float* __restrict__ src, const float* __restrict__ residual, float* __restrict__ dst,
+                    int B, int C, int H, int W, int Cp) {
+    const int64_t hw = (int64_t)H * W, total = (int64_t)B * C * hw;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % hw, bc = i / hw;
+        const int c = (int)(bc % C);
+        const int64_t b = bc / C;
+        float v = src[(b * hw + s) * Cp + c];
+        if (residual) v += residual[i];
+        dst[i] = v;
+    }
+}
+
+// NHWC 2x2 max pool, one thread per 4 channels of one output pixel.
+__global__ void __launch_bounds__(256)
+maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int C) {
+    const int h = H / 2, w = W / 2, cq = C / 4;
+    const int64_t total = (int64_t)B * h * w * cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        int64_t p = i / cq;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int64_t b = p / h;
+        const float* s = x + ((b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + C);
+        const float4 a2 = *reinterpret_cast<const float4*>(s + (int64_t)W * C), a3 = *reinterpret_cast<const float4*>(s + (int64_t)W * C + C);
+        float4 m;
+        m.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x)); m.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
+        m.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z)); m.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
+        *reinterpret_cast<float4*>(y + ((b * h + oy) * w + ox) * C + c) = m;
+    }
+}
+
+// Backward of y = maxpool2(x) where x = act(pre):  gx[pos] (+)= (pos is the window's first max ?
+// gy : 0) * act'(x[pos]).  act_mode 0 none, 1 LeakyReLU(0.2)', 2 ReLU'.  accumulate: the skip
+// connection's gradient is already in gx (it was written by the decoder's backward-data).
+__global__ void __launch_bounds__(256)
+maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, float* __restrict__ gx,
+                   int B, int H, int W, int C, int act_mode, int accumulate) {
+    const int h = H / 2, w = W / 2, cq = C / 4;
+    const int64_t total = (int64_t)B * h * w * cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        int64_t p = i / cq;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int64_t b = p / h;
+        const int64_t base = ((b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const int64_t off[4] = {0, (int64_t)C, (int64_t)W * C, (int64_t)W * C + C};
+        float xv[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(x + base + off[k]);
+            xv[k][0] = t.x; xv[k][1] = t.y; xv[k][2] = t.z; xv[k][3] = t.w;
+        }
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + ((b * h + oy) * w + ox) * C + c);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float o[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int arg = 0; float best = xv[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (xv[k][j] > best) { best = xv[k][j]; arg = k; }   // first max wins
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float d = 1.f;
+                if (act_mode == 1) d = xv[k][j] > 0.f ? 1.f : 0.2f;
+                else if (act_mode == 2) d = xv[k][j] > 0.f ? 1.f : 0.f;
+                o[k][j] = (k == arg) ? g[j] * d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4* d = reinterpret_cast<float4*>(gx + base + off[k]);
+            float4 v = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+            if (accumulate) { const float4 t = *d; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            *d = v;
+        }
+    }
+}
+
+// per-channel sum over pixels of an NHWC tensor: partial[blockIdx][C] then a fixed-order finish
+__global__ void __launch_bounds__(256)
+channel_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t npix, int C) {
+    // thread t owns channel (t % C) when C <= 256, striding pixels by 256/C per block step
+    const int lanes_per_pix = C < 256 ? C : 256;
+    const int pix_per_iter = 256 / lanes_per_pix;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+        const int c = c0 + threadIdx.x % lanes_per_pix;
+        float s = 0.f;
+        for (int64_t p = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / lanes_per_pix; p < npix;
+             p += (int64_t)gridDim.x * pix_per_iter)
+            if (c < C) s += x[p * C + c];
+        __shared__ float red[256];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < lanes_per_pix && c < C) {
+            float t = 0.f;
+            for (int k = 0; k < pix_per_iter; ++k) t += red[k * lanes_per_pix + threadIdx.x];
+            partial[(int64_t)blockIdx.x * C + c] = t;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void __launch_bounds__(256)
+rows_sum_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows, int C, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// L1 on clamp(pred,0,1) vs hr, NCHW in; gradient written NHWC with Cp channels (padding zero).
+// partial[block] = {sum |d|, then per-crop SSE is accumulated in sse_partial[block]} ; a block
+// never straddles two crops (grid = B x blocks_per_crop).
+__global__ void __launch_bounds__(256)
+l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, float* __restrict__ grad_nhwc,
+                float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop) {
+    const int b = blockIdx.x / blocks_per_crop, blk = blockIdx.x % blocks_per_crop;
+    float l1 = 0.f, sse = 0.f;
+    for (int64_t s = (int64_t)blk * 256 + threadIdx.x; s < hw; s += (int64_t)blocks_per_crop * 256) {
+        float g[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) g[k] = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const int64_t i = ((int64_t)b * C + c) * hw + s;
+            const float p = pred[i], t = hr[i];
+            const float pc = fminf(fmaxf(p, 0.f), 1.f);
+            const float d = pc - t;
+            l1 += fabsf(d);
+            const float tc = fminf(fmaxf(t, 0.f), 1.f);          // PSNR uses clamped hr (trainer_SID.py:112-114)
+            sse += (pc - tc) * (pc - tc);
+            const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+            if (c < 8) g[c] = (p >= 0.f && p <= 1.f) ? sgn * inv_n : 0.f;   // clamp passes grad on [0,1]
+        }
+        if (grad_nhwc) {
+            float* d = grad_nhwc + ((int64_t)b * hw + s) * Cp;
+            *reinterpret_cast<float4*>(d) = make_float4(g[0], g[1], g[2], g[3]);
+            if (Cp >= 8) *reinterpret_cast<float4*>(d + 4) = make_float4(g[4], g[5], g[6], g[7]);
+        }
+    }
+    __shared__ float r1[256], r2[256];
+    r1[threadIdx.x] = l1; r2[threadIdx.x] = sse;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) { r1[threadIdx.x] += r1[threadIdx.x + k]; r2[threadIdx.x] += r2[threadIdx.x + k]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = r1[0]; partial[2 * blockIdx.x + 1] = r2[0]; }
+}
+
+// out[0] = mean L1 over the batch; out[1 + b] = SSE of crop b
+__global__ void l1_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int blocks_per_crop, float inv_n) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float tot = 0.f;
+    for (int b = 0; b < B; ++b) {
+        float l = 0.f, s = 0.f;
+        for (int k = 0; k < blocks_per_crop; ++k) { l += partial[2 * (b * blocks_per_crop + k)]; s += partial[2 * (b * blocks_per_crop + k) + 1]; }
+        tot += l; out[1 + b] = s;
+    }
+    out[0] = tot * inv_n;
+}
+
+// torch.optim.Adam (defaults, no weight decay / amsgrad), one flat launch over all parameters.
+// grad_scale multiplies g first (1/world_size after a sum all-reduce).
+__global__ void __launch_bounds__(256)
+adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, int64_t n,
+            float lr, float b1, float b2, float eps, float bc1, float bc2_sqrt, float grad_scale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 P = reinterpret_cast<float4*>(p)[i], G = reinterpret_cast<const float4*>(g)[i];
+        float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
+        float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float gk = gg[k] * grad_scale;
+            mm[k] = mm[k] + (gk - mm[k]) * (1.f - b1);                // exp_avg.lerp_(grad, 1-beta1)
+            vv[k] = vv[k] * b2 + (1.f - b2) * gk * gk;               // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+            const float denom = sqrtf(vv[k]) / bc2_sqrt + eps;
+            pp[k] = pp[k] - (lr / bc1) * (mm[k] / denom);
+        }
+        reinterpret_cast<float4*>(p)[i] = P; reinterpret_cast<float4*>(m)[i] = M; reinterpret_cast<float4*>(v)[i] = V;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (n4 << 2) + threadIdx.x;
+        const float gk = g[i] * grad_scale;
+        m[i] = m[i] + (gk - m[i]) * (1.f - b1);
+        v[i] = v[i] * b2 + (1.f - b2) * gk * gk;
+        p[i] = p[i] - (lr / bc1) * (m[i] / (sqrtf(v[i]) / bc2_sqrt + eps));
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+    if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * H * W * (Cp / 4))), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, Cp);
+    return pnnp_launch_status();
+}
+
+int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+    if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid1d((int64_t)B * C * H * W)), dim3(256), 0, as_stream(stream), src, residual, dst, B, C, H, W, Cp);
+    return pnnp_launch_status();
+}
+
+int pnnp_maxpool2_fwd_f32(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    if (!x || !y || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 3)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream), x, y, B, H, W, C);
+    return pnnp_launch_status();
+}
+
+int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                          int accumulate, void* stream) {
+    if (!x || !gy || !gx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 3)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream),
+                       x, gy, gx, B, H, W, C, act_mode, accumulate);
+    return pnnp_launch_status();
+}
+
+// out[c] (+)= sum over pixels of x[pix][c];  workspace >= 256*C floats
+int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int accumulate, float* workspace, void* stream) {
+    if (!x || !out || !workspace || npix <= 0 || C <= 0 || (C <= 256 && 256 % C)) return PNNP_E_INVALID;
+    const int blocks = 256;
+    hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, workspace, npix, C);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, out, blocks, C, accumulate);
+    return pnnp_launch_status();
+}
+
+// loss_out[0] = mean |clamp(pred,0,1) - hr| (trainer_SID.py:99); loss_out[1+b] = sum_b (clamp(pred)-clamp(hr))^2
+// (PSNR_b = -10 log10(SSE_b / (C*H*W)), losses/__init__.py:4-15).  grad_nhwc (optional): dL/dpred laid out
+// [B][H][W][Cp] for the backward pass.  workspace >= 2 * B * 64 floats.
+int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc, float* loss_out, int B, int C, int H, int W,
+                           int Cp, float* workspace, void* stream) {
+    if (!pred || !hr || !loss_out || !workspace || B <= 0 || C <= 0 || C > 8 || (grad_nhwc && (Cp < C || (Cp != 4 && Cp != 8)))) return PNNP_E_INVALID;
+    const int bpc = 64;
+    const float inv_n = 1.0f / ((float)B * C * H * W);
+    hipLaunchKernelGGL(l1_clamp_kernel, dim3(B * bpc), dim3(256), 0, as_stream(stream), pred, hr, grad_nhwc, workspace, C,
+                       (int64_t)H * W, Cp, inv_n, bpc);
+    hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, loss_out, B, bpc, inv_n);
+    return pnnp_launch_status();
+}
+
+int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                       int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return PNNP_E_INVALID;
+    if ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15) return PNNP_E_INVALID;
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));         // python-float bias corrections
+    const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid1d(n >> 2)), dim3(256), 0, as_stream(stream), p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2s, grad_scale);
+    return pnnp_launch_status();
+}
+
+}  // extern "C"

@@ -83,8 +83,11 @@ __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0
 }
 
 __device__ __forceinline__ float tukey_lambda(float u, float lam) {
-    if (lam == 0.f) return logf(u / (1.f - u));
-    return (powf(u, lam) - powf(1.f - u, lam)) / lam;
+    // (u^lam - (1-u)^lam)/lam, evaluated through expm1 so the cancellation for small |lam|
+    // (the calibrated cameras have |lam| < 0.3) does not amplify rounding
+    const float lu = logf(u), l1u = log1pf(-u);
+    if (lam == 0.f) return lu - l1u;
+    return (expm1f(lam * lu) - expm1f(lam * l1u)) / lam;
 }
 
 __global__ void __launch_bounds__(256)
@@ -182,6 +185,9 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
             float z = __fdiv_rn(acc, span);
             z = fminf(fmaxf(z, lo), 1.f);
             if (!(flags & PNNP_NOISE_ORI)) z = __fmul_rn(z, ratio);
+            // the trainer's clamp of the noisy input (trainer_SID.py:481-485), fused into the store
+            if (flags & PNNP_NOISE_POST_MIN0) z = fmaxf(z, 0.f);
+            if (flags & PNNP_NOISE_POST_MAX1) z = fminf(z, 1.f);
             o[i] = z;
         }
         if (nx == 4 && ((((uintptr_t)(out + base)) & 15) == 0)) {

@@ -167,8 +167,9 @@ int grid_for(int64_t threads) {
 template <typename T>
 int pack_impl(const T* src, int B, int H, int W, int64_t rs, int64_t bs, float* dst, const double* black4,
               double wp, int norm, int clip, void* stream) {
-    if (!src || !dst || !black4 || B < 0 || H < 0 || W < 0 || (H & 1) || (W & 1) || rs < W) return PNNP_E_INVALID;
-    if (B == 0 || H == 0 || W == 0) return PNNP_OK;
+    if (B < 0 || H < 0 || W < 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0 || H == 0 || W == 0) return PNNP_OK;          // empty input: nothing to do (pointers may be null)
+    if (!src || !dst || !black4 || rs < W) return PNNP_E_INVALID;
     PackArgs a;
     for (int i = 0; i < 4; ++i) a.black[i] = black4[i];
     a.wp = wp; a.norm = norm; a.clip = clip;
@@ -186,8 +187,9 @@ int move_impl(const void* src, void* dst, int H, int W, int mode, void* stream) 
 }
 
 int move_dispatch(const void* src, void* dst, int H, int W, int eb, int mode, void* stream) {
-    if (!src || !dst || H < 0 || W < 0 || (H & 1) || ((mode <= 1) && (W & 1))) return PNNP_E_INVALID;
+    if (H < 0 || W < 0 || (H & 1) || ((mode <= 1) && (W & 1))) return PNNP_E_INVALID;
     if (H == 0 || W == 0) return PNNP_OK;
+    if (!src || !dst) return PNNP_E_INVALID;
     switch (eb) {
         case 1: return move_impl<uint8_t>(src, dst, H, W, mode, stream);
         case 2: return move_impl<uint16_t>(src, dst, H, W, mode, stream);
@@ -212,8 +214,9 @@ int pnnp_pack_bayer_f32(const float* src, int B, int H, int W, int64_t rs, int64
 }
 
 int pnnp_unpack_bayer_u16(const float* src, int B, int h, int w, uint16_t* dst, int wp, int bl, void* stream) {
-    if (!src || !dst || B < 0 || h < 0 || w < 0) return PNNP_E_INVALID;
+    if (B < 0 || h < 0 || w < 0) return PNNP_E_INVALID;
     if (B == 0 || h == 0 || w == 0) return PNNP_OK;
+    if (!src || !dst) return PNNP_E_INVALID;
     const int64_t total = (int64_t)B * h * ((w + 3) / 4);
     hipLaunchKernelGGL(unpack_bayer_kernel, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                        src, dst, B, h, w, (float)(wp - bl), (float)bl);

@@ -1,0 +1,128 @@
+"""Thin ctypes wrappers of the layer-level C ABI (include/pnnp_hip.h).  Tensors are CUDA
+fp32; activations NHWC.  No CPU path: every function raises on CPU tensors."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import check, lib, ptr, require_cuda, stream
+
+_i64 = C.c_int64
+
+
+def _prep():
+    L = lib()
+    if not getattr(L, '_pnnp_sigs', False):
+        L.pnnp_wgrad_workspace_floats.restype = C.c_int64
+        L._pnnp_sigs = True
+    return L
+
+
+def pack_conv_weight(w, fwd, dgrad, cin_pad=None, cout_pad=None):
+    co, ci, kh, kw = w.shape
+    check(_prep().pnnp_pack_conv_weight_f32(ptr(w), ptr(fwd), ptr(dgrad), co, ci, kh * kw,
+                                            cin_pad or ci, cout_pad or co, stream()), 'pack_conv_weight')
+
+
+def pack_convt_weight(w, fwd, dgrad):
+    ci, co = w.shape[:2]
+    check(_prep().pnnp_pack_convt_weight_f32(ptr(w), ptr(fwd), ptr(dgrad), ci, co, stream()), 'pack_convt_weight')
+
+
+def conv_fwd(x1, x2, w_packed, bias, y, cout, taps, act, residual=None):
+    require_cuda(x1, x2, w_packed, y)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    check(_prep().pnnp_conv_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_packed), ptr(bias), ptr(residual), ptr(y),
+                                    B, H, W, cout, taps, act, stream()), 'conv_fwd')
+    return y
+
+
+def conv_bwd_data(g, w_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask2=None, mode2=0, accum2=0, taps=9):
+    require_cuda(g, w_dgrad, dx1)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]
+    C2 = dx2.shape[3] if dx2 is not None else 0
+    check(_prep().pnnp_conv_bwd_data_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
+                                         ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
+
+
+def wgrad_workspace_floats(B, H, W, M, N, taps):
+    return int(_prep().pnnp_wgrad_workspace_floats(B, H, W, M, N, taps))
+
+
+def conv_bwd_weight(g, cout, x1, c1, x2, dW, dbias, taps, ws, accumulate=0):
+    """g [B,H,W,>=cout] (first ``cout`` channels used), x1 [B,H,W,>=c1], x2 [B,H,W,C2] or None."""
+    require_cuda(g, x1, dW, ws)
+    B, H, W, gcs = g.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    check(_prep().pnnp_conv_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), C2, C2, ptr(dW), ptr(dbias),
+                                           B, H, W, taps, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv_bwd_weight')
+
+
+def convt_fwd(x, w_packed, bias, y, cout):
+    require_cuda(x, w_packed, y)
+    B, H, W, Cin = x.shape
+    check(_prep().pnnp_convt2x2_fwd_f32(ptr(x), Cin, ptr(w_packed), ptr(bias), ptr(y), B, H, W, cout, stream()), 'convt_fwd')
+    return y
+
+
+def convt_bwd_data(g, w_dgrad, dx, mask=None, mode=0):
+    require_cuda(g, w_dgrad, dx)
+    B, H, W, Cin = dx.shape
+    check(_prep().pnnp_convt2x2_bwd_data_f32(ptr(g), g.shape[3], ptr(w_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W,
+                                             stream()), 'convt_bwd_data')
+
+
+def convt_bwd_weight(x, g, dW, ws, accumulate=0):
+    require_cuda(x, g, dW, ws)
+    B, H, W, Cin = x.shape
+    check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), None, B, H, W, accumulate,
+                                               ptr(ws), _i64(ws.numel()), stream()), 'convt_bwd_weight')
+
+
+def maxpool_fwd(x, y):
+    require_cuda(x, y)
+    B, H, W, Cc = x.shape
+    check(_prep().pnnp_maxpool2_fwd_f32(ptr(x), ptr(y), B, H, W, Cc, stream()), 'maxpool_fwd')
+    return y
+
+
+def maxpool_bwd(x, gy, gx, act_mode, accumulate):
+    require_cuda(x, gy, gx)
+    B, H, W, Cc = x.shape
+    check(_prep().pnnp_maxpool2_bwd_f32(ptr(x), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd')
+
+
+def nchw_to_nhwc(src, dst, cp):
+    require_cuda(src, dst)
+    B, Cc, H, W = src.shape
+    check(_prep().pnnp_nchw_to_nhwc_f32(ptr(src), ptr(dst), B, Cc, H, W, cp, stream()), 'nchw_to_nhwc')
+    return dst
+
+
+def nhwc_to_nchw(src, dst, residual=None):
+    require_cuda(src, dst, residual)
+    B, Cc, H, W = dst.shape
+    check(_prep().pnnp_nhwc_to_nchw_f32(ptr(src), ptr(residual), ptr(dst), B, Cc, H, W, src.shape[3], stream()), 'nhwc_to_nchw')
+    return dst
+
+
+def channel_sum(x, out, ws, accumulate=0):
+    require_cuda(x, out, ws)
+    Cc = x.shape[-1]
+    check(_prep().pnnp_channel_sum_f32(ptr(x), ptr(out), _i64(x.numel() // Cc), Cc, accumulate, ptr(ws), stream()), 'channel_sum')
+
+
+def l1_clamp_loss(pred, hr, grad_nhwc, loss_out, ws):
+    require_cuda(pred, hr, loss_out, ws)
+    B, Cc, H, W = pred.shape
+    cp = grad_nhwc.shape[3] if grad_nhwc is not None else 0
+    check(_prep().pnnp_l1_clamp_loss_f32(ptr(pred), ptr(hr), ptr(grad_nhwc), ptr(loss_out), B, Cc, H, W, cp, ptr(ws),
+                                         stream()), 'l1_clamp_loss')
+
+
+def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    require_cuda(p, g, m, v)
+    check(_prep().pnnp_adam_step_f32(ptr(p), ptr(g), ptr(m), ptr(v), _i64(p.numel()), C.c_float(lr), C.c_float(beta1),
+                                     C.c_float(beta2), C.c_float(eps), int(step), C.c_float(grad_scale), stream()), 'adam_step')

@@ -186,6 +186,7 @@ def sample_params(camera_type='NikonD850', ln_ratio=False):
 # ---------------------------------------------------------------------------- device sampler
 _FLAG = dict(p=0x01, g=0x02, r=0x04, q=0x08, d=0x10, b=0x20)
 F_ORI, F_CLIP, F_TORCH = 0x100, 0x200, 0x1000
+F_POST_MAX1, F_POST_MIN0 = 0x2000, 0x4000      # Trainer.preprocess clamp fused into the sampler
 _ORDER = ('K', 'sigGs', 'sigTL', 'lam', 'sigR', 'q', 'ratio', 'wp', 'bl')
 
 

@@ -1,0 +1,175 @@
+"""The training step of the reference (trainer_SID.py:86-102,421-486) as one fused device
+pipeline, and its data-parallel form (one process per GPU, RCCL all-reduce over xGMI).
+
+    per crop: sample_params_max (host scalars) -> noise sampler -> clamp -> UNet forward ->
+    L1(pred.clamp(0,1), hr) -> backward -> [all-reduce of gradients] -> Adam
+
+Everything between the clean crops and the updated weights runs in libpnnp_hip.so; torch
+supplies device memory, streams and the process group only.  The reference's single-process
+``nn.DataParallel`` (base_trainer.py:115-118) is replaced by sharding the crops over ranks:
+rank r owns global crops [r*B, (r+1)*B); the sampler's counter RNG is keyed by the global
+crop index, so the noise does not depend on the number of GPUs.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops, process
+from ._lib import PnnpError
+
+
+def get_cos_lr(step, period=1000, peak=20, lr=1e-4, ratio=0.2):
+    """base_trainer.py:140-149 -- SGDR with warm-up on restarts; returns the absolute lr."""
+    T = step // period
+    s = step % period
+    if s <= peak and T > 0:
+        mul = s / peak
+    else:
+        mul = (1 - ratio) * (np.cos((s - peak) / (period - peak) * math.pi) * 0.5 + 0.5) + ratio
+    return lr * mul / (2 ** T)
+
+
+class BucketedAllReduce:
+    """Sum-all-reduce of a flat gradient buffer in contiguous buckets, launched from the END
+    of the buffer backwards as the backward pass finishes layers (the flat layout is the
+    forward parameter order, the backward pass completes it in exactly the reverse order),
+    on a side stream so RCCL overlaps the remaining backward kernels.
+
+    xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring moves 2(N-1)/N x bytes over
+    one link per direction, ~0.35 ms for the 31 MB of UNet gradients -- a few 8 MB buckets keep
+    each collective bandwidth-bound rather than latency-bound while leaving >= 3 to pipeline."""
+
+    def __init__(self, flat, bucket_bytes=8 << 20, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.flat = flat
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = flat.numel()
+        per = max(1, bucket_bytes // 4)
+        edges = list(range(n, 0, -per))[::-1]            # bucket starts, counted from the end
+        starts = [max(0, e - per) for e in edges]
+        self.buckets = sorted(set(zip(starts, edges)))   # [(start, end)] ascending
+        self.pending = len(self.buckets) - 1             # next bucket to launch (from the end)
+        self.works = []
+        self.cuda = flat.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+
+    def reset(self):
+        self.pending = len(self.buckets) - 1
+        self.works = []
+
+    def ready(self, offset):
+        """Everything at flat[offset:] has its final gradient: launch every bucket that lies
+        entirely in that range."""
+        if self.world == 1:
+            return
+        while self.pending >= 0 and self.buckets[self.pending][0] >= offset:
+            s, e = self.buckets[self.pending]
+            view = self.flat[s:e]
+            if self.cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self.comm_stream.wait_event(ev)
+                with torch.cuda.stream(self.comm_stream):
+                    self.works.append(self.dist.all_reduce(view, group=self.group, async_op=True))
+            else:
+                self.works.append(self.dist.all_reduce(view, group=self.group, async_op=True))
+            self.pending -= 1
+
+    def finish(self):
+        """Launch what is left and make the current stream wait for every bucket."""
+        self.ready(0)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def shard_crops(global_batch, rank, world):
+    """Rank r of `world` owns crops [lo, hi) of a global batch (strong scaling); returns
+    (lo, hi).  Remainders go to the low ranks."""
+    q, r = divmod(global_batch, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+class HipTrainStep:
+    """One optimiser step on a batch of clean crops ``hr`` [B,4,H,W] (CUDA):
+    noise sampler ('camera_type', 'noise_code', 'ori', 'clip' as in the dst section of the
+    YAMLs) -> denoiser -> L1 -> backward -> (all-reduce) -> Adam.  Returns the device tensor
+    ``[loss, sse_0 .. sse_{B-1}]`` without synchronising."""
+
+    def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
+                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20):
+        self.net = net
+        self.engine = net.engine
+        self.lr = lr
+        self.camera_type, self.noise_code, self.ori, self.clip = camera_type, noise_code, ori, clip
+        self.seed = seed
+        self.rank, self.world, self.group = rank, world, group
+        self.bucket_bytes = bucket_bytes
+        self.step_count = 0
+        self.m = self.v = None
+        self.reducer = None
+        self._loss = None
+
+    def _state(self, device):
+        self.engine.params.ensure(device)
+        flat = self.engine.params.flat
+        if self.m is None or self.m.numel() != flat.numel() or self.m.device != device:
+            self.m = torch.zeros_like(flat)
+            self.v = torch.zeros_like(flat)
+        if self.world > 1 and (self.reducer is None or self.reducer.flat is not self.engine.params.grad):
+            self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group)
+
+    def sample_noise_params(self, batch):
+        """trainer_SID.py:451-459: one host-side parameter draw per crop."""
+        return [process.sample_params_max(camera_type=self.camera_type, ratio=None) for _ in range(batch)]
+
+    def make_noisy(self, hr, plist=None, rows=None):
+        """preprocess(): per-crop physics noise on the clean crops, then the trainer's clamp
+        (trainer_SID.py:461,481-485) -- fused into the sampler's store."""
+        B = hr.shape[0]
+        if rows is None:
+            rows = process.pack_params(plist if plist is not None else self.sample_noise_params(B), hr.device)
+        # `clip: 2` (HALF_CLIP) is truthy: generate_noisy_torch clamps to [0,1] before x ratio
+        # (process.py:668), then preprocess clamps the result to (-inf, 1] (trainer_SID.py:483-484)
+        flags = process.noise_flags(self.noise_code, ori=self.ori, clip=bool(self.clip), torch_mode=True)
+        if self.clip:
+            flags |= process.F_POST_MAX1 | (0 if self.clip == process.HALF_CLIP else process.F_POST_MIN0)
+        return process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count,
+                                    crop_base=self.rank * B), rows
+
+    def step(self, hr, plist=None, rows=None, noisy=None, lr=None):
+        if not hr.is_cuda:
+            raise PnnpError('HipTrainStep needs CUDA tensors (no CPU path)')
+        dev = hr.device
+        self._state(dev)
+        e = self.engine
+        B, C, H, W = hr.shape
+        if noisy is None:
+            noisy, _ = self.make_noisy(hr, plist, rows)
+        target = hr.clamp(0, 1) if self.clip else hr        # trainer_SID.py:485 (plumbing)
+        pred = e.forward(noisy, True)
+        bufs = e.bufs[(B, H, W, dev)]
+        g8 = bufs.get('g_out8', (B, H, W, e.cout_pad), dev)
+        loss = bufs.get('loss_out', (1 + B,), dev)
+        lws = bufs.get('loss_ws', (128 * B,), dev)
+        ops.l1_clamp_loss(pred, target, g8, loss, lws)
+        if self.reducer is not None:
+            self.reducer.reset()
+        e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.step_count += 1
+        ops.adam_step(e.params.flat, e.params.grad, self.m, self.v, self.lr if lr is None else lr, self.step_count,
+                      grad_scale=1.0 / self.world)
+        self._loss = loss
+        return loss
+
+    @staticmethod
+    def psnr_from(loss_out, elems_per_crop):
+        """PSNR_Loss (losses/__init__.py:4-15) from the SSE the loss kernel returns."""
+        sse = loss_out[1:].double()
+        return float((-10.0 * torch.log10(sse / elems_per_crop)).mean())

@@ -31,7 +31,8 @@ def _hip(y, plist, flags, mfm=1.0, seed=1997, offset=3, crop_base=0):
 def test_tier_a_vs_c_oracle(code, torch_mode, ori, clip):
     """Same uniforms on both sides; differences come only from libm (log/exp/cos/lgamma)
     rounding, which can flip a Poisson accept/reject at a handful of pixels.
-    Bar: >= 99.9 % of pixels equal to 1e-5 relative, every pixel within 2 Poisson counts."""
+    A flipped rejection draws a fresh, independent Poisson sample for that pixel.
+    Bar: >= 99.9 % of pixels equal to 1e-5 relative; the rest within 10 sqrt(lam)+2 counts."""
     from oracle import cbind
     from pnnp_amd import process as P
     rng = np.random.default_rng(42)
@@ -52,7 +53,9 @@ def test_tier_a_vs_c_oracle(code, torch_mode, ori, clip):
             tol = 1e-5 * np.maximum(np.abs(ref[b]), scale)
             frac = float((d <= tol).mean())
             assert frac >= 0.999, (code, b, mfm, frac)
-            assert d.max() <= 2.0 * p['K'] / mfm * scale + tol.max(), (code, b, d.max())
+            lam = mfm * y[b] * (p['wp'] - p['bl']) / p['ratio'] / p['K']
+            bound = (10 * np.sqrt(np.maximum(lam, 1)) + 2) * p['K'] / mfm * scale + tol
+            assert (d <= bound).all(), (code, b, float((d / bound).max()))
 
 
 def test_determinism_and_counter_semantics():
