@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""Benchmark of the PNNP hot path on MI355X: one TRAIN STEP of BASELINE.json's config
+"PNNP noise-proxy + UNet train step, batch 16x512x512x4":
+
+    per crop: sample_params_max (host scalars) -> physics noise sampler (HIP) -> UNetSeeInDark
+    nf=32 forward -> L1(pred.clamp(0,1), hr) -> backward -> [RCCL all-reduce] -> Adam
+
+Metric: packed raw crops (4x512x512 fp32) per second, whole job (all ranks).  Inputs are
+synthetic clean crops already resident in HBM; weights are random-init (initialize_weights).
+Weak scaling: every rank processes --batch crops per step.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (schema in the task contract) with `roofline` (dominant kernel
+class = the 3x3 implicit-GEMM convolutions, fp32 MFMA, timed with HIP events on the launch
+stream inside the timed region) and `cpu_baseline` (the torch-fp32 oracle port of the same
+step, on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+GFLOP_PER_CROP_TRAIN = 289.70      # fwd + dgrad (no conv1_1) + wgrad, UNet nf=32 @4x512x512
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+
+
+def cpu_baseline(batch, H, W, seconds_hint=20.0):
+    """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py +
+    oracle/noise_np.py), timed on this box's host cores.  Bounded: one step on `batch`
+    crops after a short un-timed warm-up on a 64x64 patch."""
+    import numpy as np
+    import torch
+    from oracle import net_torch as O, noise_np as N
+    cores = min(os.cpu_count() or 1, 32)       # more threads than this slow torch-CPU convs down on big hosts
+    torch.set_num_threads(cores)
+    sd = O.init_state(O.unet_param_shapes(nf=32), seed=0)
+    m = {k: torch.zeros_like(v) for k, v in sd.items()}
+    v = {k: torch.zeros_like(vv) for k, vv in sd.items()}
+    p = dict(K=1.5, sigGs=6.0, sigR=1.0, q=1 / 2 ** 14, ratio=150.0, wp=16383, bl=512, bias=0)
+    pt = {k: torch.tensor(float(val)) for k, val in p.items()}
+
+    def one(b, h, w, step):
+        hr = torch.rand(b, 4, h, w)
+        lr = torch.stack([N.generate_noisy_torch(hr[i], noise_code='pr', param=pt, ori=False, clip=2) for i in range(b)])
+        lr = lr.clamp(max=1.0)
+        return O.train_step(sd, m, v, step, lr, hr, lr=1e-4)
+
+    one(1, 64, 64, 1)
+    t0 = time.perf_counter()
+    one(batch, H, W, 2)
+    dt = time.perf_counter() - t0
+    return {"value": batch / dt, "unit": "crops/s", "cores": cores, "kind": "port",
+            "sample": f"1 train step (sampler 'pr' + UNet nf=32 fwd/L1/bwd/Adam) on {batch} crops of 4x{H}x{W}, torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=16, help='crops per GPU per step')
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline becomes whole-step)')
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as ge
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if not os.path.exists(os.path.join(REPO, 'pnnp_amd', 'libpnnp_hip.so')):
+        if rank == 0:
+            ge.build()
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        dist.barrier()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+
+    from pnnp_amd import ops
+    from pnnp_amd.archs import UNetSeeInDark, initialize_weights
+    from pnnp_amd.trainer import HipTrainStep
+
+    torch.manual_seed(1997)                     # same init on every rank (utils/utils.py:45-48 seeds 1997)
+    net = UNetSeeInDark(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
+    initialize_weights(net)
+    net = net.to(dev)
+    ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
+                      rank=rank, world=world)
+    B, S = args.batch, args.size
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    hr = torch.rand(B, 4, S, S, device=dev, generator=g)          # synthetic clean crops, resident in HBM
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def one_step(step):
+        np.random.seed(1997 + step * world + rank)                # per-crop params from sample_params_max
+        return ts.step(hr)
+
+    for i in range(args.warmup):
+        one_step(i)
+    barrier()
+    if not args.no_kernel_events:
+        ops.PROFILE = []
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss[0])
+
+    if rank == 0:
+        crops = B * world * args.steps
+        value = crops / dt
+        out = {
+            "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params) + UNetSeeInDark nf=32 train step "
+                                   "(fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
+                       "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
+            "final_loss": loss_val,
+        }
+        step_tflops = GFLOP_PER_CROP_TRAIN * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
+        classes = {}
+        if prof:
+            for kind, fl, by, e0, e1 in prof:
+                c = classes.setdefault(kind, [0, 0.0, 0.0, 0.0])
+                c[0] += 1; c[1] += fl; c[2] += by; c[3] += e0.elapsed_time(e1) * 1e-3
+            dom = [k for k in classes if k.startswith('conv9_fwd') or k.startswith('conv9_dgrad')]
+            n = sum(classes[k][0] for k in dom); fl = sum(classes[k][1] for k in dom); sec = sum(classes[k][3] for k in dom)
+            out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "kernel": "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
+                               "launches": n, "avg_launch_ms": 1e3 * sec / n,
+                               "alg_gflop_per_launch": fl / n / 1e9}
+            out["kernel_classes"] = {k: {"launches": v[0], "ms_per_step": 1e3 * v[3] / args.steps,
+                                         "tflops": (v[1] / v[3] / 1e12) if v[3] > 0 else None} for k, v in sorted(classes.items())}
+            out["mfma_time_frac_of_step"] = sum(v[3] for v in classes.values()) / dt
+        else:
+            out["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": step_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": "whole train step"}
+        out["step_tflops_per_gpu"] = step_tflops
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(min(B, 16), S, S)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -9,6 +9,26 @@ from ._lib import check, lib, ptr, require_cuda, stream
 
 _i64 = C.c_int64
 
+# Optional per-launch timing with HIP events on the launching stream (bench.py turns it on):
+# PROFILE = [] collects (kind, algorithmic_flops, algorithmic_bytes, start_event, end_event).
+PROFILE = None
+
+
+class _Timed:
+    def __init__(self, kind, flops=0.0, nbytes=0.0):
+        self.rec = None
+        if PROFILE is not None:
+            self.rec = (kind, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.rec[3].record(torch.cuda.current_stream())
+
+    def __exit__(self, *a):
+        if self.rec is not None:
+            self.rec[4].record(torch.cuda.current_stream())
+            PROFILE.append(self.rec)
+
 
 def _prep():
     L = lib()
@@ -33,8 +53,9 @@ def conv_fwd(x1, x2, w_packed, bias, y, cout, taps, act, residual=None):
     require_cuda(x1, x2, w_packed, y)
     B, H, W, C1 = x1.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    check(_prep().pnnp_conv_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_packed), ptr(bias), ptr(residual), ptr(y),
-                                    B, H, W, cout, taps, act, stream()), 'conv_fwd')
+    with _Timed('conv%d_fwd' % taps, 2.0 * B * H * W * cout * (C1 + C2) * taps, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_packed), ptr(bias), ptr(residual), ptr(y),
+                                        B, H, W, cout, taps, act, stream()), 'conv_fwd')
     return y
 
 
@@ -43,8 +64,9 @@ def conv_bwd_data(g, w_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask
     B, H, W, Cout = g.shape
     C1 = dx1.shape[3]
     C2 = dx2.shape[3] if dx2 is not None else 0
-    check(_prep().pnnp_conv_bwd_data_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
-                                         ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
+    with _Timed('conv%d_dgrad' % taps, 2.0 * B * H * W * Cout * (C1 + C2) * taps, 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv_bwd_data_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
+                                             ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
 
 
 def wgrad_workspace_floats(B, H, W, M, N, taps):
@@ -56,29 +78,33 @@ def conv_bwd_weight(g, cout, x1, c1, x2, dW, dbias, taps, ws, accumulate=0):
     require_cuda(g, x1, dW, ws)
     B, H, W, gcs = g.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    check(_prep().pnnp_conv_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), C2, C2, ptr(dW), ptr(dbias),
-                                           B, H, W, taps, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv_bwd_weight')
+    with _Timed('conv%d_wgrad' % taps, 2.0 * B * H * W * cout * (c1 + C2) * taps, 4.0 * B * H * W * (c1 + C2 + cout)):
+        check(_prep().pnnp_conv_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), C2, C2, ptr(dW), ptr(dbias),
+                                               B, H, W, taps, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv_bwd_weight')
 
 
 def convt_fwd(x, w_packed, bias, y, cout):
     require_cuda(x, w_packed, y)
     B, H, W, Cin = x.shape
-    check(_prep().pnnp_convt2x2_fwd_f32(ptr(x), Cin, ptr(w_packed), ptr(bias), ptr(y), B, H, W, cout, stream()), 'convt_fwd')
+    with _Timed('convt_fwd', 8.0 * B * H * W * Cin * cout, 4.0 * B * H * W * (Cin + 4 * cout)):
+        check(_prep().pnnp_convt2x2_fwd_f32(ptr(x), Cin, ptr(w_packed), ptr(bias), ptr(y), B, H, W, cout, stream()), 'convt_fwd')
     return y
 
 
 def convt_bwd_data(g, w_dgrad, dx, mask=None, mode=0):
     require_cuda(g, w_dgrad, dx)
     B, H, W, Cin = dx.shape
-    check(_prep().pnnp_convt2x2_bwd_data_f32(ptr(g), g.shape[3], ptr(w_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W,
-                                             stream()), 'convt_bwd_data')
+    with _Timed('convt_dgrad', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_bwd_data_f32(ptr(g), g.shape[3], ptr(w_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W,
+                                                 stream()), 'convt_bwd_data')
 
 
 def convt_bwd_weight(x, g, dW, ws, accumulate=0):
     require_cuda(x, g, dW, ws)
     B, H, W, Cin = x.shape
-    check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), None, B, H, W, accumulate,
-                                               ptr(ws), _i64(ws.numel()), stream()), 'convt_bwd_weight')
+    with _Timed('convt_wgrad', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), None, B, H, W, accumulate,
+                                                   ptr(ws), _i64(ws.numel()), stream()), 'convt_bwd_weight')
 
 
 def maxpool_fwd(x, y):
