@@ -146,7 +146,7 @@ int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int
 int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
 int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual /*or null*/, float* dst,
                           int B, int C, int H, int W, int Cp, void* stream);
-/* out[c] (+)= sum over pixels (bias gradient of a ConvTranspose2d); workspace >= 256*C floats */
+/* out[c] (+)= sum over pixels (bias gradient of a ConvTranspose2d); workspace >= 1024*C floats */
 int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int accumulate,
                          float* workspace, void* stream);
 /* loss = mean|clamp(pred,0,1) - hr| (trainer_SID.py:99, losses/base_loss.py:92-107) on NCHW

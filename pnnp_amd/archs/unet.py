@@ -231,7 +231,7 @@ class UNetEngine:
 
     def _ws_floats(self, B, H, W):
         ch = self.ch
-        need = 256 * max(ch)
+        need = 1024 * max(ch)
         for lvl in range(5):
             h, w = H >> lvl, W >> lvl
             c = ch[lvl]

@@ -2,7 +2,14 @@
 // forward and backward-data) -- see igemm.h for the data layout.
 //   reference ops: archs/Unet.py:16-51,54-94 (Conv2d 3x3 pad 1, ConvTranspose2d 2x2 s2,
 //   LeakyReLU(0.2)), archs/ResUnet.py:15-44.
+//
+// Structure: PERSISTENT workgroups (grid = CUs x resident workgroups per CU) walk a flattened
+// list of (output tile, K chunk) work items.  While the MFMAs of item i run out of LDS, the
+// global loads of item i+1 (input halo tile + weight tile) are already in flight into registers
+// and are written to LDS after the barrier that retires item i (issue-early / write-late); the
+// epilogue stores of a finished tile overlap the next tile's loads the same way.
 #include "igemm.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -14,7 +21,9 @@ struct IgemmCfg {
     static constexpr int KQ = KC / 4;
     static constexpr int XS_F4 = KQ * NPIX;            // float4 count of the input tile
     static constexpr int WS_F4 = TAPS * KQ * BN;       // float4 count of the weight tile
-    static constexpr int LDS_BYTES = (XS_F4 + WS_F4) * 16;
+    static constexpr int NA = (XS_F4 + 255) / 256;     // float4 per thread, input tile
+    static constexpr int NB = (WS_F4 + 255) / 256;     // float4 per thread, weight tile
+    static constexpr int LDS_BYTES = (XS_F4 + WS_F4) * 16 + 4 * 4096;
     static_assert(WM * WN == 4, "4 waves per workgroup");
     static_assert(WN * NT * 32 == BN, "N tiling");
     static_assert(KC % 8 == 0, "KC multiple of 8");
@@ -22,19 +31,21 @@ struct IgemmCfg {
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
     // blocks are dealt round-robin over the 8 XCDs: give each XCD a contiguous run of logical
-    // tiles so neighbours (shared halo rows / shared input tile) hit the same L2.  Bijective for any n.
+    // ids so neighbouring tiles (shared halo rows / shared input tile) hit the same L2.  Bijective.
     const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
 template <int TAPS, int KC, int BN, int MT, int NT, int WM, int WN>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 igemm_kernel(const IgemmArgs a) {
     using Cfg = IgemmCfg<TAPS, KC, BN, MT, NT, WM, WN>;
     constexpr int P = Cfg::P, TH = Cfg::TH, HC = Cfg::HC, NPIX = Cfg::NPIX, KQ = Cfg::KQ;
+    constexpr int NA = Cfg::NA, NB = Cfg::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float4* xs = reinterpret_cast<float4*>(smem);
     float4* ws = xs + Cfg::XS_F4;
+    float* epi = reinterpret_cast<float*>(ws + Cfg::WS_F4);     // 4 waves x 32x32 floats (epilogue transpose)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, half = lane >> 5;
@@ -43,13 +54,45 @@ igemm_kernel(const IgemmArgs a) {
     const int tiles_x = (a.DW + 31) >> 5, tiles_y = (a.DH + TH - 1) / TH;
     const int n_tiles = (a.Ntot + BN - 1) / BN;
     const int total = tiles_x * tiles_y * a.B * n_tiles;
-    const int id = xcd_remap(blockIdx.x, total);
-    const int nt_i = id % n_tiles;
-    int m_i = id / n_tiles;
-    const int tx = m_i % tiles_x; m_i /= tiles_x;
-    const int ty = m_i % tiles_y;
-    const int b = m_i / tiles_y;
-    const int x0 = tx * 32, y0 = ty * TH, n0 = nt_i * BN;
+    const int G = gridDim.x;
+    const int nchunks = a.nseg * a.chunks_per_seg;
+    const int K4 = nchunks * KQ;                       // Ktot / 4
+    const float4* w4 = reinterpret_cast<const float4*>(a.w);
+
+    float4 ra[NA], rb[NB];                             // staging registers of the NEXT work item
+
+    // issue the global loads of (tile t, chunk g) into ra / rb (no wait)
+    auto prefetch = [&](int t, int g) {
+        const int nt_i = t % n_tiles;
+        int m_i = t / n_tiles;
+        const int tx = m_i % tiles_x; m_i /= tiles_x;
+        const int ty = m_i % tiles_y;
+        const int b = m_i / tiles_y;
+        const int x0 = tx * 32, y0 = ty * TH, n0 = nt_i * BN;
+        const int si = g / a.chunks_per_seg;
+        const IgemmSeg sg = a.seg[si];
+        const int c0 = sg.coff + (g - si * a.chunks_per_seg) * KC;
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int i = tid + 256 * k;
+            const int cq = i % KQ, pix = i / KQ;
+            const int r = pix / HC, q = pix - r * HC;
+            const int gy = (y0 + r - P) * a.in_mul + sg.yoff, gx = (x0 + q - P) * a.in_mul + sg.xoff;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < Cfg::XS_F4 && gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
+                v = *reinterpret_cast<const float4*>(sg.ptr + (((int64_t)b * a.IH + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq);
+            ra[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + 256 * k;
+            const int n = i % BN, rest = i / BN;
+            const int cq = rest % KQ, tt = rest / KQ;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < Cfg::WS_F4 && n0 + n < a.Ntot) v = w4[((int64_t)tt * K4 + g * KQ + cq) * a.Ntot + n0 + n];
+            rb[k] = v;
+        }
+    };
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -59,38 +102,33 @@ igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = a.nseg * a.chunks_per_seg;
-    const int K4 = nchunks * KQ;                       // Ktot / 4
-    const float4* w4 = reinterpret_cast<const float4*>(a.w);
-
-    for (int g = 0; g < nchunks; ++g) {
-        const int si = g / a.chunks_per_seg;
-        const IgemmSeg sg = a.seg[si];
-        const int c0 = sg.coff + (g - si * a.chunks_per_seg) * KC;
-        if (g) __syncthreads();
-        // ---- stage the input halo tile: xs[cq][pix] <- src[b][gy][gx][c0 + 4cq ..]
-        for (int i = tid; i < Cfg::XS_F4; i += 256) {
-            const int cq = i % KQ, pix = i / KQ;
-            const int r = pix / HC, q = pix - r * HC;
-            const int gy = (y0 + r - P) * a.in_mul + sg.yoff, gx = (x0 + q - P) * a.in_mul + sg.xoff;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
-                v = *reinterpret_cast<const float4*>(sg.ptr + (((int64_t)b * a.IH + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq);
-            xs[cq * NPIX + pix] = v;
+    int t = xcd_remap(blockIdx.x, G);
+    int g = 0;
+    if (t < total) prefetch(t, 0);
+    bool first = true;
+    while (t < total) {
+        if (!first) __syncthreads();                   // every wave is done reading the previous item
+        first = false;
+        // ---- write the staged registers into the LDS images
+#pragma unroll
+        for (int k = 0; k < NA; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Cfg::XS_F4) xs[(i % KQ) * NPIX + i / KQ] = ra[k];
         }
-        // ---- stage the weight tile: ws[t][cq][n] <- w[t][g*KQ + cq][n0 + n]
-        for (int i = tid; i < Cfg::WS_F4; i += 256) {
-            const int n = i % BN, rest = i / BN;
-            const int cq = rest % KQ, t = rest / KQ;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + n < a.Ntot) v = w4[((int64_t)t * K4 + g * KQ + cq) * a.Ntot + n0 + n];
-            ws[i] = v;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Cfg::WS_F4) ws[i] = rb[k];
         }
         __syncthreads();
+        // ---- next work item: its loads fly while this item's MFMAs run
+        int ng = g + 1, nt = t;
+        if (ng == nchunks) { ng = 0; nt = t + G; }
+        if (nt < total) prefetch(nt, ng);
         // ---- MFMA over taps x channel octets
 #pragma unroll
-        for (int t = 0; t < TAPS; ++t) {
-            const int dy = (TAPS == 9) ? t / 3 : 0, dx = (TAPS == 9) ? t % 3 : 0;
+        for (int tp = 0; tp < TAPS; ++tp) {
+            const int dy = (TAPS == 9) ? tp / 3 : 0, dx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
             for (int j = 0; j < KC / 8; ++j) {
                 float4 av[MT], bv[NT];
@@ -99,7 +137,7 @@ igemm_kernel(const IgemmArgs a) {
                     av[i] = xs[(2 * j + half) * NPIX + (wm * MT + i + dy) * HC + dx + l31];
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
-                    bv[i] = ws[(t * KQ + 2 * j + half) * BN + (wn * NT + i) * 32 + l31];
+                    bv[i] = ws[(tp * KQ + 2 * j + half) * BN + (wn * NT + i) * 32 + l31];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -111,74 +149,139 @@ igemm_kernel(const IgemmArgs a) {
                     }
             }
         }
-    }
-
-    // ---- epilogue: C/D layout col = lane&31 (channel), row = (r&3) + 8(r>>2) + 4(lane>>5) (pixel)
+        if (g == nchunks - 1) {
+            // ---- epilogue.  The accumulator has the channel on the lane and 16 pixels in registers
+            // (col = lane&31, row = (r&3) + 8(r>>2) + 4(lane>>5)): storing it directly is 16 dword
+            // stores per tile and is store-ISSUE bound.  Each wave transposes its 32x32 tile through
+            // a private 4 KB LDS patch instead, so a lane owns 4 consecutive channels of a pixel and
+            // all epilogue traffic (mask / residual / accumulate loads, the store) is 16 bytes wide:
+            // 4 instructions per tile, each covering 8 whole 128-byte pixel rows.
+            const int nt_i = t % n_tiles;
+            int m_i = t / n_tiles;
+            const int tx = m_i % tiles_x; m_i /= tiles_x;
+            const int ty = m_i % tiles_y;
+            const int b = m_i / tiles_y;
+            const int x0 = tx * 32, y0 = ty * TH, n0 = nt_i * BN;
+            float* eb = epi + wave * 1024;
+            const int q4 = (lane & 7) * 4, pr = lane >> 3;
 #pragma unroll
-    for (int k = 0; k < NT; ++k) {
-        const int n = n0 + (wn * NT + k) * 32 + l31;
-        const bool n_ok = n < a.Ntot;
-        const int d = (n >= a.n_split) ? 1 : 0;
-        const int ch = n - (d ? a.n_split : 0);
-        float* dst = a.dst[d];
-        const float* msk = a.mask[d];
-        const int cs = a.dst_cs[d], mmode = a.mask_mode[d], accum = a.accum[d];
-        const float bias = (a.bias && n_ok) ? a.bias[n] : 0.f;
+            for (int k = 0; k < NT; ++k) {
+                const int n = n0 + (wn * NT + k) * 32 + q4;             // first of this lane's 4 channels
+                const bool n_ok = n < a.Ntot;
+                const int d = (n >= a.n_split) ? 1 : 0;
+                const int ch = n - (d ? a.n_split : 0);
+                float* dst = a.dst[d];
+                const float* msk = a.mask[d];
+                const int cs = a.dst_cs[d], mmode = a.mask_mode[d], accum = a.accum[d];
+                float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a.bias && n_ok) bias = *reinterpret_cast<const float4*>(a.bias + n);
+                const float* addsrc = (d == 0) ? a.addsrc : nullptr;
 #pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int py = y0 + wm * MT + i;
-            if (py >= a.DH) continue;
-            const int oy = py * a.out_mul + a.out_yoff;
+                for (int i = 0; i < MT; ++i) {
+                    const int py = y0 + wm * MT + i;
+                    const int oy = py * a.out_mul + a.out_yoff;
+                    const int rowo = (int)(((int64_t)b * a.OH + oy) * a.OW) * cs + ch;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = x0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (px >= a.DW || !n_ok) continue;
-                const int ox = px * a.out_mul + a.out_xoff;
-                const int64_t idx = (((int64_t)b * a.OH + oy) * a.OW + ox) * cs + ch;
-                float v = acc[i][k][r] + bias;
-                if (a.addsrc && d == 0) v += a.addsrc[idx];
-                if (a.act == 1) v = v > 0.f ? v : 0.2f * v;
-                else if (a.act == 2) v = fmaxf(v, 0.f);
-                if (mmode) {
-                    const float mv = msk[idx];
-                    v *= (mv > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
+                    for (int r = 0; r < 16; ++r) {
+                        eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][r];
+                        acc[i][k][r] = 0.f;
+                    }
+                    if (py < a.DH) {
+                        float4 v[4], mv[4], add[4];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int p = pr + 8 * it, px = x0 + p;
+                            const bool ok = px < a.DW && n_ok;
+                            const int idx = rowo + (px * a.out_mul + a.out_xoff) * cs;
+                            v[it] = *reinterpret_cast<const float4*>(eb + p * 32 + q4);
+                            mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+                            add[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                            if (mmode && ok) mv[it] = *reinterpret_cast<const float4*>(msk + idx);
+                            if (addsrc && ok) add[it] = *reinterpret_cast<const float4*>(addsrc + idx);
+                            if (accum && ok) add[it] = *reinterpret_cast<const float4*>(dst + idx);
+                        }
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int px = x0 + pr + 8 * it;
+                            if (px >= a.DW || !n_ok) continue;
+                            const int idx = rowo + (px * a.out_mul + a.out_xoff) * cs;
+                            float o[4] = {v[it].x + bias.x, v[it].y + bias.y, v[it].z + bias.z, v[it].w + bias.w};
+                            const float ad[4] = {add[it].x, add[it].y, add[it].z, add[it].w};
+                            const float mk[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) {
+                                if (addsrc) o[c] += ad[c];
+                                if (a.act == 1) o[c] = o[c] > 0.f ? o[c] : 0.2f * o[c];
+                                else if (a.act == 2) o[c] = fmaxf(o[c], 0.f);
+                                if (mmode) o[c] *= (mk[c] > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
+                                if (accum) o[c] += ad[c];
+                            }
+                            *reinterpret_cast<float4*>(dst + idx) = make_float4(o[0], o[1], o[2], o[3]);
+                        }
+                    }
                 }
-                if (accum) v += dst[idx];
-                dst[idx] = v;
             }
         }
+        t = nt; g = ng;
     }
+}
+
+int grid_cap() {   // experiments: PNNP_IGEMM_WGS_PER_CU overrides the resident-workgroup count
+    static int v = -2;
+    if (v == -2) { const char* e = getenv("PNNP_IGEMM_WGS_PER_CU"); v = e ? atoi(e) : -1; }
+    return v;
 }
 
 template <int TAPS, int KC, int BN, int MT, int NT, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     using Cfg = IgemmCfg<TAPS, KC, BN, MT, NT, WM, WN>;
     auto kern = igemm_kernel<TAPS, KC, BN, MT, NT, WM, WN>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static int per_cu = 0, cus = 0;
+    if (!per_cu) {
         if (Cfg::LDS_BYTES > 64 * 1024 &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 Cfg::LDS_BYTES) != hipSuccess)
             return PNNP_E_LAUNCH;
-        attr_set = true;
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, Cfg::LDS_BYTES) != hipSuccess || n < 1)
+            n = 1;
+        cus = pnnp_device_cus();
+        if (cus < 1) cus = 256;
+        per_cu = n;
     }
     const int tiles = ((a.DW + 31) / 32) * ((a.DH + Cfg::TH - 1) / Cfg::TH) * a.B * ((a.Ntot + BN - 1) / BN);
     if (tiles <= 0) return PNNP_OK;
-    hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), Cfg::LDS_BYTES, s, a);
+    int wgs = (grid_cap() > 0 ? grid_cap() : per_cu) * cus;
+    if (wgs > tiles) wgs = tiles;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();
+}
+
+// tuning knob (experiments): PNNP_KC_CAP caps the channel chunk
+int kc_cap() {
+    static int cap = -1;
+    if (cap < 0) { const char* e = getenv("PNNP_KC_CAP"); cap = e ? atoi(e) : 32; if (cap < 8) cap = 8; }
+    return cap;
+}
+
+int pick_bn(int ntot) { return ntot >= 128 ? 128 : (ntot >= 64 ? 64 : 32); }
+
+int pick_kc(int bn, int chan) {
+    // weight tile <= 36 KB and at most 16 channels per chunk: ~40 KB of LDS per workgroup keeps
+    // 3-4 workgroups resident per CU
+    int kc = 1024 / bn;
+    if (kc > 16) kc = 16;
+    if (kc > kc_cap()) kc = kc_cap();
+    while (kc > 8 && (chan % kc)) kc >>= 1;
+    return kc;
 }
 
 template <int TAPS>
 int launch_taps(const IgemmArgs& a, int kc_chan, hipStream_t s) {
-    // kc_chan: channels per segment (all segments equal).  BN from N, KC the largest of {32,16,8}
-    // that divides the segment and keeps the weight tile <= 36 KB.
-    const int bn = a.Ntot >= 128 ? 128 : (a.Ntot >= 64 ? 64 : 32);
-    int kc = 1024 / bn;
-    if (kc > 32) kc = 32;
-    while (kc > 8 && (kc_chan % kc)) kc >>= 1;
+    const int bn = pick_bn(a.Ntot);
+    const int kc = pick_kc(bn, kc_chan);
     if (kc_chan % kc) return PNNP_E_UNSUPPORTED;
     if (bn == 32) {
-        if (kc == 32) return launch_cfg<TAPS, 32, 32, 2, 1, 4, 1>(a, s);
         if (kc == 16) return launch_cfg<TAPS, 16, 32, 2, 1, 4, 1>(a, s);
         return launch_cfg<TAPS, 8, 32, 2, 1, 4, 1>(a, s);
     }
@@ -193,11 +296,15 @@ int launch_taps(const IgemmArgs& a, int kc_chan, hipStream_t s) {
 
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s) {
     if (a.nseg < 1 || a.nseg > 4 || chan_per_seg <= 0 || (chan_per_seg & 7) || a.Ntot <= 0) return PNNP_E_INVALID;
+    if (a.addsrc && a.accum[0]) return PNNP_E_UNSUPPORTED;   // the epilogue shares one register set for both
+    // 16-byte epilogue accesses: channel counts / splits in multiples of 4, 16-byte aligned bases
+    if ((a.Ntot & 3) || (a.dst_cs[0] & 3) || (a.dst[1] && ((a.dst_cs[1] & 3) || (a.n_split & 3)))) return PNNP_E_UNSUPPORTED;
+    if ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) |
+         ((uintptr_t)a.addsrc)) & 15) return PNNP_E_INVALID;
+    for (int d = 0; d < 2; ++d)                              // 32-bit element offsets in the epilogue
+        if (a.dst[d] && (int64_t)a.B * a.OH * a.OW * a.dst_cs[d] >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     IgemmArgs b = a;
-    const int bn = a.Ntot >= 128 ? 128 : (a.Ntot >= 64 ? 64 : 32);
-    int kc = 1024 / bn;
-    if (kc > 32) kc = 32;
-    while (kc > 8 && (chan_per_seg % kc)) kc >>= 1;
+    const int kc = pick_kc(pick_bn(a.Ntot), chan_per_seg);
     b.chunks_per_seg = chan_per_seg / kc;
     if (taps == 9) return launch_taps<9>(b, chan_per_seg, s);
     if (taps == 1) return launch_taps<1>(b, chan_per_seg, s);

@@ -119,24 +119,25 @@ maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, fl
 // per-channel sum over pixels of an NHWC tensor: partial[blockIdx][C] then a fixed-order finish
 __global__ void __launch_bounds__(256)
 channel_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t npix, int C) {
-    // thread t owns channel (t % C) when C <= 256, striding pixels by 256/C per block step
-    const int lanes_per_pix = C < 256 ? C : 256;
-    const int pix_per_iter = 256 / lanes_per_pix;
-    for (int c0 = 0; c0 < C; c0 += 256) {
-        const int c = c0 + threadIdx.x % lanes_per_pix;
-        float s = 0.f;
-        for (int64_t p = (int64_t)blockIdx.x * pix_per_iter + threadIdx.x / lanes_per_pix; p < npix;
-             p += (int64_t)gridDim.x * pix_per_iter)
-            if (c < C) s += x[p * C + c];
-        __shared__ float red[256];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        if (threadIdx.x < lanes_per_pix && c < C) {
-            float t = 0.f;
-            for (int k = 0; k < pix_per_iter; ++k) t += red[k * lanes_per_pix + threadIdx.x];
-            partial[(int64_t)blockIdx.x * C + c] = t;
+    // thread t owns the channel quad (t % (C/4)) of every (256/(C/4))-th pixel: float4 loads,
+    // a wave reads whole pixels (fully coalesced); C/4 must divide 256 (C = 4 .. 1024, power of 2)
+    const int cq = C >> 2;
+    const int q = threadIdx.x % cq, lane_pix = threadIdx.x / cq, pix_per_iter = 256 / cq;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t p = (int64_t)blockIdx.x * pix_per_iter + lane_pix; p < npix; p += (int64_t)gridDim.x * pix_per_iter) {
+        const float4 v = *reinterpret_cast<const float4*>(x + p * C + 4 * q);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    __shared__ float4 red[256];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < cq) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < pix_per_iter; ++k) {
+            const float4 v = red[k * cq + threadIdx.x];
+            t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
         }
-        __syncthreads();
+        *reinterpret_cast<float4*>(partial + (int64_t)blockIdx.x * C + 4 * threadIdx.x) = t;
     }
 }
 
@@ -263,10 +264,10 @@ int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int
     return pnnp_launch_status();
 }
 
-// out[c] (+)= sum over pixels of x[pix][c];  workspace >= 256*C floats
+// out[c] (+)= sum over pixels of x[pix][c];  workspace >= 1024*C floats
 int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int accumulate, float* workspace, void* stream) {
-    if (!x || !out || !workspace || npix <= 0 || C <= 0 || (C <= 256 && 256 % C)) return PNNP_E_INVALID;
-    const int blocks = 256;
+    if (!x || !out || !workspace || npix <= 0 || C < 4 || (C & 3) || C > 1024 || (256 % (C / 4))) return PNNP_E_INVALID;
+    const int blocks = 1024;       // workspace holds blocks x C partial sums (deterministic two-stage sum)
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, workspace, npix, C);
     hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, out, blocks, C, accumulate);
     return pnnp_launch_status();

@@ -174,12 +174,32 @@ wgrad_kernel(const WgradArgs a) {
     }
 }
 
+// out[i] = sum_z slab[z][i] in a fixed order.  32 consecutive elements x 8 z-phases per block so the
+// Z (up to 512) dependent loads per element are spread over 8 threads and many blocks.
 __global__ void __launch_bounds__(256)
 slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int z = 0; z < Z; ++z) s += slab[(int64_t)z * n + i];
-        out[i] = accumulate ? out[i] + s : s;
+    __shared__ float red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n; i0 += (int64_t)gridDim.x * 32) {
+        const int64_t i = i0 + tx;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        if (i < n) {
+            int z = ty;
+            for (; z + 24 < Z; z += 32) {
+                s0 += slab[(int64_t)z * n + i]; s1 += slab[(int64_t)(z + 8) * n + i];
+                s2 += slab[(int64_t)(z + 16) * n + i]; s3 += slab[(int64_t)(z + 24) * n + i];
+            }
+            for (; z < Z; z += 8) s0 += slab[(int64_t)z * n + i];
+        }
+        red[ty][tx] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (ty == 0 && i < n) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[k][tx];
+            out[i] = accumulate ? out[i] + s : s;
+        }
+        __syncthreads();
     }
 }
 
@@ -271,10 +291,10 @@ int pnnp_conv_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1
     else rc = launch_shape<1>(a, shape, as_stream(stream));
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cout * N * taps;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
                        as_stream(stream), a.slab, dW, n, a.Z, accumulate);
     if (dbias)
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, as_stream(stream), a.bias_slab, dbias,
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, as_stream(stream), a.bias_slab, dbias,
                            (int64_t)Cout, a.Z, accumulate);
     return pnnp_launch_status();
 }
@@ -296,7 +316,7 @@ int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Co
     int rc = launch_shape<4>(a, pick_shape(Cin, Cout), as_stream(stream));
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cin * Cout * 4;
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
                        as_stream(stream), a.slab, dW, n, a.Z, accumulate);
     (void)dbias;   // the bias gradient of a ConvTranspose2d is a plain channel sum: pnnp_channel_sum_f32
     return pnnp_launch_status();

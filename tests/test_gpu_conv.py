@@ -177,7 +177,7 @@ def test_convt(case):
     dx = torch.full((B, H, W, Ci), float('nan'), device='cuda')
     ops.convt_bwd_data(nhwc(g).cuda(), d, dx, mask=nhwc(m).cuda(), mode=1)
     close(nchw(dx), x.grad * torch.where(m > 0, 1.0, 0.2), what=f'convT dgrad {case}')
-    ws = torch.empty(max(ops.wgrad_workspace_floats(B, H, W, Ci, Co, 4), 256 * Co), device='cuda')
+    ws = torch.empty(max(ops.wgrad_workspace_floats(B, H, W, Ci, Co, 4), 1024 * Co), device='cuda')
     dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
     ops.convt_bwd_weight(nhwc(x.detach()).cuda(), nhwc(g).cuda(), dW, ws)
     ops.channel_sum(nhwc(g).cuda(), db, ws)

@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the conv-stack kernels at the UNet nf=32 shapes (B crops of 4xSxS):
+forward, backward-data and backward-weight of every distinct layer shape, HIP events on the
+launch stream, median of `--reps` interleaved repetitions.  Prints TFLOP/s per layer and op.
+
+    python tools/layer_bench.py [--batch 16] [--size 512] [--reps 5] [--only fwd,dgrad,wgrad]
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from pnnp_amd import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--reps', type=int, default=5)
+    ap.add_argument('--only', default='fwd,dgrad,wgrad')
+    ap.add_argument('--layers', default='')
+    a = ap.parse_args()
+    B, S = a.batch, a.size
+    dev = torch.device('cuda')
+    nf = 32
+    ch = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+    layers = []   # name, H, C1, C2, Cout
+    for l in range(5):
+        layers.append((f'conv{l + 1}_1', S >> l, 8 if l == 0 else ch[l - 1], 0, ch[l]))
+        layers.append((f'conv{l + 1}_2', S >> l, ch[l], 0, ch[l]))
+    for i in range(6, 10):
+        l = 9 - i
+        layers.append((f'conv{i}_1', S >> l, ch[l], ch[l], ch[l]))
+    if a.layers:
+        layers = [x for x in layers if x[0] in a.layers.split(',')]
+    kinds = a.only.split(',')
+    res = {}
+    for name, H, C1, C2, Co in layers:
+        x1 = torch.randn(B, H, H, C1, device=dev)
+        x2 = torch.randn(B, H, H, C2, device=dev) if C2 else None
+        w = torch.randn(Co, C1 + C2, 3, 3, device=dev) * 0.05
+        bias = torch.randn(Co, device=dev)
+        f = torch.empty(w.numel(), device=dev); d = torch.empty(w.numel(), device=dev)
+        ops.pack_conv_weight(w, f, d)
+        y = torch.empty(B, H, H, Co, device=dev)
+        g = torch.randn(B, H, H, Co, device=dev)
+        dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
+        dW = torch.empty_like(w); db = torch.empty(Co, device=dev)
+        ws = torch.empty(ops.wgrad_workspace_floats(B, H, H, Co, C1 + C2, 9), device=dev)
+        flops = 2.0 * B * H * H * Co * (C1 + C2) * 9
+        fns = {'fwd': lambda: ops.conv_fwd(x1, x2, f, bias, y, Co, 9, 1),
+               'dgrad': lambda: ops.conv_bwd_data(g, d, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1),
+               'wgrad': lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws)}
+        for k in kinds:
+            fns[k](); torch.cuda.synchronize()
+            ts = []
+            for _ in range(a.reps):
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record(); fns[k](); e1.record(); torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts.sort()
+            res[(name, k)] = (ts[len(ts) // 2], flops)
+        del x1, x2, y, g, dx1, dx2, ws
+    tot = {k: [0.0, 0.0] for k in kinds}
+    print(f'{"layer":10s} ' + ' '.join(f'{k + " ms":>9s} {"TF":>6s}' for k in kinds))
+    for name, H, C1, C2, Co in layers:
+        line = f'{name:10s} '
+        for k in kinds:
+            ms, fl = res[(name, k)]
+            tot[k][0] += ms; tot[k][1] += fl
+            line += f'{ms:9.3f} {fl / ms / 1e9:6.1f} '
+        print(line + f' H={H} Cin={C1 + C2} Cout={Co}')
+    print('total      ' + ' '.join(f'{tot[k][0]:9.3f} {tot[k][1] / tot[k][0] / 1e9:6.1f}' for k in kinds))
+
+
+if __name__ == '__main__':
+    main()
