@@ -49,7 +49,7 @@ struct WgCfg {
 };
 
 template <int TAPS, int WMO, int WNO, int WK, int TH>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 wgrad_kernel(const WgradArgs a) {
     using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH>;
     constexpr int P = Cfg::P, SM = Cfg::SM, BMO = Cfg::BMO, BNO = Cfg::BNO, SC = Cfg::SC;
@@ -77,37 +77,58 @@ wgrad_kernel(const WgradArgs a) {
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
     float bsum = 0.f;
 
-    for (int tile = z; tile < ntile; tile += a.Z) {
+    // staging registers of the NEXT pixel tile (its loads fly while this tile's MFMAs run)
+    constexpr int NU = (Cfg::US_F / 4 + 255) / 256, NS = (Cfg::SS_F / 4 + 255) / 256;
+    float4 ru[NU], rs[NS];
+    auto prefetch = [&](int tile) {
         int q = tile;
         const int tx = q % tiles_x; q /= tiles_x;
         const int ty = q % tiles_y;
         const int b = q / tiles_y;
         const int x0 = tx * 32, y0 = ty * TH;
-        if (tile != z) __syncthreads();
-        // ---- stage U tile: us[pix][BMO]
-        for (int i = tid; i < Cfg::US_F / 4; i += 256) {
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int i = tid + 256 * k;
             const int cq = i % (BMO / 4), pix = i / (BMO / 4);
             const int r = pix >> 5, c = pix & 31;
             const int gy = y0 + r, gx = x0 + c, m = m0 + 4 * cq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy < a.DH && gx < a.DW && m < a.M)
+            if (i < Cfg::US_F / 4 && gy < a.DH && gx < a.DW && m < a.M)
                 v = *reinterpret_cast<const float4*>(a.U + (((int64_t)b * a.DH + gy) * a.DW + gx) * a.Ucs + m);
-            *reinterpret_cast<float4*>(us + pix * BMO + 4 * cq) = v;
+            ru[k] = v;
         }
-        // ---- stage S tile (with halo for 3x3): ss[spix][BNO]
-        for (int i = tid; i < Cfg::SS_F / 4; i += 256) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = tid + 256 * k;
             const int cq = i % (BNO / 4), pix = i / (BNO / 4);
             const int r = pix / SC, c = pix - r * SC;
             const int gy = y0 * SM + r - P, gx = x0 * SM + c - P, n = n0 + 4 * cq;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (gy >= 0 && gy < a.SH && gx >= 0 && gx < a.SW && n < a.N) {
+            if (i < Cfg::SS_F / 4 && gy >= 0 && gy < a.SH && gx >= 0 && gx < a.SW && n < a.N) {
                 const int d = n >= a.n_split ? 1 : 0;
                 const int ch = n - (d ? a.n_split : 0);
                 v = *reinterpret_cast<const float4*>(a.S[d] + (((int64_t)b * a.SH + gy) * a.SW + gx) * a.Scs[d] + ch);
             }
-            *reinterpret_cast<float4*>(ss + pix * BNO + 4 * cq) = v;
+            rs[k] = v;
+        }
+    };
+
+    if (z < ntile) prefetch(z);
+    for (int tile = z; tile < ntile; tile += a.Z) {
+        if (tile != z) __syncthreads();
+        // ---- write the staged tiles: us[pix][BMO], ss[spix][BNO] (linear float4 copies)
+#pragma unroll
+        for (int k = 0; k < NU; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Cfg::US_F / 4) reinterpret_cast<float4*>(us)[i] = ru[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const int i = tid + 256 * k;
+            if (i < Cfg::SS_F / 4) reinterpret_cast<float4*>(ss)[i] = rs[k];
         }
         __syncthreads();
+        if (tile + a.Z < ntile) prefetch(tile + a.Z);
         // ---- MFMA: k = pixel pairs along a row
         for (int r = wk; r < TH; r += WK) {
 #pragma unroll 4
@@ -223,7 +244,9 @@ int launch_wg(const WgradArgs& a, hipStream_t s) {
 // output-tile shape from (M, N): 32x32 with the 4 waves splitting pixel rows (8-row tiles),
 // 64x32 / 32x64 with 2 pixel splits (4-row tiles), 64x64 with none (2-row tiles, 3 workgroups/CU)
 int pick_shape(int M, int N) { return (M > 32 ? 1 : 0) + (N > 32 ? 2 : 0); }
-int tile_rows(int taps, int shape) { return taps == 4 ? 2 : (shape == 0 ? 8 : (shape == 3 ? 2 : 4)); }
+// rows per pixel tile: small tiles keep the prefetch registers (next tile in flight) + 144
+// accumulator registers under 256 VGPRs without spilling
+int tile_rows(int taps, int shape) { return taps == 4 ? 2 : (shape == 0 ? 4 : 2); }
 
 template <int TAPS>
 int launch_shape(const WgradArgs& a, int shape, hipStream_t s) {
@@ -236,9 +259,9 @@ int launch_shape(const WgradArgs& a, int shape, hipStream_t s) {
         }
     } else {
         switch (shape) {
-            case 0: return launch_wg<TAPS, 1, 1, 4, 8>(a, s);
-            case 1: return launch_wg<TAPS, 2, 1, 2, 4>(a, s);
-            case 2: return launch_wg<TAPS, 1, 2, 2, 4>(a, s);
+            case 0: return launch_wg<TAPS, 1, 1, 4, 4>(a, s);
+            case 1: return launch_wg<TAPS, 2, 1, 2, 2>(a, s);
+            case 2: return launch_wg<TAPS, 1, 2, 2, 2>(a, s);
             default: return launch_wg<TAPS, 2, 2, 1, 2>(a, s);
         }
     }
