@@ -122,6 +122,11 @@ int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
 /* backward-weight: dW [Cout][C1+C2][taps] (+ dbias [Cout]); workspace from the query below. */
 int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps);
 int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps);
+/* backward-data through an identity shortcut: dx = (conv_bwd_data(g) + addsrc) * act'(mask)
+ * (ResidualBlock, archs/modules.py:193-197). */
+int pnnp_conv_bwd_data_res_f32(const float* g, int Cout, const float* w_dgrad, float* dx, int C1,
+                               const float* addsrc, const float* mask, int mode, int B, int H, int W,
+                               int taps, void* stream);
 /* *_cs = channels per pixel of that tensor (>= the channels used: the 4-channel boundary
  * tensors travel zero-padded to 8 channels). */
 int pnnp_conv_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
@@ -136,6 +141,18 @@ int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, f
 int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Cout, float* dW,
                                  float* dbias_unused, int B, int H, int W, int accumulate,
                                  float* workspace, int64_t workspace_floats, void* stream);
+/* Conv2d 3x3 stride 2 pad 1 (ResUnet down-sampling `conv3x3`, archs/modules.py:130-138,
+ * archs/ResUnet.py:18-27): x [B][H][W][Cin] <-> y [B][H/2][W/2][Cout].  forward takes the ordinary
+ * forward pack; backward-data its own pack (9*Cout*Cin floats); backward-weight workspace is
+ * pnnp_wgrad_workspace_floats(B, H/2, W/2, Cout, Cin, 18). */
+int pnnp_conv3x3s2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
+                           int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_pack_conv3x3s2_dgrad_f32(const float* w, float* dst, int Cout, int Cin, void* stream);
+int pnnp_conv3x3s2_bwd_data_f32(const float* g, int Cout, const float* w_s2dgrad, float* dx, int Cin,
+                                const float* mask, int mode, int accum, int B, int H, int W, void* stream);
+int pnnp_conv3x3s2_bwd_weight_f32(const float* g, int Cout, const float* x, int Cin, float* dW,
+                                  float* dbias /*or null*/, int B, int H, int W, int accumulate,
+                                  float* workspace, int64_t workspace_floats, void* stream);
 /* MaxPool2d(2) (archs/Unet.py:57-69); backward routes to the first maximum of each window,
  * multiplies by act'(x) and optionally accumulates into gx (skip-connection gradient). */
 int pnnp_maxpool2_fwd_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);

@@ -1,0 +1,281 @@
+"""ResUnet on hand-written HIP kernels (reference: archs/ResUnet.py:3-88, building blocks
+archs/modules.py:130-153,176-197).
+
+Same contract as UNetSeeInDark: the reference's constructor, attribute names and state_dict
+keys (``conv_in``, ``conv{1..9}.block.{0,1}.conv.conv.weight``, ``conv{6..9}.short_cut.0.conv.conv
+.weight``, ``pool{1..4}.conv.{weight,bias}``, ``upv{6..9}``, ``conv10``); children only own
+parameters, forward/backward run through libpnnp_hip.so.
+
+Reference quirks kept: ``conv3x3`` attaches its ReLU as a child of nn.Conv2d, which never runs
+(the down-sampling convs are stride-2 conv + bias, NO activation); ResidualBlock is built with
+``is_activate=False`` so the block output has no activation: out = conv(relu(conv(x))) + shortcut(x).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .._lib import PnnpError
+from .unet import FlatParams, _Bufs, RELU
+
+
+class _ConvHolder(nn.Module):      # modules.py:140-153 convWithBN(is_bn=False): .conv = Sequential(conv=Conv2d(bias=False))
+    def __init__(self, ci, co, k):
+        super().__init__()
+        self.conv = nn.Sequential(OrderedDict([('conv', nn.Conv2d(ci, co, kernel_size=k, padding=k // 2, stride=1, bias=False))]))
+
+
+class _ResBlockHolder(nn.Module):  # modules.py:176-197
+    def __init__(self, ci, co):
+        super().__init__()
+        self.block = nn.Sequential(_ConvHolder(ci, co, 3), _ConvHolder(co, co, 3))
+        self.short_cut = nn.Sequential(_ConvHolder(ci, co, 1)) if ci != co else nn.Sequential(OrderedDict([]))
+
+
+class _DownHolder(nn.Module):      # modules.py:130-138 conv3x3(stride=2)
+    def __init__(self, ci, co):
+        super().__init__()
+        self.conv = nn.Conv2d(ci, co, kernel_size=3, padding=1, stride=2)
+
+
+class ResUnetEngine:
+    def __init__(self, module):
+        self.m = module
+        self.params = FlatParams(module)
+        self.bufs = {}
+        self.packed = {}
+        self.saved = None
+        nf = module.nf
+        if nf % 8:
+            raise PnnpError('ResUnet on HIP needs nf % 8 == 0')
+        self.ch = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        self.cin = module.in_nc * module.nframes
+        self.cin_pad = (self.cin + 7) // 8 * 8
+        self.cout = module.out_nc
+        self.cout_pad = (self.cout + 7) // 8 * 8
+
+    # ---------------------------------------------------------------- weights
+    def _buf(self, key, n, dev):
+        k = (key, dev)
+        if k not in self.packed or self.packed[k].numel() != n:
+            self.packed[k] = torch.empty(n, dtype=torch.float32, device=dev)
+        return self.packed[k]
+
+    def pack_weights(self, train):
+        dev = self.params.flat.device
+        P = dict(self.m.named_parameters())
+        W = {}
+        def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True):
+            w = P[pname]
+            co, ci, kh, kw = w.shape
+            t = kh * kw
+            f = self._buf(name + ':f', t * (cin_pad or ci) * co, dev)
+            d = self._buf(name + ':d', t * (cout_pad or co) * ci, dev) if (train and dgrad) else None
+            ops.pack_conv_weight(w, f, d, cin_pad=cin_pad, cout_pad=cout_pad)
+            W[name] = (f, d)
+        conv('conv_in', 'conv_in.weight', cin_pad=self.cin_pad, dgrad=False)
+        for i in range(1, 10):
+            conv(f'b{i}_0', f'conv{i}.block.0.conv.conv.weight')
+            conv(f'b{i}_1', f'conv{i}.block.1.conv.conv.weight')
+            if i >= 6:
+                conv(f'sc{i}', f'conv{i}.short_cut.0.conv.conv.weight')
+        for l in range(1, 5):
+            w = P[f'pool{l}.conv.weight']
+            f = self._buf(f'pool{l}:f', w.numel(), dev)
+            ops.pack_conv_weight(w, f, None)
+            d = None
+            if train:
+                d = self._buf(f'pool{l}:d', w.numel(), dev)
+                ops.pack_conv_s2_dgrad(w, d)
+            W[f'pool{l}'] = (f, d)
+        for i in range(6, 10):
+            w = P[f'upv{i}.weight']
+            f = self._buf(f'upv{i}:f', w.numel(), dev)
+            d = self._buf(f'upv{i}:d', w.numel(), dev) if train else None
+            ops.pack_convt_weight(w, f, d)
+            W[f'upv{i}'] = (f, d)
+        conv('conv10', 'conv10.weight', cout_pad=self.cout_pad)
+        self.W = W
+
+    # ---------------------------------------------------------------- forward
+    def forward(self, x, train):
+        if not x.is_cuda:
+            raise PnnpError('ResUnet.forward: input must be a CUDA tensor (pnnp_amd has no CPU path)')
+        x = x.contiguous().float()
+        B, Cin, H, Wd = x.shape
+        if Cin != self.cin or H % 16 or Wd % 16:
+            raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
+        dev = x.device
+        self.params.ensure(dev)
+        self.pack_weights(train)
+        bufs = self.bufs.setdefault((B, H, Wd, dev), _Bufs())
+        P = dict(self.m.named_parameters())
+        ch, W = self.ch, self.W
+        g = lambda n, s: bufs.get(n, s, dev)
+        hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
+        a = {}
+        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad)
+        a['t0'] = ops.conv_fwd(a['x8'], None, W['conv_in'][0], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], 9, RELU)
+        xin = a['t0']
+        for l in range(1, 6):
+            lv = l - 1
+            shp = (B, hs[lv], ws[lv], ch[lv])
+            a[f't{l}'] = ops.conv_fwd(xin, None, W[f'b{l}_0'][0], None, g(f't{l}', shp), ch[lv], 9, RELU)
+            a[f'c{l}'] = ops.conv_fwd(a[f't{l}'], None, W[f'b{l}_1'][0], None, g(f'c{l}', shp), ch[lv], 9, 0, residual=xin)
+            if l < 5:
+                a[f'd{l}'] = ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
+                                             g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
+                xin = a[f'd{l}']
+        cur = a['c5']
+        for i in range(6, 10):
+            lv = 9 - i
+            shp = (B, hs[lv], ws[lv], ch[lv])
+            u = ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
+            skip = a[f'c{lv + 1}']
+            a[f'u{i}'] = u
+            a[f't{i}'] = ops.conv_fwd(u, skip, W[f'b{i}_0'][0], None, g(f't{i}', shp), ch[lv], 9, RELU)
+            sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
+            a[f'c{i}'] = ops.conv_fwd(a[f't{i}'], None, W[f'b{i}_1'][0], None, g(f'c{i}', shp), ch[lv], 9, 0, residual=sc)
+            cur = a[f'c{i}']
+        o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
+        out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
+        ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
+        if train:
+            self.saved = (a, (B, H, Wd, dev))
+        return out
+
+    # ---------------------------------------------------------------- backward
+    def backward(self, g_out8, need_dx=False, accumulate=False, on_ready=None):
+        a, (B, H, Wd, dev) = self.saved
+        bufs = self.bufs[(B, H, Wd, dev)]
+        ch, W = self.ch, self.W
+        gb = lambda n, like: bufs.get('g_' + n, like.shape, dev)
+        P = dict(self.m.named_parameters())
+        G = lambda name: self.params.grad_view(name, P[name].shape)
+        acc = 1 if accumulate else 0
+        wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, Wd),), dev)
+
+        def done(pname):
+            if on_ready is not None:
+                on_ready(self.params.slices[pname][0])
+
+        def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
+            ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
+
+        # head
+        wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
+        done('conv10.weight')
+        g = gb('c9', a['c9'])
+        ops.conv_bwd_data(g_out8, W['conv10'][1], g, taps=1)
+        for i in range(9, 5, -1):                    # decoder blocks, top-down
+            lv = 9 - i
+            u, skip, t = a[f'u{i}'], a[f'c{lv + 1}'], a[f't{i}']
+            wgrad(f'conv{i}.short_cut.0.conv.conv.weight', g, ch[lv], u, ch[lv], x2=skip, taps=1)
+            wgrad(f'conv{i}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
+            g_t = gb(f't{i}', t)
+            ops.conv_bwd_data(g, W[f'b{i}_1'][1], g_t, mask1=t, mode1=RELU)
+            wgrad(f'conv{i}.block.0.conv.conv.weight', g_t, ch[lv], u, ch[lv], x2=skip)
+            done(f'conv{i}.block.0.conv.conv.weight')
+            g_u, g_skip = gb(f'u{i}', u), gb(f'c{lv + 1}', skip)
+            ops.conv_bwd_data(g_t, W[f'b{i}_0'][1], g_u, dx2=g_skip)
+            ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
+            below = a['c5'] if i == 6 else a[f'c{i - 1}']
+            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc)
+            ops.channel_sum(g_u, G(f'upv{i}.bias'), wsf, accumulate=acc)
+            done(f'upv{i}.weight')
+            g = gb('c5' if i == 6 else f'c{i - 1}', below)
+            ops.convt_bwd_data(g_u, W[f'upv{i}'][1], g)
+        for l in range(5, 0, -1):                    # encoder blocks, bottom-up; g = dL/d c_l
+            lv = l - 1
+            t = a[f't{l}']
+            xin = a['t0'] if l == 1 else a[f'd{l - 1}']
+            wgrad(f'conv{l}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
+            g_t = gb(f't{l}', t)
+            ops.conv_bwd_data(g, W[f'b{l}_1'][1], g_t, mask1=t, mode1=RELU)
+            wgrad(f'conv{l}.block.0.conv.conv.weight', g_t, ch[lv], xin, ch[lv])
+            done(f'conv{l}.block.0.conv.conv.weight')
+            g_x = gb('t0' if l == 1 else f'd{l - 1}', xin)
+            # identity shortcut: d/d(xin) = dgrad(block) + g ; xin = t0 is a ReLU output (mask), d_l is not
+            ops.conv_bwd_data_res(g_t, W[f'b{l}_0'][1], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+            if l > 1:
+                c_prev = a[f'c{l - 1}']
+                ops.conv_s2_bwd_weight(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
+                done(f'pool{l - 1}.conv.weight')
+                g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
+                ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
+            else:
+                wgrad('conv_in.weight', g_x, ch[0], a['x8'], self.cin, bias='conv_in.bias')
+                done('conv_in.weight')
+        if need_dx:
+            raise PnnpError('gradient w.r.t. the network input is not implemented on the HIP path')
+        return None
+
+    def _ws_floats(self, B, H, W):
+        ch = self.ch
+        need = 1024 * max(ch)
+        for lv in range(5):
+            h, w, c = H >> lv, W >> lv, ch[lv]
+            need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9),
+                       ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 1), ops.wgrad_workspace_floats(B, h, w, c, self.cin, 9))
+            if lv < 4:
+                need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 4),
+                           ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 18))
+        return max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
+
+
+class _ResUnetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, engine, train, *params):
+        ctx.engine = engine
+        ctx.x_needs = x.requires_grad
+        return engine.forward(x, train)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        e = ctx.engine
+        if e.saved is None:
+            raise PnnpError('backward without a training-mode forward')
+        B, _, H, W = grad_out.shape
+        bufs = e.bufs[(B, H, W, grad_out.device)]
+        g8 = ops.nchw_to_nhwc(grad_out.contiguous().float(), bufs.get('g_out8', (B, H, W, e.cout_pad), grad_out.device), e.cout_pad)
+        e.backward(g8, need_dx=ctx.x_needs)
+        grads = [e.params.grad_view(n, p.shape).clone() if p.requires_grad else None for n, p in e.m.named_parameters()]
+        return (None, None, None) + tuple(grads)
+
+
+class ResUnet(nn.Module):
+    """Drop-in for archs/ResUnet.py:3-88 (``args`` keys: nframes, res, nf, in_nc, out_nc)."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = args
+        self.nframes = args['nframes']
+        self.cf = args['nframes'] // 2
+        self.res = args['res']
+        nf = self.nf = args['nf']
+        self.in_nc = args['in_nc']
+        self.out_nc = args['out_nc']
+        c = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
+        self.conv_in = nn.Conv2d(self.in_nc * self.nframes, nf, kernel_size=3, stride=1, padding=1)
+        for l in range(1, 6):
+            setattr(self, f'conv{l}', _ResBlockHolder(c[l - 1], c[l - 1]))
+            if l < 5:
+                setattr(self, f'pool{l}', _DownHolder(c[l - 1], c[l]))
+        for i in range(6, 10):
+            lv = 9 - i
+            setattr(self, f'upv{i}', nn.ConvTranspose2d(c[lv + 1], c[lv], 2, stride=2))
+            setattr(self, f'conv{i}', _ResBlockHolder(c[lv + 1], c[lv]))
+        self.conv10 = nn.Conv2d(nf, self.out_nc, kernel_size=1, stride=1)
+        self._engine = None
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            object.__setattr__(self, '_engine', ResUnetEngine(self))
+        return self._engine
+
+    def forward(self, x, noise_map=None):
+        params = list(self.parameters())
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _ResUnetFn.apply(x, self.engine, train, *params)

@@ -112,6 +112,21 @@ int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
     return pnnp_igemm_launch(a, taps, Cout, as_stream(stream));
 }
 
+// backward-data through a block with an identity shortcut (ResidualBlock, archs/modules.py:193-197):
+//   dx = (conv_bwd_data(g) + addsrc) * act'(mask)      addsrc, dx: [B][H][W][C1]
+int pnnp_conv_bwd_data_res_f32(const float* g, int Cout, const float* w_dgrad, float* dx, int C1,
+                               const float* addsrc, const float* mask, int mode, int B, int H, int W, int taps, void* stream) {
+    if (!g || !w_dgrad || !dx || !addsrc || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = w_dgrad; a.Ntot = C1;
+    a.dst[0] = dx; a.dst_cs[0] = C1; a.addsrc = addsrc; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+    return pnnp_igemm_launch(a, taps, Cout, as_stream(stream));
+}
+
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47
 //   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  one GEMM with N = 4*Cout (the 4 output sub-pixels).
 int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
@@ -140,6 +155,63 @@ int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, f
     a.w = w_dgrad; a.Ntot = Cin;
     a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
     return pnnp_igemm_launch(a, 1, Cout, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- Conv2d 3x3, stride 2, pad 1
+// (ResUnet down-sampling: archs/modules.py:130-138 `conv3x3`, archs/ResUnet.py:18-27)
+// forward: 9 strided 1x1 taps as 9 K segments of one GEMM; w_packed is the ordinary forward pack
+// [9][Cin/4][Cout][4] (tap-major == segment-major).  x [B][H][W][Cin] -> y [B][H/2][W/2][Cout].
+int pnnp_conv3x3s2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
+                           int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a; base_args(a);
+    for (int t = 0; t < 9; ++t) a.seg[t] = IgemmSeg{x, Cin, 0, t / 3 - 1, t % 3 - 1};
+    a.nseg = 9; a.in_mul = 2;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H / 2; a.OW = W / 2;
+    a.w = w_packed; a.Ntot = Cout;
+    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias; a.act = act;
+    return pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
+}
+
+// backward-data weights of the stride-2 conv: 9 slices [Cout/4][Cin][4] = W[co][ci][t] ordered by the
+// parity class of the input pixel they reach: (even,even) t4 | (even,odd) t3,t5 | (odd,even) t1,t7 |
+// (odd,odd) t0,t2,t6,t8.   dst: 9*Cout*Cin floats.
+static const int S2_TAP_ORDER[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};
+int pnnp_pack_conv3x3s2_dgrad_f32(const float* w, float* dst, int Cout, int Cin, void* stream) {
+    int rc = PNNP_OK;
+    for (int i = 0; i < 9 && rc == PNNP_OK; ++i)
+        rc = pack_launch(w, dst + (int64_t)i * Cout * Cin, 1, Cout, Cin, (int64_t)Cin * 9, 9, 0, S2_TAP_ORDER[i], 0, stream);
+    return rc;
+}
+
+// backward-data: g [B][H/2][W/2][Cout] -> dx [B][H][W][Cin].  Every input pixel parity class
+// (Y&1, X&1) is its own GEMM over the 1 / 2 / 2 / 4 taps that reach it, so each dx element is written
+// exactly once (no read-modify-write over the 9 taps).
+int pnnp_conv3x3s2_bwd_data_f32(const float* g, int Cout, const float* w_s2dgrad, float* dx, int Cin,
+                                const float* mask, int mode, int accum, int B, int H, int W, void* stream) {
+    if (!g || !w_s2dgrad || !dx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    int slice = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        const int py = cls >> 1, px = cls & 1;
+        IgemmArgs a; base_args(a);
+        int ns = 0;
+        for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+            for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+                const int dy = py ? 2 * iy : 1, dxk = px ? 2 * ix : 1;      // tap (dy, dxk)
+                a.seg[ns++] = IgemmSeg{g, Cout, 0, dy == 0 ? 1 : 0, dxk == 0 ? 1 : 0};
+            }
+        a.nseg = ns;
+        a.IH = H / 2; a.IW = W / 2; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H; a.OW = W;
+        a.out_mul = 2; a.out_yoff = py; a.out_xoff = px;
+        a.w = w_s2dgrad + (int64_t)slice * Cout * Cin; a.Ntot = Cin;
+        a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0; a.accum[0] = accum;
+        const int rc = pnnp_igemm_launch(a, 1, Cout, as_stream(stream));
+        if (rc != PNNP_OK) return rc;
+        slice += ns;
+    }
+    return PNNP_OK;
 }
 
 }  // extern "C"

@@ -191,12 +191,13 @@ igemm_kernel(const IgemmArgs a) {
                         eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][r];
                         acc[i][k][r] = 0.f;
                     }
-                    if (py < a.DH) {
+                    if (py < a.DH && oy >= 0 && oy < a.OH) {
                         float4 v[4], mv[4], add[4];
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int p = pr + 8 * it, px = x0 + p;
-                            const bool ok = px < a.DW && n_ok;
+                            const int oxp = px * a.out_mul + xoff;
+                            const bool ok = px < a.DW && n_ok && oxp >= 0 && oxp < a.OW;
                             const int idx = rowo + (px * a.out_mul + xoff) * cs;
                             v[it] = *reinterpret_cast<const float4*>(eb + p * 32 + q4);
                             mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -208,7 +209,8 @@ igemm_kernel(const IgemmArgs a) {
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int px = x0 + pr + 8 * it;
-                            if (px >= a.DW || !n_ok) continue;
+                            const int oxq = px * a.out_mul + xoff;
+                            if (px >= a.DW || !n_ok || oxq < 0 || oxq >= a.OW) continue;
                             const int idx = rowo + (px * a.out_mul + xoff) * cs;
                             float o[4] = {v[it].x + bias.x, v[it].y + bias.y, v[it].z + bias.z, v[it].w + bias.w};
                             const float ad[4] = {add[it].x, add[it].y, add[it].z, add[it].w};
@@ -300,7 +302,7 @@ int launch_taps(const IgemmArgs& a, int kc_chan, hipStream_t s) {
 }  // namespace
 
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s) {
-    if (a.nseg < 1 || a.nseg > 4 || chan_per_seg <= 0 || (chan_per_seg & 7) || a.Ntot <= 0) return PNNP_E_INVALID;
+    if (a.nseg < 1 || a.nseg > 9 || chan_per_seg <= 0 || (chan_per_seg & 7) || a.Ntot <= 0) return PNNP_E_INVALID;
     if (a.addsrc && a.accum[0]) return PNNP_E_UNSUPPORTED;   // the epilogue shares one register set for both
     // 16-byte epilogue accesses: channel counts / splits in multiples of 4, 16-byte aligned bases
     if ((a.Ntot & 3) || (a.dst_cs[0] & 3) || (a.dst[1] && ((a.dst_cs[1] & 3) || (a.n_split & 3)))) return PNNP_E_UNSUPPORTED;

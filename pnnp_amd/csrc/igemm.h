@@ -11,7 +11,7 @@
 //   One b128 read feeds 4 MFMAs: step s multiplies channel 8j+s (lanes 0-31) and 8j+4+s
 //   (lanes 32-63) -- the two k-slices of the 32x32x2 instruction.
 //
-// The kernel is generic over "segments": K is the concatenation of up to 4 sources, each a
+// The kernel is generic over "segments": K is the concatenation of up to 9 sources, each a
 // tensor + channel range + pixel offset.  That expresses
 //   conv3x3 on torch.cat([up, skip], 1) without materialising the cat   (2 segments)
 //   ConvTranspose2d(k2,s2) backward-data as a 1x1 over the 4 sub-pixel sources (4 segments)
@@ -30,7 +30,7 @@ struct IgemmSeg {
 };
 
 struct IgemmArgs {
-    IgemmSeg seg[4];
+    IgemmSeg seg[9];               // up to 9 K segments (a stride-2 3x3 conv is 9 strided 1x1 taps)
     int nseg, chunks_per_seg;      // K = nseg * chunks_per_seg * KC channels (x TAPS)
     int in_mul, IH, IW;
     int B, DH, DW;                 // tile domain (what M iterates over)

@@ -34,10 +34,10 @@ struct WgradArgs {
 
 namespace {
 
-template <int TAPS, int WMO, int WNO, int WK, int TH>
+template <int TAPS, int WMO, int WNO, int WK, int TH, int SMUL = (TAPS == 4 ? 2 : 1)>
 struct WgCfg {
     static constexpr int P = (TAPS == 9) ? 1 : 0;
-    static constexpr int SM = (TAPS == 4) ? 2 : 1;          // S pixels per U pixel along each axis
+    static constexpr int SM = SMUL;                        // S pixels per U pixel along each axis (2: ConvTranspose, stride-2 conv)
     static constexpr int BMO = 32 * WMO, BNO = 32 * WNO;
     static constexpr int UPIX = TH * 32;
     static constexpr int SR = TH * SM + 2 * P, SC = 32 * SM + 2 * P, SPIX = SR * SC;
@@ -48,10 +48,10 @@ struct WgCfg {
     static_assert((US_F + SS_F) >= RED_F, "reduction scratch aliases the tiles");
 };
 
-template <int TAPS, int WMO, int WNO, int WK, int TH>
-__global__ void __launch_bounds__(256, 2)
+template <int TAPS, int WMO, int WNO, int WK, int TH, int SMUL>
+__global__ void __launch_bounds__(256, (TAPS == 9 && SMUL == 2) ? 1 : 2)   // the stride-2 halo tile needs more staging registers
 wgrad_kernel(const WgradArgs a) {
-    using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH>;
+    using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH, SMUL>;
     constexpr int P = Cfg::P, SM = Cfg::SM, BMO = Cfg::BMO, BNO = Cfg::BNO, SC = Cfg::SC;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* us = reinterpret_cast<float*>(smem);
@@ -139,7 +139,7 @@ wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                 for (int t = 0; t < TAPS; ++t) {
                     int sp;
-                    if (TAPS == 9) sp = (r + t / 3) * SC + p + t % 3;
+                    if (TAPS == 9) sp = (SM * r + t / 3) * SC + SM * p + t % 3;
                     else if (TAPS == 4) sp = (2 * r + (t >> 1)) * SC + 2 * p + (t & 1);
                     else sp = r * SC + p;
                     const float bv = ss[sp * BNO + wno * 32 + l31];
@@ -224,10 +224,10 @@ slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int6
     }
 }
 
-template <int TAPS, int WMO, int WNO, int WK, int TH>
+template <int TAPS, int WMO, int WNO, int WK, int TH, int SMUL = (TAPS == 4 ? 2 : 1)>
 int launch_wg(const WgradArgs& a, hipStream_t s) {
-    using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH>;
-    auto kern = wgrad_kernel<TAPS, WMO, WNO, WK, TH>;
+    using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH, SMUL>;
+    auto kern = wgrad_kernel<TAPS, WMO, WNO, WK, TH, SMUL>;
     static bool attr_set = false;
     if (!attr_set) {
         if (Cfg::LDS_BYTES > 64 * 1024 &&
@@ -246,7 +246,11 @@ int launch_wg(const WgradArgs& a, hipStream_t s) {
 int pick_shape(int M, int N) { return (M > 32 ? 1 : 0) + (N > 32 ? 2 : 0); }
 // rows per pixel tile: small tiles keep the prefetch registers (next tile in flight) + 144
 // accumulator registers under 256 VGPRs without spilling
-int tile_rows(int taps, int shape) { return taps == 4 ? 2 : (shape == 0 ? 4 : 2); }
+// taps == 18 stands for the 9 taps of a STRIDE-2 3x3 conv (S halo tile is (2 TH + 2) x 66 pixels)
+int tile_rows(int taps, int shape) {
+    if (taps == 18) return shape == 0 ? 4 : (shape == 3 ? 1 : 2);
+    return taps == 4 ? 2 : (shape == 0 ? 4 : 2);
+}
 
 template <int TAPS>
 int launch_shape(const WgradArgs& a, int shape, hipStream_t s) {
@@ -264,6 +268,15 @@ int launch_shape(const WgradArgs& a, int shape, hipStream_t s) {
             case 2: return launch_wg<TAPS, 1, 2, 2, 2>(a, s);
             default: return launch_wg<TAPS, 2, 2, 1, 2>(a, s);
         }
+    }
+}
+
+int launch_s2(const WgradArgs& a, int shape, hipStream_t s) {
+    switch (shape) {
+        case 0: return launch_wg<9, 1, 1, 4, 4, 2>(a, s);
+        case 1: return launch_wg<9, 2, 1, 2, 2, 2>(a, s);
+        case 2: return launch_wg<9, 1, 2, 2, 2, 2>(a, s);
+        default: return launch_wg<9, 2, 2, 1, 1, 2>(a, s);
     }
 }
 
@@ -286,7 +299,7 @@ int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps) {
 
 int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps) {
     const int64_t z = pnnp_wgrad_splits(B, H, W, M, N, taps);
-    return z * ((int64_t)M * N * taps + M);
+    return z * ((int64_t)M * N * (taps == 18 ? 9 : taps) + M);
 }
 
 // dW (+ optional dbias) of Conv2d 3x3 / 1x1 (taps = 9 / 1):
@@ -342,6 +355,34 @@ int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Co
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
                        as_stream(stream), a.slab, dW, n, a.Z, accumulate);
     (void)dbias;   // the bias gradient of a ConvTranspose2d is a plain channel sum: pnnp_channel_sum_f32
+    return pnnp_launch_status();
+}
+
+// dW (+ dbias) of Conv2d 3x3 stride 2 pad 1 (ResUnet down-sampling, archs/modules.py:130-138):
+//   g [B][H/2][W/2][Cout]; x [B][H][W][Cin]; dW [Cout][Cin][3][3].  Workspace: query with taps = 18
+//   and the OUTPUT size (H/2, W/2).
+int pnnp_conv3x3s2_bwd_weight_f32(const float* g, int Cout, const float* x, int Cin, float* dW, float* dbias,
+                                  int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats,
+                                  void* stream) {
+    if (!g || !x || !dW || !workspace || B <= 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if ((Cout & 3) || (Cin & 3)) return PNNP_E_UNSUPPORTED;
+    const int h = H / 2, w = W / 2;
+    if (workspace_floats < pnnp_wgrad_workspace_floats(B, h, w, Cout, Cin, 18)) return PNNP_E_WORKSPACE;
+    WgradArgs a{};
+    a.U = g; a.Ucs = Cout;
+    a.S[0] = x; a.Scs[0] = Cin; a.S[1] = x; a.Scs[1] = Cin; a.n_split = 1 << 30;
+    a.s_mul = 2; a.SH = H; a.SW = W; a.B = B; a.DH = h; a.DW = w; a.M = Cout; a.N = Cin;
+    a.Z = pnnp_wgrad_splits(B, h, w, Cout, Cin, 18);
+    a.slab = workspace;
+    a.bias_slab = dbias ? workspace + (int64_t)a.Z * Cout * Cin * 9 : nullptr;
+    const int rc = launch_s2(a, pick_shape(Cout, Cin), as_stream(stream));
+    if (rc != PNNP_OK) return rc;
+    const int64_t n = (int64_t)Cout * Cin * 9;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
+                       as_stream(stream), a.slab, dW, n, a.Z, accumulate);
+    if (dbias)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, as_stream(stream), a.bias_slab, dbias,
+                           (int64_t)Cout, a.Z, accumulate);
     return pnnp_launch_status();
 }
 

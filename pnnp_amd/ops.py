@@ -69,6 +69,16 @@ def conv_bwd_data(g, w_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask
                                              ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
 
 
+def conv_bwd_data_res(g, w_dgrad, dx, addsrc, mask=None, mode=0, taps=9):
+    """dx = (conv_bwd_data(g) + addsrc) * act'(mask): backward through an identity shortcut."""
+    require_cuda(g, w_dgrad, dx, addsrc)
+    B, H, W, Cout = g.shape
+    C1 = dx.shape[3]
+    with _Timed('conv%d_dgrad' % taps, 2.0 * B * H * W * Cout * C1 * taps, 4.0 * B * H * W * (2 * C1 + Cout)):
+        check(_prep().pnnp_conv_bwd_data_res_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
+                                                 B, H, W, taps, stream()), 'conv_bwd_data_res')
+
+
 def wgrad_workspace_floats(B, H, W, M, N, taps):
     return int(_prep().pnnp_wgrad_workspace_floats(B, H, W, M, N, taps))
 
@@ -105,6 +115,37 @@ def convt_bwd_weight(x, g, dW, ws, accumulate=0):
     with _Timed('convt_wgrad', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
         check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), None, B, H, W, accumulate,
                                                    ptr(ws), _i64(ws.numel()), stream()), 'convt_bwd_weight')
+
+
+def conv_s2_fwd(x, w_packed, bias, y, cout, act=0):
+    """Conv2d 3x3 stride 2 pad 1: x [B,H,W,Cin] -> y [B,H/2,W/2,cout]."""
+    require_cuda(x, w_packed, y)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_fwd', 2.0 * B * (H // 2) * (W // 2) * cout * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_fwd_f32(ptr(x), Cin, ptr(w_packed), ptr(bias), ptr(y), B, H, W, cout, act, stream()),
+              'conv3x3s2_fwd')
+    return y
+
+
+def pack_conv_s2_dgrad(w, dst):
+    co, ci = w.shape[:2]
+    check(_prep().pnnp_pack_conv3x3s2_dgrad_f32(ptr(w), ptr(dst), co, ci, stream()), 'pack_conv3x3s2_dgrad')
+
+
+def conv_s2_bwd_data(g, w_s2dgrad, dx, mask=None, mode=0, accum=0):
+    require_cuda(g, w_s2dgrad, dx)
+    B, H, W, Cin = dx.shape
+    with _Timed('conv9s2_dgrad', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_bwd_data_f32(ptr(g), g.shape[3], ptr(w_s2dgrad), ptr(dx), Cin, ptr(mask), mode, accum,
+                                                  B, H, W, stream()), 'conv3x3s2_bwd_data')
+
+
+def conv_s2_bwd_weight(g, x, dW, dbias, ws, accumulate=0):
+    require_cuda(g, x, dW, ws)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_wgrad', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_bwd_weight_f32(ptr(g), g.shape[3], ptr(x), Cin, ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                    ptr(ws), _i64(ws.numel()), stream()), 'conv3x3s2_bwd_weight')
 
 
 def maxpool_fwd(x, y):

@@ -40,12 +40,13 @@ class BucketedAllReduce:
     one link per direction, ~0.35 ms for the 31 MB of UNet gradients -- a few 8 MB buckets keep
     each collective bandwidth-bound rather than latency-bound while leaving >= 3 to pipeline."""
 
-    def __init__(self, flat, bucket_bytes=8 << 20, group=None):
+    def __init__(self, flat, bucket_bytes=8 << 20, group=None, force=False):
         import torch.distributed as dist
         self.dist = dist
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the collective path at world size 1
         n = flat.numel()
         per = max(1, bucket_bytes // 4)
         edges = list(range(n, 0, -per))[::-1]            # bucket starts, counted from the end
@@ -63,7 +64,7 @@ class BucketedAllReduce:
     def ready(self, offset):
         """Everything at flat[offset:] has its final gradient: launch every bucket that lies
         entirely in that range."""
-        if self.world == 1:
+        if not self.active:
             return
         while self.pending >= 0 and self.buckets[self.pending][0] >= offset:
             s, e = self.buckets[self.pending]
@@ -101,7 +102,7 @@ class HipTrainStep:
     ``[loss, sse_0 .. sse_{B-1}]`` without synchronising."""
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
-                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20):
+                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False):
         self.net = net
         self.engine = net.engine
         self.lr = lr
@@ -109,6 +110,7 @@ class HipTrainStep:
         self.seed = seed
         self.rank, self.world, self.group = rank, world, group
         self.bucket_bytes = bucket_bytes
+        self.force_reducer = force_reducer
         self.step_count = 0
         self.m = self.v = None
         self.reducer = None
@@ -120,8 +122,8 @@ class HipTrainStep:
         if self.m is None or self.m.numel() != flat.numel() or self.m.device != device:
             self.m = torch.zeros_like(flat)
             self.v = torch.zeros_like(flat)
-        if self.world > 1 and (self.reducer is None or self.reducer.flat is not self.engine.params.grad):
-            self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group)
+        if (self.world > 1 or self.force_reducer) and (self.reducer is None or self.reducer.flat is not self.engine.params.grad):
+            self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group, force=self.force_reducer)
 
     def sample_noise_params(self, batch):
         """trainer_SID.py:451-459: one host-side parameter draw per crop."""

@@ -185,6 +185,38 @@ def test_convt(case):
     close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'convT bgrad {case}')
 
 
+@pytest.mark.parametrize('case', [(1, 8, 32, 8, 16), (2, 16, 64, 32, 64), (1, 12, 40, 64, 128), (1, 6, 70, 128, 256),
+                                  (1, 4, 4, 256, 512), (1, 34, 66, 16, 8)])
+def test_conv3x3_stride2(case):
+    """ResUnet down-sampling conv (archs/modules.py:130-138): forward, backward-data (4 parity-class
+    GEMMs), backward-weight, vs F.conv2d(stride=2, padding=1)."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = case
+    x = _rand(B, Ci, H, W, seed=1).requires_grad_(True)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True); b = _rand(Co, seed=3).requires_grad_(True)
+    y = F.conv2d(x, w, b, stride=2, padding=1)
+    g = _rand(B, Co, H // 2, W // 2, seed=4)
+    y.backward(g)
+    f = torch.empty(w.numel(), device='cuda'); d = torch.empty(w.numel(), device='cuda')
+    ops.pack_conv_weight(w.detach().cuda(), f, None)
+    ops.pack_conv_s2_dgrad(w.detach().cuda(), d)
+    yo = torch.full((B, H // 2, W // 2, Co), float('nan'), device='cuda')
+    ops.conv_s2_fwd(nhwc(x.detach()).cuda(), f, b.detach().cuda(), yo, Co)
+    close(nchw(yo), y, what=f's2 fwd {case}')
+    dx = torch.full((B, H, W, Ci), float('nan'), device='cuda')
+    ops.conv_s2_bwd_data(nhwc(g).cuda(), d, dx)
+    close(nchw(dx), x.grad, what=f's2 dgrad {case}')
+    m = _rand(B, Ci, H, W, seed=5); base = _rand(B, Ci, H, W, seed=6)
+    dx = nhwc(base).cuda().clone()
+    ops.conv_s2_bwd_data(nhwc(g).cuda(), d, dx, mask=nhwc(m).cuda(), mode=2, accum=1)
+    close(nchw(dx), base + x.grad * (m > 0).float(), what='s2 dgrad mask+accum')
+    ws = torch.empty(ops.wgrad_workspace_floats(B, H // 2, W // 2, Co, Ci, 18), device='cuda')
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_s2_bwd_weight(nhwc(g).cuda(), nhwc(x.detach()).cuda(), dW, db, ws)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f's2 wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f's2 bgrad {case}')
+
+
 def test_maxpool_loss_adam():
     from pnnp_amd import ops
     B, H, W, Cc = 2, 12, 20, 16

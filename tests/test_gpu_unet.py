@@ -142,3 +142,31 @@ def test_train_step_with_sampler_runs_and_learns():
     assert torch.equal(n1, n2) and float(n1.max()) <= 1.0 and torch.isfinite(n1).all()
     losses = [float(ts.step(hr, rows=rows)[0]) for _ in range(12)]
     assert np.isfinite(losses).all() and losses[-1] < 0.9 * losses[0], losses
+
+
+def test_rccl_bucketed_reducer_on_one_gpu():
+    """The data-parallel step's collective path (side stream, events, RCCL all-reduce per bucket,
+    Adam waiting on it) exercised with a 1-rank `nccl` group: must equal the plain step bit for bit."""
+    import socket
+    import torch.distributed as dist
+    from oracle import net_torch as O
+    from pnnp_amd.archs import UNetSeeInDark
+    from pnnp_amd.trainer import HipTrainStep
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1,
+                            device_id=torch.device('cuda', 0))
+    try:
+        sd = O.init_state(O.unet_param_shapes(nf=8), seed=11)
+        x = torch.rand(2, 4, 64, 64).cuda(); t = torch.rand(2, 4, 64, 64).cuda()
+        outs = []
+        for force in (False, True):
+            net = _load(UNetSeeInDark(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4)), sd)
+            ts = HipTrainStep(net, lr=1e-3, clip=0, force_reducer=force, bucket_bytes=64 << 10)
+            losses = [float(ts.step(t, noisy=x)[0]) for _ in range(3)]
+            if force:
+                assert ts.reducer is not None and len(ts.reducer.buckets) > 3
+            outs.append((losses, net.engine.params.flat.clone()))
+        assert outs[0][0] == outs[1][0]
+        assert torch.equal(outs[0][1], outs[1][1])
+    finally:
+        dist.destroy_process_group()
