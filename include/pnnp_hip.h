@@ -177,6 +177,16 @@ int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc,
 int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                        float beta2, float eps, int step, float grad_scale, void* stream);
 
+/* ---------------------------------------------------------------- NoiseFlow.sample
+ * archs/noise_flow.py:173-188: z ~ N(0,I) pushed through the reversed bijector chain
+ * 8 x [AffineCoupling^-1, Conv2d1x1^-1] (+ GainISO^-1 after the 4th pair, SignalDependantISO^-1
+ * at the end).  NCHW fp32 [B][4][H][W].  `step` [host] = 317 floats (struct NfStep in csrc/nf.hip):
+ * conv2d_1 w[4][2][9] b[4], BN1 scale[4] offset[4], conv2d_2 w[4][4] b[4], BN2 scale[4] offset[4],
+ * conv2d_3 w[4][5][9] b[4], exp(3*logs)[4], scale, W^-1[4][4] (x ISO gain where it applies). */
+int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
+int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
+                     const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

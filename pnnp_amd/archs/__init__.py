@@ -3,6 +3,7 @@ looked up by name -- ``globals()[arch['name']](arch)`` (trainer_SID.py:17) -- an
 initialised with ``initialize_weights``."""
 import torch.nn as nn
 
+from .noise_flow import NoiseFlow  # noqa: F401
 from .resunet import ResUnet  # noqa: F401
 from .unet import UNetSeeInDark  # noqa: F401
 

@@ -1,0 +1,217 @@
+"""NoiseFlow proxy with the reference's module structure and state_dict (222 keys), sampling on
+HIP kernels (reference: archs/noise_flow.py:24-221, archs/flow_layers/{conv2d1x1,affine_coupling,
+signal_dependant,gain}.py).
+
+Only what the denoiser-training hot path uses is implemented on the device: ``sample(clean=, iso=)``
+(trainer_SID.py:464-472, trainer_LRID.py:420-427).  ``forward``/``loss``/``inverse`` (fitting the flow
+by NLL) are outside this build's scope and raise.  BatchNorm inside the coupling networks runs in
+eval mode (running statistics), as in the SID trainer which calls ``proxy_net.eval()``
+(trainer_SID.py:42); trainer_LRID.py:34-39 forgets that call and samples with batch statistics --
+a reference quirk that is NOT reproduced.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.linalg
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from .._lib import PnnpError
+
+LEGAL_ISO = [50, 64, 80, 100, 125, 160, 200, 250, 320, 400, 500, 640, 800, 1000, 1250, 1600,
+             2000, 2500, 3200, 4000, 5000, 6400, 8000, 10000, 12800, 16000, 20000, 25600, 32000, 40000, 51200]
+BN_EPS = 1e-5
+
+
+class Conv2d1x1(nn.Module):                       # flow_layers/conv2d1x1.py:19-45 (LU-parametrised)
+    def __init__(self, num_channels=4, name='Conv2d1x1'):
+        super().__init__()
+        self.name = name
+        w = np.linalg.qr(np.random.randn(num_channels, num_channels))[0].astype(np.float32)
+        p, l, u = scipy.linalg.lu(w)
+        s = np.diag(u)
+        self.register_buffer('p', torch.tensor(p.astype(np.float32)))
+        self.register_buffer('sign_s', torch.tensor(np.sign(s).astype(np.float32)))
+        self.l = nn.Parameter(torch.tensor(l.astype(np.float32)))
+        self.log_s = nn.Parameter(torch.tensor(np.log(np.abs(s)).astype(np.float32)))
+        self.u = nn.Parameter(torch.tensor(np.triu(u, k=1).astype(np.float32)))
+
+    def inverse_matrix(self):
+        """conv2d1x1.py:66-74: U^-1 L^-1 P^-1 with float64 inverses (host side, 4x4)."""
+        mask = torch.tril(torch.ones(4, 4), -1)
+        l = self.l.detach().cpu() * mask + torch.eye(4)
+        u = self.u.detach().cpu() * mask.t() + torch.diag(self.sign_s.cpu() * torch.exp(self.log_s.detach().cpu()))
+        li = torch.inverse(l.double()).float(); ui = torch.inverse(u.double()).float()
+        return torch.matmul(ui, torch.matmul(li, self.p.cpu().inverse()))
+
+
+class ShiftAndLogScale(nn.Module):                # flow_layers/affine_coupling.py:245-277
+    def __init__(self, num_in=2, num_out=4, width=4):
+        super().__init__()
+        self.scale = nn.Parameter(torch.full((1,), 1e-4))
+        self.conv2d_1 = nn.Conv2d(num_in, width, kernel_size=3, padding=1)
+        nn.init.normal_(self.conv2d_1.weight, mean=0.0, std=width / 512 * 0.05); self.conv2d_1.bias.data.fill_(0.0)
+        self.conv2d_2 = nn.Conv2d(width, width, kernel_size=1, padding=0)
+        nn.init.normal_(self.conv2d_2.weight, mean=0.0, std=width / 512 * 0.05); self.conv2d_2.bias.data.fill_(0.0)
+        self.net = nn.Sequential(self.conv2d_1, nn.BatchNorm2d(width), nn.ReLU(), self.conv2d_2, nn.BatchNorm2d(width), nn.ReLU())
+        self.conv2d_3 = nn.Conv2d(width + 1, num_out, kernel_size=3, padding=0)
+        self.conv2d_3.weight.data.fill_(0.0); self.conv2d_3.bias.data.fill_(0.0)
+        self.logs = nn.Parameter(torch.zeros([1, num_out, 1, 1]))
+
+
+class AffineCoupling(nn.Module):                  # flow_layers/affine_coupling.py:19-34
+    def __init__(self, x_shape, name='real_nvp'):
+        super().__init__()
+        self.name = name
+        self._shift_and_log_scale = ShiftAndLogScale(num_in=x_shape[0] // 2, num_out=2 * (x_shape[0] - x_shape[0] // 2))
+
+
+class SignalDependantISO(nn.Module):              # flow_layers/signal_dependant.py:19-29
+    def __init__(self, name='sdn'):
+        super().__init__()
+        self.name = name
+        self.cam_param = nn.Parameter(torch.zeros(len(LEGAL_ISO), 3), requires_grad=False)
+        self.gain = nn.Parameter(torch.tensor(-6.0))
+        self.beta1 = nn.Parameter(torch.tensor(-5.0))
+        self.beta2 = nn.Parameter(torch.tensor(-4.0))
+
+
+class GainISO(nn.Module):                         # flow_layers/gain.py:65-72
+    def __init__(self, name='giso'):
+        super().__init__()
+        self.name = name
+        self.cam_param = nn.Parameter(torch.zeros(len(LEGAL_ISO)))
+        self.gain_params = nn.Parameter(torch.tensor(-5.0))
+
+
+def _interp(table, iso):
+    """searchsorted(left/right) + linear interpolation of exp(table) (signal_dependant.py:39-43)."""
+    legal = np.asarray(LEGAL_ISO, np.float32)
+    iso = np.float32(iso)
+    l = int(np.searchsorted(legal, iso, side='left')); r = int(np.searchsorted(legal, iso, side='right'))
+    if l >= len(legal) or r >= len(legal):
+        raise IndexError('iso beyond the calibrated table (the reference indexes out of range too)')
+    pl, pr = np.exp(table[l].astype(np.float32)), np.exp(table[r].astype(np.float32))
+    if legal[r] - legal[l] != 0:
+        return ((iso - legal[l]) * pr + (legal[r] - iso) * pl) / (legal[r] - legal[l])
+    return pl
+
+
+class NoiseFlow(nn.Module):
+    """Drop-in for archs/noise_flow.py:24 (args keys: x_shape, arch, flow_permutation, param_inits, lu_decomp)."""
+
+    def __init__(self, args=None):
+        super().__init__()
+        self.args = {'x_shape': (4, 256, 256), 'arch': 'sdn|unc|unc|unc|unc|gain|unc|unc|unc|unc',
+                     'flow_permutation': 1, 'param_inits': None, 'lu_decomp': True}
+        if args is not None:
+            self.args.update(args)
+        self.x_shape = self.args['x_shape']
+        self.arch = self.args['arch']
+        layers = []
+        for i, lyr in enumerate(self.arch.split('|')):          # noise_flow.py:46-111
+            if lyr == 'unc':
+                if self.args['flow_permutation'] == 1:
+                    layers.append(Conv2d1x1(self.x_shape[0], name=f'Conv2d_1x1_{i}'))
+                layers.append(AffineCoupling(self.x_shape, name=f'unc_{i}'))
+            elif lyr == 'sdn':
+                layers.append(SignalDependantISO(name=f'sdn_{i}'))
+            elif lyr == 'giso':
+                layers.append(GainISO(name=f'giso_{i}'))
+        self.model = nn.ModuleList(layers)
+        self._steps = None
+        self._steps_key = None
+        self.seed, self.offset = 1997, 0
+
+    # ------------------------------------------------------------------ host-side step tables
+    def _plan(self):
+        """Reversed chain -> list of (AffineCoupling, Conv2d1x1, gain_after: bool, sdn_after: module|None)."""
+        rev = list(self.model)[::-1]
+        plan, i = [], 0
+        while i < len(rev):
+            m = rev[i]
+            if isinstance(m, AffineCoupling):
+                if i + 1 >= len(rev) or not isinstance(rev[i + 1], Conv2d1x1):
+                    raise PnnpError('HIP NoiseFlow.sample supports unc = [Conv2d1x1, AffineCoupling] pairs (flow_permutation=1)')
+                plan.append([m, rev[i + 1], None, None]); i += 2
+            elif isinstance(m, GainISO):
+                plan[-1][2] = m; i += 1
+            elif isinstance(m, SignalDependantISO):
+                plan[-1][3] = m; i += 1
+            else:
+                raise PnnpError(f'unsupported flow layer {type(m).__name__}')
+        return plan
+
+    def _tables(self):
+        key = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+        if self._steps is not None and key == self._steps_key:
+            return self._steps
+        steps = []
+        for ac, cv, g_after, s_after in self._plan():
+            s = ac._shift_and_log_scale
+            f = lambda t: t.detach().cpu().float().numpy().reshape(-1)
+            bn1, bn2 = s.net[1], s.net[4]
+            def fold(bn):
+                sc = bn.weight.detach().cpu() / torch.sqrt(bn.running_var.cpu() + BN_EPS)
+                return f(sc), f(bn.bias.detach().cpu() - bn.running_mean.cpu() * sc)
+            s1, o1 = fold(bn1); s2, o2 = fold(bn2)
+            vec = np.concatenate([f(s.conv2d_1.weight), f(s.conv2d_1.bias), s1, o1,
+                                  f(s.conv2d_2.weight), f(s.conv2d_2.bias), s2, o2,
+                                  f(s.conv2d_3.weight), f(s.conv2d_3.bias), np.exp(3.0 * f(s.logs)),
+                                  f(s.scale), np.zeros(16, np.float32)]).astype(np.float32)
+            assert vec.size == 317
+            steps.append((vec, cv.inverse_matrix().numpy().astype(np.float32), g_after, s_after))
+        self._steps, self._steps_key = steps, key
+        return steps
+
+    # ------------------------------------------------------------------ API
+    def forward(self, **kwargs):
+        mode = kwargs.get('mode', 'forward')
+        if mode == 'sample':
+            return self.sample(**kwargs)
+        raise NotImplementedError('only NoiseFlow.sample runs on the HIP path (NLL fitting is out of scope)')
+
+    def loss(self, **kwargs):
+        raise NotImplementedError('NoiseFlow.loss (NLL fitting) is out of scope of the HIP hot path')
+
+    def inverse(self, **kwargs):
+        raise NotImplementedError('NoiseFlow.inverse is out of scope of the HIP hot path')
+
+    def sample(self, **kwargs):
+        """noise_flow.py:173-188.  kwargs: clean [B,4,H,W] (CUDA), iso (scalar / 0-dim tensor);
+        optional ``z`` injects the prior draw (else N(0,1) from the counter-based generator)."""
+        clean = kwargs['clean'] if 'clean' in kwargs else kwargs['noise']
+        _lib.require_cuda(clean)
+        clean = clean.contiguous().float()
+        iso = float(kwargs['iso'])
+        B, Cc, H, W = clean.shape
+        L = _lib.lib()
+        z = kwargs.get('z')
+        if z is None:
+            z = torch.empty_like(clean)
+            _lib.check(L.pnnp_normal_fill_f32(_lib.ptr(z), C.c_int64(z.numel()), C.c_uint64(self.seed), C.c_uint64(self.offset),
+                                              _lib.stream()), 'normal_fill')
+            self.offset += 1
+        else:
+            z = z.contiguous().float().clone()       # the ping-pong below overwrites its buffers
+        cur, nxt = z, torch.empty_like(clean)
+        for vec, winv, g_after, s_after in self._tables():
+            w = winv.copy()
+            if g_after is not None:        # gain.py:79-86: x * exp(cam*gain_params) * iso  (scalar: folded into W^-1)
+                w *= np.float32(np.exp(_interp(g_after.cam_param.detach().cpu().numpy(), iso) *
+                                       np.float32(g_after.gain_params.item())) * np.float32(iso))
+            vec = vec.copy(); vec[301:317] = w.reshape(-1)
+            a = b = np.float32(0.0); cl = None
+            if s_after is not None:        # signal_dependant.py:37-51: sqrt(beta1*clean/gain + beta2)
+                cam = _interp(s_after.cam_param.detach().cpu().numpy(), iso)
+                beta1 = np.exp(np.float32(s_after.beta1.item()) * cam[0]); beta2 = np.exp(np.float32(s_after.beta2.item()) * cam[1])
+                gain = np.exp(np.float32(s_after.gain.item()) * cam[2]) * np.float32(iso)
+                a, b, cl = np.float32(beta1 / gain), np.float32(beta2), clean
+                if float(a) * float(clean.min()) + float(b) < 0:
+                    raise AssertionError('scale must be non-negative')      # signal_dependant.py:50
+            buf = (C.c_float * 317)(*vec.tolist())
+            _lib.check(L.pnnp_nf_step_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
+                                          C.c_float(1.0), _lib.stream()), 'nf_step')
+            cur, nxt = nxt, cur
+        return cur

@@ -1,0 +1,168 @@
+// NoiseFlow.sample on the device (reference: archs/noise_flow.py:173-188 and the bijector
+// inverses it chains: flow_layers/affine_coupling.py:27-34,245-295, conv2d1x1.py:47-92,
+// gain.py:79-93, signal_dependant.py:37-57).
+//
+// The reversed chain is 8 x [AffineCoupling^-1, Conv2d1x1^-1] with the ISO gain after the 4th pair
+// and the signal-dependent scale at the end.  One kernel = one pair (+ the optional final scale):
+// an HBM-streaming pass (read 4 planes, write 4 planes) whose coupling network
+//   conv3x3(2->4)+BN+ReLU -> conv1x1(4->4)+BN+ReLU -> [pad + border-ones channel] -> conv3x3(5->4)
+// is evaluated from an LDS tile (z0 with a 2-pixel halo, hidden map with a 1-pixel halo); the scalar
+// ISO gain is folded into the 4x4 inverse matrix on the host.  NCHW fp32, like the reference.
+#include "common.h"
+#include <string.h>
+
+struct NfStep {              // 317 floats, passed by value as a kernel argument
+    float w1[4][2][9], b1[4], s1[4], o1[4];   // conv2d_1, eval-mode BatchNorm folded to y = s*x + o
+    float w2[4][4], b2[4], s2[4], o2[4];      // conv2d_2 (1x1) + BatchNorm
+    float w3[4][5][9], b3[4], e3[4];          // conv2d_3 (input channel 4 = border-ones), exp(3*logs)
+    float scale;                              // log_scale = scale * tanh(.)
+    float winv[4][4];                         // the Conv2d1x1 inverse that follows (x gain where it applies)
+};
+
+namespace {
+
+constexpr int TS = 32;                        // output tile
+constexpr int ZW = TS + 4, HW_ = TS + 2;      // z0 tile with halo 2, hidden tile with halo 1
+
+__device__ __forceinline__ uint4 philox_nf(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return make_uint4(c0, c1, c2, c3);
+}
+
+__device__ __forceinline__ float u01_nf(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f; }
+
+// z ~ N(0,1): 4 values per Philox block (two Box-Muller pairs, both outputs used)
+__global__ void __launch_bounds__(256)
+normal_fill_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1, uint32_t off) {
+    const int64_t n4 = (n + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint4 r = philox_nf((uint32_t)i, (uint32_t)(i >> 32), 0x4E46u, off, k0, k1);
+        const float ra = sqrtf(-2.f * logf(u01_nf(r.x))), rb = sqrtf(-2.f * logf(u01_nf(r.z)));
+        const float ta = 6.28318530717958647692f * u01_nf(r.y), tb = 6.28318530717958647692f * u01_nf(r.w);
+        const float v[4] = {ra * cosf(ta), ra * sinf(ta), rb * cosf(tb), rb * sinf(tb)};
+        for (int k = 0; k < 4; ++k)
+            if (4 * i + k < n) out[4 * i + k] = v[k];
+    }
+}
+
+__global__ void __launch_bounds__(256)
+nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, const NfStep p,
+               const float* __restrict__ clean, float sdn_a, float sdn_b, float out_mul) {
+    __shared__ float z0s[2][ZW][ZW + 1];
+    __shared__ float hs[4][HW_][HW_ + 1];
+    const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+    const int64_t plane = (int64_t)H * W;
+    const float* xb = x + (int64_t)b * 4 * plane;
+    // z0 tile (channels 0,1) with halo 2; zero outside the image (conv2d_1 pads with zeros)
+    for (int i = threadIdx.x; i < 2 * ZW * ZW; i += 256) {
+        const int c = i / (ZW * ZW), r = (i / ZW) % ZW, q = i % ZW;
+        const int gy = ty0 + r - 2, gx = tx0 + q - 2;
+        z0s[c][r][q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[c * plane + (int64_t)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+    // hidden map h2 (4 channels) on the tile + halo 1; positions outside the image are the zero pad
+    for (int i = threadIdx.x; i < HW_ * HW_; i += 256) {
+        const int r = i / HW_, q = i % HW_;
+        const int gy = ty0 + r - 1, gx = tx0 + q - 1;
+        float h2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float h1[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = p.b1[o];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) s += p.w1[o][c][t] * z0s[c][r + t / 3][q + t % 3];
+                h1[o] = fmaxf(p.s1[o] * s + p.o1[o], 0.f);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = p.b2[o];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += p.w2[o][c] * h1[c];
+                h2[o] = fmaxf(p.s2[o] * s + p.o2[o], 0.f);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) hs[o][r][q] = h2[o];
+    }
+    __syncthreads();
+    // outputs: 4 pixels per thread
+    for (int i = threadIdx.x; i < TS * TS; i += 256) {
+        const int r = i / TS, q = i % TS;
+        const int gy = ty0 + r, gx = tx0 + q;
+        if (gy >= H || gx >= W) continue;
+        float o3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float s = p.b3[o];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += p.w3[o][c][t] * hs[c][r + t / 3][q + t % 3];
+                // channel 4: ones on the border ring of the padded map, i.e. exactly the out-of-image taps
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) s += p.w3[o][4][t];
+            }
+            o3[o] = s * p.e3[o];
+        }
+        const int64_t pix = (int64_t)gy * W + gx;
+        const float z0a = z0s[0][r + 2][q + 2], z0b = z0s[1][r + 2][q + 2];
+        const float z1a = xb[2 * plane + pix], z1b = xb[3 * plane + pix];
+        const float v[4] = {z0a, z0b,
+                            (z1a - o3[0]) * expf(-(p.scale * tanhf(o3[2]))),
+                            (z1b - o3[1]) * expf(-(p.scale * tanhf(o3[3])))};
+        float post = out_mul;
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s += p.winv[o][c] * v[c];
+            if (clean) {
+                const float cl = clean[((int64_t)b * 4 + o) * plane + pix];
+                post = out_mul * sqrtf(sdn_a * cl + sdn_b);
+            }
+            y[((int64_t)b * 4 + o) * plane + pix] = s * post;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+// out[i] ~ N(0,1), counter-based (Philox4x32-10, Box-Muller); the prior draw of NoiseFlow.sample
+// (archs/noise_flow.py:208-221 draws it with torch.normal).
+int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream) {
+    if (n < 0 || (n && !out)) return PNNP_E_INVALID;
+    if (n == 0) return PNNP_OK;
+    int64_t blocks = ((n + 3) / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(normal_fill_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), out, n,
+                       (uint32_t)seed, (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), (uint32_t)offset);
+    return pnnp_launch_status();
+}
+
+// One [AffineCoupling^-1, Conv2d1x1^-1] pair of the reversed chain on x [B][4][H][W] -> y.
+// step [host]: 317 floats laid out as struct NfStep.  clean (optional, [B][4][H][W]): multiply the
+// result by sqrt(sdn_a*clean + sdn_b) (SignalDependantISO^-1, last pair); out_mul: scalar factor.
+int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
+                     const float* clean, float sdn_a, float sdn_b, float out_mul, void* stream) {
+    if (!x || !y || !step || B < 0 || H <= 0 || W <= 0 || x == y) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    NfStep p;
+    static_assert(sizeof(NfStep) == 317 * sizeof(float), "NfStep layout");
+    memcpy(&p, step, sizeof p);
+    hipLaunchKernelGGL(nf_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
+                       x, y, H, W, p, clean, sdn_a, sdn_b, out_mul);
+    return pnnp_launch_status();
+}
+
+}  // extern "C"

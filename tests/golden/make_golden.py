@@ -312,14 +312,76 @@ def gen_misc(base_trainer, losses, data_process):
                         psnr4=np.float64(ps4), psnr3=np.float64(ps3), ic_src=src.numpy(), ic_out=ic.numpy())
 
 
+# ------------------------------------------------------------------ G8 NoiseFlow.sample
+def gen_noiseflow():
+    """NoiseFlow().sample() of the reference on CPU with an injected prior draw z.  The reference
+    hard-requires CUDA in two places (affine_coupling.py:20 device default, conv2d1x1.py:73 .cuda());
+    both are patched to CPU for this capture only."""
+    import torch
+    import archs.noise_flow as NFm
+    _AC = NFm.AffineCoupling
+    NFm.AffineCoupling = lambda **kw: _AC(device='cpu', **kw)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    np.random.seed(0); torch.manual_seed(0)
+    net = NFm.NoiseFlow({'x_shape': (4, 32, 32), 'arch': 'sdn|unc|unc|unc|unc|giso|unc|unc|unc|unc'}).eval()   # runfiles/*/NF.yml:60-62
+    sd = net.state_dict()
+    g = torch.Generator().manual_seed(123)
+    with torch.no_grad():        # zero-initialised pieces would make the couplings the identity: perturb them
+        for k, v in sd.items():
+            if k.endswith('conv2d_3.weight') or k.endswith('conv2d_3.bias'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.3)
+            elif k.endswith('.logs'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('_shift_and_log_scale.scale'):
+                v.fill_(0.7)
+            elif k.endswith('running_mean'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.05)
+            elif k.endswith('running_var'):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.5)
+            elif 'net.1.weight' in k or 'net.4.weight' in k:
+                v.copy_(torch.rand(v.shape, generator=g) + 0.5)
+            elif 'net.1.bias' in k or 'net.4.bias' in k:
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+            elif k.endswith('conv2d_1.weight') or k.endswith('conv2d_2.weight') or k.endswith('net.0.weight') or k.endswith('net.3.weight'):
+                pass
+            elif k.endswith('cam_param'):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.2)
+        for k in list(sd.keys()):   # conv2d_1/2 appear twice (also inside .net): give them real weights once
+            if k.endswith('conv2d_1.weight') or k.endswith('conv2d_2.weight'):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.4)
+            if k.endswith('conv2d_1.bias') or k.endswith('conv2d_2.bias'):
+                sd[k].copy_(torch.randn(sd[k].shape, generator=g) * 0.1)
+    net.load_state_dict(sd)
+    out = {'keys': np.array(list(sd.keys()))}
+    for k, v in net.state_dict().items():
+        out['sd:' + k] = v.numpy()
+    clean = torch.rand(2, 4, 32, 32, generator=g) * 0.01
+    z = torch.randn(2, 4, 32, 32, generator=g)
+    out['clean'] = clean.numpy(); out['z'] = z.numpy()
+    orig = NFm.gaussian_diag
+    def fixed(mean, logsd):
+        o = orig(mean, logsd)
+        o.eps = z
+        o.sample = mean + torch.exp(logsd) * z
+        return o
+    NFm.gaussian_diag = fixed
+    for iso in (100, 1600, 3000, 6400):
+        with torch.no_grad():
+            x = net.sample(clean=clean, iso=torch.tensor(float(iso)))
+        out[f'out_iso{iso}'] = x.numpy()
+    NFm.gaussian_diag = orig
+    np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
+
+
 def main():
     archs, proc, isp, losses, data_process, base_trainer = import_reference()
-    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc']
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow']
     if 'pack' in which: gen_pack(isp)
     if 'params' in which: gen_params(proc)
     if 'noise' in which: gen_noise(proc)
     if 'nets' in which: gen_nets(archs, losses)
     if 'misc' in which: gen_misc(base_trainer, losses, data_process)
+    if 'noiseflow' in which: gen_noiseflow()
     print('golden fixtures written to', HERE)
 
 
