@@ -27,7 +27,7 @@ import time
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
-GFLOP_PER_CROP_TRAIN = 289.70      # fwd + dgrad (no conv1_1) + wgrad, UNet nf=32 @4x512x512
+GFLOP_PER_CROP_TRAIN = {'unet': 289.70, 'resunet': 375.07}   # fwd + dgrad + wgrad, nf=32 @4x512x512
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
@@ -67,6 +67,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='crops per GPU per step')
     ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--arch', default='unet', choices=['unet', 'resunet'], help='resunet + --noise noiseflow = BASELINE config 5')
+    ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline becomes whole-step)')
     args = ap.parse_args()
@@ -90,18 +92,28 @@ def main():
     torch.cuda.set_device(dev)
 
     from pnnp_amd import ops
-    from pnnp_amd.archs import UNetSeeInDark, initialize_weights
+    from pnnp_amd.archs import NoiseFlow, ResUnet, UNetSeeInDark, initialize_weights
     from pnnp_amd.trainer import HipTrainStep
 
     torch.manual_seed(1997)                     # same init on every rank (utils/utils.py:45-48 seeds 1997)
-    net = UNetSeeInDark(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
+    np.random.seed(1997)
+    net = (UNetSeeInDark if args.arch == 'unet' else ResUnet)(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
     initialize_weights(net)
+    proxy = None
+    if args.noise == 'noiseflow':               # random-init proxy (no checkpoint here), non-trivial couplings
+        proxy = NoiseFlow({'x_shape': (4, args.size, args.size), 'arch': 'sdn|unc|unc|unc|unc|giso|unc|unc|unc|unc'})
+        with torch.no_grad():
+            for k, v in proxy.state_dict().items():
+                if k.endswith('conv2d_3.weight'):
+                    v.normal_(0, 0.05)
+        proxy = proxy.to(dev).eval()
     net = net.to(dev)
     ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
                       rank=rank, world=world)
     B, S = args.batch, args.size
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     hr = torch.rand(B, 4, S, S, device=dev, generator=g)          # synthetic clean crops, resident in HBM
+    hr_nf = hr * 0.01                                             # dark crops for the NoiseFlow proxy (clean/gain scale)
 
     def barrier():
         if world > 1:
@@ -110,6 +122,9 @@ def main():
 
     def one_step(step):
         np.random.seed(1997 + step * world + rank)                # per-crop params from sample_params_max
+        if proxy is not None:                                     # config 5: NoiseFlow proxy, IMX686 ratios {1,2,4,8,16}
+            noisy, _, _ = ts.make_noisy_proxy(hr_nf, proxy, ratio_choices=(1, 2, 4, 8, 16), iso=6400)
+            return ts.step(hr_nf, noisy=noisy)
         return ts.step(hr)
 
     for i in range(args.warmup):
@@ -136,12 +151,12 @@ def main():
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params) + UNetSeeInDark nf=32 train step "
-                                   "(fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
+            "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else "NoiseFlow.sample proxy (iso 6400, ratio in {1,2,4,8,16})") +
+                                   (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
             "final_loss": loss_val,
         }
-        step_tflops = GFLOP_PER_CROP_TRAIN * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
+        step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
         classes = {}
         if prof:
             for kind, fl, by, e0, e1 in prof:

@@ -49,6 +49,11 @@ int pnnp_pack_bayer_u16(const uint16_t* src, int B, int H, int W, int64_t src_ro
 int pnnp_pack_bayer_f32(const float* src, int B, int H, int W, int64_t src_row_stride,
                         int64_t src_batch_stride, float* dst, const double* black4 /*[host]*/,
                         double wp, int norm, int clip, void* stream);
+/* pack_raw_bayer  data_process/process.py:40-64: CFA-pattern-aware pack.  pos4 [host] = Bayer offset
+ *   (dy<<1|dx) of the R, G1, B, G2 sites; black4 [host] per-channel black level; float32 arithmetic. */
+int pnnp_pack_bayer_pattern(const void* src, int is_f32, int B, int H, int W, int64_t src_row_stride,
+                            int64_t src_batch_stride, float* dst, const double* black4 /*[host]*/,
+                            double wp, int clip, const int* pos4 /*[host]*/, void* stream);
 /* bayer2raw  utils/isp_ops.py:98-112    f32 [B][4][h][w] -> u16 [B][2h][2w]
  *   clamp(x,0,1) * (wp-bl) + bl in float32 (two roundings), C-cast truncation.        */
 int pnnp_unpack_bayer_u16(const float* src, int B, int h, int w, uint16_t* dst,

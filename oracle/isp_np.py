@@ -86,3 +86,17 @@ def rows2bayer(rows):
     out[0::2] = rows[0]
     out[1::2] = rows[1]
     return out
+
+
+def pack_raw_bayer(raw, wp=1023, clip=True):
+    """data_process/process.py:40-64 (CFA-pattern-aware pack of a rawpy object; float32 arithmetic)."""
+    im = np.asarray(raw.raw_image_visible).astype(np.float32)
+    pat = np.asarray(raw.raw_pattern)
+    planes = []
+    for c in range(4):
+        r, q = np.where(pat == c)
+        planes.append(im[r[0]::2, q[0]::2])
+    out = np.stack(planes, axis=0).astype(np.float32)
+    black = np.array(raw.black_level_per_channel)[:, None, None].astype(np.float32)
+    out = (out - black) / (wp - black)
+    return np.clip(out, 0.0, 1.0) if clip else out

@@ -11,6 +11,8 @@ struct PackArgs {
     double black[4];
     double wp;
     int norm, clip;
+    int pos[4];      // Bayer offset of plane c: (dy << 1) | dx; raw2bayer: {0, 1, 3, 2} = R,G1,B,G2
+    int f32math;     // normalise in float32 (pack_raw_bayer, process.py:59-61) instead of float64 (raw2bayer)
 };
 
 __device__ __forceinline__ float pack_value(float x, double black, double wp, int norm, int clip) {
@@ -22,6 +24,13 @@ __device__ __forceinline__ float pack_value(float x, double black, double wp, in
     double v = ((double)x - black) / (wp - black);
     if (clip) v = fmin(fmax(v, 0.0), 1.0);
     return (float)v;
+}
+
+__device__ __forceinline__ float pack_value_f32(float x, float black, float wp, int clip) {
+    // numpy: float32 stack - float32 black, / (python-int wp - float32 black) -> all float32
+    float v = __fdiv_rn(__fsub_rn(x, black), __fsub_rn(wp, black));
+    if (clip) v = fminf(fmaxf(v, 0.f), 1.f);
+    return v;
 }
 
 template <typename T>
@@ -68,10 +77,14 @@ pack_bayer_kernel(const T* __restrict__ src, float* __restrict__ dst, int B, int
         float o[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            o[0][i] = pack_value(top[2 * i], a.black[0], a.wp, a.norm, a.clip);      // R  (0,0)
-            o[1][i] = pack_value(top[2 * i + 1], a.black[1], a.wp, a.norm, a.clip);  // G1 (0,1)
-            o[2][i] = pack_value(bot[2 * i + 1], a.black[2], a.wp, a.norm, a.clip);  // B  (1,1)
-            o[3][i] = pack_value(bot[2 * i], a.black[3], a.wp, a.norm, a.clip);      // G2 (1,0)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {      // plane c <- Bayer offset pos[c] (default R,G1,B,G2 = (0,0),(0,1),(1,1),(1,0))
+                const float te = (a.pos[c] & 1) ? top[2 * i + 1] : top[2 * i];
+                const float be = (a.pos[c] & 1) ? bot[2 * i + 1] : bot[2 * i];
+                const float v = (a.pos[c] & 2) ? be : te;
+                o[c][i] = a.f32math ? pack_value_f32(v, (float)a.black[c], (float)a.wp, a.clip)
+                                    : pack_value(v, a.black[c], a.wp, a.norm, a.clip);
+            }
         }
         const int64_t plane = (int64_t)h * w;
         float* d = dst + (int64_t)b * 4 * plane + (int64_t)y * w + 4 * xq;
@@ -166,13 +179,15 @@ int grid_for(int64_t threads) {
 
 template <typename T>
 int pack_impl(const T* src, int B, int H, int W, int64_t rs, int64_t bs, float* dst, const double* black4,
-              double wp, int norm, int clip, void* stream) {
+              double wp, int norm, int clip, void* stream, const int* pos4 = nullptr, int f32math = 0) {
     if (B < 0 || H < 0 || W < 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
     if (B == 0 || H == 0 || W == 0) return PNNP_OK;          // empty input: nothing to do (pointers may be null)
     if (!src || !dst || !black4 || rs < W) return PNNP_E_INVALID;
     PackArgs a;
     for (int i = 0; i < 4; ++i) a.black[i] = black4[i];
-    a.wp = wp; a.norm = norm; a.clip = clip;
+    a.wp = wp; a.norm = norm; a.clip = clip; a.f32math = f32math;
+    static const int default_pos[4] = {0, 1, 3, 2};
+    for (int i = 0; i < 4; ++i) a.pos[i] = (pos4 ? pos4[i] : default_pos[i]) & 3;
     const int64_t total = (int64_t)B * (H / 2) * ((W / 2 + 3) / 4);
     hipLaunchKernelGGL(pack_bayer_kernel<T>, dim3(grid_for(total)), dim3(256), 0, as_stream(stream),
                        src, dst, B, H, W, rs, bs, a);
@@ -211,6 +226,16 @@ int pnnp_pack_bayer_u16(const uint16_t* src, int B, int H, int W, int64_t rs, in
 int pnnp_pack_bayer_f32(const float* src, int B, int H, int W, int64_t rs, int64_t bs, float* dst,
                         const double* black4, double wp, int norm, int clip, void* stream) {
     return pack_impl<float>(src, B, H, W, rs, bs, dst, black4, wp, norm, clip, stream);
+}
+
+// pack_raw_bayer (process.py:40-64): the CFA-pattern-aware variant.  pos4 [host]: Bayer offset
+// (dy << 1 | dx) of R, G1, B, G2 (from rawpy's raw_pattern); black4 [host] per-channel black level;
+// arithmetic in float32 like the reference: (x - black) / (wp - black), optional clip to [0,1].
+int pnnp_pack_bayer_pattern(const void* src, int is_f32, int B, int H, int W, int64_t rs, int64_t bs, float* dst,
+                            const double* black4, double wp, int clip, const int* pos4, void* stream) {
+    if (!pos4) return PNNP_E_INVALID;
+    if (is_f32) return pack_impl<float>((const float*)src, B, H, W, rs, bs, dst, black4, wp, 1, clip, stream, pos4, 1);
+    return pack_impl<uint16_t>((const uint16_t*)src, B, H, W, rs, bs, dst, black4, wp, 1, clip, stream, pos4, 1);
 }
 
 int pnnp_unpack_bayer_u16(const float* src, int B, int h, int w, uint16_t* dst, int wp, int bl, void* stream) {

@@ -183,6 +183,28 @@ def sample_params(camera_type='NikonD850', ln_ratio=False):
             'wp': params['wp'], 'bl': params['bl']}
 
 
+def pack_raw_bayer(raw, wp=1023, clip=True):
+    """process.py:40-64: pack a rawpy-like object (``raw_image_visible``, ``raw_pattern`` 2x2 with the
+    colour indices 0..3 = R,G1,B,G2, ``black_level_per_channel``) to f32 [4,H/2,W/2]; float32
+    arithmetic like the reference; runs on the HIP pack kernel, returns numpy like the reference."""
+    im = np.ascontiguousarray(raw.raw_image_visible)
+    pat = np.asarray(raw.raw_pattern)
+    pos = (C.c_int * 4)()
+    for c in range(4):
+        r, q = np.where(pat == c)
+        pos[c] = (int(r[0]) << 1) | int(q[0])
+    black = (C.c_double * 4)(*[float(np.float32(b)) for b in raw.black_level_per_channel])
+    is_f32 = im.dtype == np.float32
+    if not is_f32:
+        im = im.astype(np.uint16) if im.dtype != np.uint16 else im
+    x = torch.from_numpy(im).cuda()
+    H, W = x.shape
+    out = torch.empty((4, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().pnnp_pack_bayer_pattern(_lib.ptr(x), int(is_f32), 1, H, W, C.c_int64(W), C.c_int64(H * W), _lib.ptr(out),
+                                                  black, C.c_double(float(wp)), int(bool(clip)), pos, _lib.stream()), 'pack_bayer_pattern')
+    return out.cpu().numpy()
+
+
 # ---------------------------------------------------------------------------- device sampler
 _FLAG = dict(p=0x01, g=0x02, r=0x04, q=0x08, d=0x10, b=0x20)
 F_ORI, F_CLIP, F_TORCH = 0x100, 0x200, 0x1000

@@ -143,6 +143,28 @@ class HipTrainStep:
         return process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count,
                                     crop_base=self.rank * B), rows
 
+    LEGAL_ISO = (50, 64, 80, 100, 125, 160, 200, 250, 320, 400, 500, 640, 800, 1000, 1250, 1600, 2000, 2500, 3200,
+                 4000, 5000, 6400, 8000, 10000, 12800, 16000, 20000, 25600)             # trainer_SID.py:33-34
+
+    def make_noisy_proxy(self, hr, proxy_net, ratio=None, iso=None, ratio_choices=None):
+        """preprocess() with a NoiseFlow proxy (dataset 'NF_Syn_Dataset'):
+        ratio ~ U(100,300) per crop (trainer_SID.py:464) or one draw from ``ratio_choices`` per batch
+        (trainer_LRID.py:33,420: {1,2,4,8,16}); one random legal ISO per batch (:465);
+        noisy = hr + proxy.sample(clean=hr/ratio, iso) * ratio (:466-472); then the clamp (:481-485)."""
+        B = hr.shape[0]
+        if ratio is None:
+            if ratio_choices is not None:
+                ratio = torch.full((B, 1, 1, 1), float(ratio_choices[np.random.randint(len(ratio_choices))]), device=hr.device)
+            else:
+                ratio = torch.rand(B, dtype=torch.float32, device=hr.device).view(-1, 1, 1, 1) * 200 + 100
+        if iso is None:
+            iso = self.LEGAL_ISO[np.random.randint(len(self.LEGAL_ISO))]
+        noise = proxy_net.sample(clean=hr / ratio, iso=iso)
+        noisy = torch.addcmul(hr, noise, ratio)
+        if self.clip:
+            noisy = noisy.clamp_(max=1.0) if self.clip == process.HALF_CLIP else noisy.clamp_(0.0, 1.0)
+        return noisy, ratio, iso
+
     def step(self, hr, plist=None, rows=None, noisy=None, lr=None):
         if not hr.is_cuda:
             raise PnnpError('HipTrainStep needs CUDA tensors (no CPU path)')

@@ -96,6 +96,15 @@ def gen_pack(isp):
     out['maps_rggb_back'] = isp.rggb2bayer(isp.bayer2rggb(b))
     out['maps_rows'] = isp.bayer2rows(b)
     out['maps_rows_back'] = isp.rows2bayer(isp.bayer2rows(b))
+    # pack_raw_bayer (process.py:40-64) on a rawpy-like object, two CFA patterns
+    import data_process.process  # noqa
+    proc = sys.modules['data_process.process']
+    for name, pat, bl in (('rggb', [[0, 1], [3, 2]], [512, 512, 512, 512]), ('gbrg', [[3, 2], [0, 1]], [63.5, 64.25, 64, 65])):
+        im = rng.integers(0, 17000, size=(20, 28), dtype=np.uint16)
+        rawobj = types.SimpleNamespace(raw_image_visible=im, raw_pattern=np.array(pat), black_level_per_channel=bl)
+        for clip in (True, False):
+            out[f'prb_{name}_c{int(clip)}'] = proc.pack_raw_bayer(rawobj, wp=16383, clip=clip)
+        out[f'prb_{name}_im'] = im; out[f'prb_{name}_pat'] = np.array(pat); out[f'prb_{name}_bl'] = np.array(bl, np.float64)
     np.savez_compressed(os.path.join(HERE, 'pack_small.npz'), **out)
     # full-size crop: hash only (input regenerated from the seed in the test)
     big = {}

@@ -66,3 +66,24 @@ def test_prior_draw_statistics_and_api(golden_dir):
     assert abs(float(a.std()) / float(c.std()) - 1) < 0.05 and abs(float(a.mean()) - float(c.mean())) < 0.05 * float(a.std())
     with pytest.raises(NotImplementedError):
         net.loss(noise=clean, clean=clean, iso=1600.0)
+
+
+def test_config5_resunet_with_noiseflow_proxy_step(golden_dir):
+    """BASELINE config 5 plumbing: ResUnet denoiser + NoiseFlow.sample proxy (IMX686 constants:
+    ratio from {1,2,4,8,16}), fused train step: finite, reproducible noise statistics, loss decreases."""
+    from pnnp_amd.archs import ResUnet, initialize_weights
+    from pnnp_amd.trainer import HipTrainStep
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    proxy = _net(g)
+    torch.manual_seed(1); np.random.seed(1)
+    net = ResUnet(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda()
+    ts = HipTrainStep(net, lr=2e-3, clip=2)
+    hr = torch.rand(3, 4, 64, 64, device='cuda') * 0.01
+    noisy, ratio, iso = ts.make_noisy_proxy(hr, proxy, ratio_choices=(1, 2, 4, 8, 16))
+    assert noisy.shape == hr.shape and torch.isfinite(noisy).all() and float(noisy.max()) <= 1.0
+    assert float(ratio.flatten()[0]) in (1, 2, 4, 8, 16) and iso in ts.LEGAL_ISO
+    losses = []
+    for _ in range(10):
+        noisy, _, _ = ts.make_noisy_proxy(hr, proxy, ratio=ratio, iso=1600)
+        losses.append(float(ts.step(hr, noisy=noisy)[0]))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses

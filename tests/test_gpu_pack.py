@@ -85,3 +85,16 @@ def test_batched_and_empty():
         assert np.array_equal(got[b], isp_np.raw2bayer(raw[b], wp=1023, bl=64))
     e = I.raw2bayer(torch.zeros((0, 8), dtype=torch.uint16).cuda(), wp=1023, bl=64)
     assert tuple(e.shape) == (4, 0, 4)
+
+
+def test_pack_raw_bayer_pattern(golden_dir):
+    """process.py:40-64 pack_raw_bayer on a rawpy-like object, RGGB and GBRG patterns: bit-exact."""
+    import types
+    from pnnp_amd import process as P
+    g = np.load(os.path.join(golden_dir, 'pack_small.npz'))
+    for name in ('rggb', 'gbrg'):
+        raw = types.SimpleNamespace(raw_image_visible=g[f'prb_{name}_im'], raw_pattern=g[f'prb_{name}_pat'],
+                                    black_level_per_channel=list(g[f'prb_{name}_bl']))
+        for clip in (True, False):
+            got = P.pack_raw_bayer(raw, wp=16383, clip=clip)
+            assert np.array_equal(got.view(np.uint32), g[f'prb_{name}_c{int(clip)}'].view(np.uint32)), (name, clip)

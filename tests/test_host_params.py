@@ -63,3 +63,20 @@ def test_flags_and_param_rows():
     assert rows.shape == (2, 16)
     assert rows[0, :13].tolist() == pytest.approx([1.5, 2.0, 3.0, -0.1, 0.5, 1 / 2 ** 14, 100.0, 16383, 512, 1, 2, 3, 4])
     assert rows[1, 9:13].tolist() == [0, 0, 0, 0]
+
+
+def test_load_weights_by_name():
+    import torch
+    from pnnp_amd.archs import UNetSeeInDark
+    from pnnp_amd.utils import load_weights, pkl_convert, tensor_dim5to4
+    net = UNetSeeInDark(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4))
+    sd = {k: torch.full_like(v, 0.5) for k, v in net.state_dict().items()}
+    sd['conv1_1.weight'] = torch.zeros(3, 3)              # wrong shape -> dropped
+    sd['not_there.weight'] = torch.zeros(1)                # unknown key -> dropped
+    before = net.state_dict()['conv1_1.weight'].clone()
+    load_weights(net, {'module.' + k: v for k, v in sd.items()} and sd, by_name=True)
+    got = net.state_dict()
+    assert torch.equal(got['conv1_1.weight'], before)
+    assert float(got['conv5_2.bias'].mean()) == 0.5
+    assert set(pkl_convert({'module.a': 1, 'b': 2})) == {'a'}
+    assert tensor_dim5to4(torch.zeros(2, 8, 4, 16, 16)).shape == (16, 4, 16, 16)

@@ -56,3 +56,15 @@ def test_full_crop_hash(golden_dir):
         p = O.raw2bayer(raw, wp=m['wp'], bl=m['bl'], norm=True, clip=True)
         assert _sha(p) == m['packed_sha']
         assert _sha(O.bayer2raw(p, wp=m['wp'], bl=m['bl'])) == m['unpack_sha']
+
+
+def test_pack_raw_bayer(golden_dir):
+    import types
+    g = np.load(os.path.join(golden_dir, 'pack_small.npz'))
+    for name in ('rggb', 'gbrg'):
+        raw = types.SimpleNamespace(raw_image_visible=g[f'prb_{name}_im'], raw_pattern=g[f'prb_{name}_pat'],
+                                    black_level_per_channel=list(g[f'prb_{name}_bl']))
+        for clip in (True, False):
+            got = O.pack_raw_bayer(raw, wp=16383, clip=clip)
+            assert got.dtype == np.float32
+            assert np.array_equal(got.view(np.uint32), g[f'prb_{name}_c{int(clip)}'].view(np.uint32)), (name, clip)
