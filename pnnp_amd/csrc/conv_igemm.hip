@@ -61,35 +61,54 @@ igemm_kernel(const IgemmArgs a) {
 
     float4 ra[NA], rb[NB];                             // staging registers of the NEXT work item
 
-    // issue the global loads of (tile t, chunk g) into ra / rb (no wait)
-    auto prefetch = [&](int t, int g) {
+    // Per-thread constants of the staging pattern (which halo pixel / channel quad / weight slot each
+    // of this thread's float4s is): computed once, so the per-item address arithmetic is a few
+    // 32-bit multiply-adds (the host guarantees every tensor has < 2^31 elements).
+    int pa[NA], pb[NB];
+#pragma unroll
+    for (int k = 0; k < NA; ++k) {
+        const int i = tid + 256 * k;
+        const int cq = i % KQ, pix = i / KQ;
+        const int r = pix / HC, q = pix - r * HC;
+        pa[k] = (i < Cfg::XS_F4) ? (((r - P) & 0xff) << 16) | (((q - P) & 0xff) << 8) | cq : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < NB; ++k) {
+        const int i = tid + 256 * k;
+        const int n = i % BN, rest = i / BN;
+        const int cq = rest % KQ, tt = rest / KQ;
+        pb[k] = (i < Cfg::WS_F4) ? (tt * K4 + cq) * a.Ntot + n : -1;      // float4 index at chunk 0, n0 = 0
+    }
+
+    struct Tile { int b, y0, x0, n0; };
+    auto decode = [&](int t) {                          // scalar divisions: once per tile, not per chunk
+        Tile o;
         const int nt_i = t % n_tiles;
         int m_i = t / n_tiles;
         const int tx = m_i % tiles_x; m_i /= tiles_x;
-        const int ty = m_i % tiles_y;
-        const int b = m_i / tiles_y;
-        const int x0 = tx * 32, y0 = ty * TH, n0 = nt_i * BN;
-        const int si = g / a.chunks_per_seg;
+        o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN;
+        return o;
+    };
+
+    // issue the global loads of (tile, segment si, chunk-in-segment cc, global chunk g) into ra / rb (no wait)
+    auto prefetch = [&](const Tile& tl, int si, int cc, int g) {
         const IgemmSeg sg = a.seg[si];
-        const int c0 = sg.coff + (g - si * a.chunks_per_seg) * KC;
+        const int c0 = sg.coff + cc * KC;
+        const int rowbase = tl.b * a.IH;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int i = tid + 256 * k;
-            const int cq = i % KQ, pix = i / KQ;
-            const int r = pix / HC, q = pix - r * HC;
-            const int gy = (y0 + r - P) * a.in_mul + sg.yoff, gx = (x0 + q - P) * a.in_mul + sg.xoff;
+            const int r = (int)(signed char)(pa[k] >> 16), q = (int)(signed char)(pa[k] >> 8), cq = pa[k] & 0xff;
+            const int gy = (tl.y0 + r) * a.in_mul + sg.yoff, gx = (tl.x0 + q) * a.in_mul + sg.xoff;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < Cfg::XS_F4 && gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
-                v = *reinterpret_cast<const float4*>(sg.ptr + (((int64_t)b * a.IH + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq);
+            if (pa[k] >= 0 && gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
+                v = *reinterpret_cast<const float4*>(sg.ptr + (((rowbase + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq));
             ra[k] = v;
         }
+        const int wb = g * KQ * a.Ntot + tl.n0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            const int i = tid + 256 * k;
-            const int n = i % BN, rest = i / BN;
-            const int cq = rest % KQ, tt = rest / KQ;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < Cfg::WS_F4 && n0 + n < a.Ntot) v = w4[((int64_t)tt * K4 + g * KQ + cq) * a.Ntot + n0 + n];
+            if (pb[k] >= 0 && tl.n0 + (tid + 256 * k) % BN < a.Ntot) v = w4[wb + pb[k]];
             rb[k] = v;
         }
     };
@@ -103,8 +122,17 @@ igemm_kernel(const IgemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     int t = xcd_remap(blockIdx.x, G);
-    int g = 0;
-    if (t < total) prefetch(t, 0);
+    int g = 0, si = 0, cc = 0;                          // global chunk, segment, chunk within segment
+    Tile cur = decode(t < total ? t : 0), nxt = cur;
+    if (t < total) prefetch(cur, 0, 0, 0);
+    // Co-resident workgroups run the same program: started together they stay in lockstep (both stage,
+    // then both share the matrix pipe).  Delaying half of them by part of a chunk's MFMA time puts one
+    // workgroup's staging / address arithmetic under the other's MFMAs.
+    if (a.stagger_mode) {
+        const bool late = a.stagger_mode == 1 ? (int)blockIdx.x >= (G >> 1) : (blockIdx.x & 1);
+        if (late)
+            for (int i = 0; i < a.stagger_n; ++i) __builtin_amdgcn_s_sleep(32);      // 32 x 64 cycles each
+    }
     bool first = true;
     while (t < total) {
         if (!first) __syncthreads();                   // every wave is done reading the previous item
@@ -122,9 +150,13 @@ igemm_kernel(const IgemmArgs a) {
         }
         __syncthreads();
         // ---- next work item: its loads fly while this item's MFMAs run
-        int ng = g + 1, nt = t;
-        if (ng == nchunks) { ng = 0; nt = t + G; }
-        if (nt < total) prefetch(nt, ng);
+        int ng = g + 1, nt = t, nsi = si, ncc = cc + 1;
+        if (ncc == a.chunks_per_seg) { ncc = 0; ++nsi; }
+        if (ng == nchunks) {
+            ng = 0; nsi = 0; ncc = 0; nt = t + G;
+            if (nt < total) nxt = decode(nt);
+        }
+        if (nt < total) prefetch(nxt, nsi, ncc, ng);
         // ---- MFMA over taps x channel octets
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {
@@ -156,13 +188,11 @@ igemm_kernel(const IgemmArgs a) {
             // a private 4 KB LDS patch instead, so a lane owns 4 consecutive channels of a pixel and
             // all epilogue traffic (mask / residual / accumulate loads, the store) is 16 bytes wide:
             // 4 instructions per tile, each covering 8 whole 128-byte pixel rows.
-            const int nt_i = t % n_tiles;
-            int m_i = t / n_tiles;
-            const int tx = m_i % tiles_x; m_i /= tiles_x;
-            const int ty = m_i % tiles_y;
-            const int b = m_i / tiles_y;
-            const int x0 = tx * 32, y0 = ty * TH, n0 = nt_i * BN;
+            const int b = cur.b, x0 = cur.x0, y0 = cur.y0, n0 = cur.n0;
             float* eb = epi + wave * 1024;
+            const bool any_mask = (a.mask_mode[0] | a.mask_mode[1]) != 0, any_accum = (a.accum[0] | a.accum[1]) != 0;
+            const float* mask_any = a.mask_mode[0] ? a.mask[0] : a.mask[1];
+            const float* accum_any = a.accum[0] ? a.dst[0] : a.dst[1];
             const int q4 = (lane & 7) * 4, pr = lane >> 3;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
@@ -192,46 +222,62 @@ igemm_kernel(const IgemmArgs a) {
                         acc[i][k][r] = 0.f;
                     }
                     if (py < a.DH && oy >= 0 && oy < a.OH) {
+                        // Epilogue loads are issued under WAVE-UNIFORM conditions (kernel arguments) and from
+                        // always-valid addresses (offset 0 for lanes that do not take part), never under a
+                        // per-lane branch: a per-element "load or not" makes hipcc branch around every load and
+                        // wait vmcnt(0) after each one.
                         float4 v[4], mv[4], add[4];
+                        int idx[4]; bool ok[4];
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
                             const int p = pr + 8 * it, px = x0 + p;
                             const int oxp = px * a.out_mul + xoff;
-                            const bool ok = px < a.DW && n_ok && oxp >= 0 && oxp < a.OW;
-                            const int idx = rowo + (px * a.out_mul + xoff) * cs;
+                            ok[it] = px < a.DW && n_ok && oxp >= 0 && oxp < a.OW;
+                            idx[it] = rowo + oxp * cs;
                             v[it] = *reinterpret_cast<const float4*>(eb + p * 32 + q4);
                             mv[it] = make_float4(1.f, 1.f, 1.f, 1.f);
                             add[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if (mmode && ok) mv[it] = *reinterpret_cast<const float4*>(msk + idx);
-                            if (addsrc && ok) add[it] = *reinterpret_cast<const float4*>(addsrc + idx);
-                            if (accum && ok) add[it] = *reinterpret_cast<const float4*>(dst + idx);
                         }
+                        if (any_mask) {
+                            const float* mb = mmode ? msk : mask_any;
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) mv[it] = *reinterpret_cast<const float4*>(mb + ((mmode && ok[it]) ? idx[it] : 0));
+                        }
+                        if (a.addsrc) {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) add[it] = *reinterpret_cast<const float4*>(a.addsrc + ((d == 0 && ok[it]) ? idx[it] : 0));
+                        }
+                        if (any_accum) {
+                            const float* ab = accum ? dst : accum_any;
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) add[it] = *reinterpret_cast<const float4*>(ab + ((accum && ok[it]) ? idx[it] : 0));
+                        }
+                        const bool use_add = (a.addsrc && d == 0), use_acc = accum != 0;
 #pragma unroll
                         for (int it = 0; it < 4; ++it) {
-                            const int px = x0 + pr + 8 * it;
-                            const int oxq = px * a.out_mul + xoff;
-                            if (px >= a.DW || !n_ok || oxq < 0 || oxq >= a.OW) continue;
-                            const int idx = rowo + (px * a.out_mul + xoff) * cs;
                             float o[4] = {v[it].x + bias.x, v[it].y + bias.y, v[it].z + bias.z, v[it].w + bias.w};
                             const float ad[4] = {add[it].x, add[it].y, add[it].z, add[it].w};
                             const float mk[4] = {mv[it].x, mv[it].y, mv[it].z, mv[it].w};
 #pragma unroll
                             for (int c = 0; c < 4; ++c) {
-                                if (addsrc) o[c] += ad[c];
+                                if (use_add) o[c] += ad[c];
                                 if (a.act == 1) o[c] = o[c] > 0.f ? o[c] : 0.2f * o[c];
                                 else if (a.act == 2) o[c] = fmaxf(o[c], 0.f);
                                 if (mmode) o[c] *= (mk[c] > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
-                                if (accum) o[c] += ad[c];
+                                if (use_acc) o[c] += ad[c];
                             }
-                            *reinterpret_cast<float4*>(dst + idx) = make_float4(o[0], o[1], o[2], o[3]);
+                            if (ok[it]) *reinterpret_cast<float4*>(dst + idx[it]) = make_float4(o[0], o[1], o[2], o[3]);
                         }
                     }
                 }
             }
         }
-        t = nt; g = ng;
+        t = nt; g = ng; si = nsi; cc = ncc;
+        if (g == 0) cur = nxt;
     }
 }
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
 
 int grid_cap() {   // experiments: PNNP_IGEMM_WGS_PER_CU overrides the resident-workgroup count
     static int v = -2;
@@ -283,6 +329,8 @@ int pick_kc(int bn, int chan) {
     return kc;
 }
 
+// (Measured and rejected: twice-as-tall tiles (MT=4) -- the extra accumulators push the kernel past 256
+// VGPRs, it spills, and the 32/64-channel layers lose 5-20 %.)
 template <int TAPS>
 int launch_taps(const IgemmArgs& a, int kc_chan, hipStream_t s) {
     const int bn = pick_bn(a.Ntot);
@@ -308,9 +356,13 @@ int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_
     if ((a.Ntot & 3) || (a.dst_cs[0] & 3) || (a.dst[1] && ((a.dst_cs[1] & 3) || (a.n_split & 3)))) return PNNP_E_UNSUPPORTED;
     if ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) |
          ((uintptr_t)a.addsrc)) & 15) return PNNP_E_INVALID;
+    for (int i = 0; i < a.nseg; ++i)                         // 32-bit element offsets when staging
+        if ((int64_t)a.B * a.IH * a.IW * a.seg[i].cstride >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     for (int d = 0; d < 2; ++d)                              // 32-bit element offsets in the epilogue
         if (a.dst[d] && (int64_t)a.B * a.OH * a.OW * a.dst_cs[d] >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     IgemmArgs b = a;
+    static const int stagger_mode = env_int("PNNP_STAGGER", 0), stagger_n = env_int("PNNP_STAGGER_N", 2);
+    b.stagger_mode = stagger_mode; b.stagger_n = stagger_n;
     const int kc = pick_kc(pick_bn(a.Ntot), chan_per_seg);
     b.chunks_per_seg = chan_per_seg / kc;
     if (taps == 9) return launch_taps<9>(b, chan_per_seg, s);
