@@ -175,7 +175,7 @@ wgrad_kernel(const WgradArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wmo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (m < a.M && n < a.N) a.slab[slab_base + ((int64_t)m * a.N + n) * TAPS + t] = v[r];
+                if (m < a.M && n < a.N) a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = v[r];   // [z][tap][m][n]: lanes (n) contiguous
             }
         }
     }
@@ -195,10 +195,14 @@ wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// out[i] = sum_z slab[z][i] in a fixed order.  32 consecutive elements x 8 z-phases per block so the
-// Z (up to 512) dependent loads per element are spread over 8 threads and many blocks.
+// out = sum_z slab[z] in a fixed order.  32 consecutive elements x 8 z-phases per block so the Z (up to
+// 512) dependent loads per element are spread over 8 threads and many blocks.  The slabs are stored
+// [tap][m][n] (what the accumulator lanes write coalesced -- the parameter's own [m][n][tap] order made
+// every slab store a scattered 4-byte write: 8x write amplification, 7.8 GB per step); the transpose to
+// [m][n][tap] happens here, once per element instead of once per slab.  taps == 1: plain sum.
 __global__ void __launch_bounds__(256)
-slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate) {
+slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate,
+                   int64_t mn, int taps) {
     __shared__ float red[8][32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n; i0 += (int64_t)gridDim.x * 32) {
@@ -218,7 +222,8 @@ slab_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int6
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += red[k][tx];
-            out[i] = accumulate ? out[i] + s : s;
+            const int64_t o = taps == 1 ? i : (i % mn) * taps + i / mn;
+            out[o] = accumulate ? out[o] + s : s;
         }
         __syncthreads();
     }
@@ -328,10 +333,10 @@ int pnnp_conv_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cout * N * taps;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
-                       as_stream(stream), a.slab, dW, n, a.Z, accumulate);
+                       as_stream(stream), a.slab, dW, n, a.Z, accumulate, (int64_t)a.M * a.N, (int)(n / ((int64_t)a.M * a.N)));
     if (dbias)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, as_stream(stream), a.bias_slab, dbias,
-                           (int64_t)Cout, a.Z, accumulate);
+                           (int64_t)Cout, a.Z, accumulate, (int64_t)Cout, 1);
     return pnnp_launch_status();
 }
 
@@ -353,7 +358,7 @@ int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Co
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cin * Cout * 4;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
-                       as_stream(stream), a.slab, dW, n, a.Z, accumulate);
+                       as_stream(stream), a.slab, dW, n, a.Z, accumulate, (int64_t)a.M * a.N, (int)(n / ((int64_t)a.M * a.N)));
     (void)dbias;   // the bias gradient of a ConvTranspose2d is a plain channel sum: pnnp_channel_sum_f32
     return pnnp_launch_status();
 }
@@ -379,10 +384,10 @@ int pnnp_conv3x3s2_bwd_weight_f32(const float* g, int Cout, const float* x, int 
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cout * Cin * 9;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
-                       as_stream(stream), a.slab, dW, n, a.Z, accumulate);
+                       as_stream(stream), a.slab, dW, n, a.Z, accumulate, (int64_t)a.M * a.N, (int)(n / ((int64_t)a.M * a.N)));
     if (dbias)
         hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, as_stream(stream), a.bias_slab, dbias,
-                           (int64_t)Cout, a.Z, accumulate);
+                           (int64_t)Cout, a.Z, accumulate, (int64_t)Cout, 1);
     return pnnp_launch_status();
 }
 
