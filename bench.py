@@ -164,8 +164,14 @@ def main():
                 c[0] += 1; c[1] += fl; c[2] += by; c[3] += e0.elapsed_time(e1) * 1e-3
             dom = [k for k in classes if k.startswith('conv9_fwd') or k.startswith('conv9_dgrad')]
             n = sum(classes[k][0] for k in dom); fl = sum(classes[k][1] for k in dom); sec = sum(classes[k][3] for k in dom)
+            traffic = None     # HBM bytes per launch from the PMC passes of this command (tools/traffic_from_pmc.py)
+            tj = os.path.join(REPO, 'profiles', 'traffic.json')
+            if os.path.exists(tj) and args.arch == 'unet' and args.noise == 'physics' and B == 16 and S == 512:
+                traffic = json.load(open(tj)).get('igemm9', {}).get('hbm_bytes_per_launch')
+            by = sum(classes[k][2] for k in dom)
             out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                               "alg_bytes_per_launch": by / n,
                                "kernel": "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "alg_gflop_per_launch": fl / n / 1e9}
