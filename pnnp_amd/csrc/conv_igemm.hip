@@ -157,28 +157,39 @@ igemm_kernel(const IgemmArgs a) {
             if (nt < total) nxt = decode(nt);
         }
         if (nt < total) prefetch(nxt, nsi, ncc, ng);
-        // ---- MFMA over taps x channel octets
+        // ---- MFMA over taps x channel octets.  The LDS reads of step s+1 are issued BEFORE the MFMAs of
+        // step s (register double buffer): left to itself hipcc issues each step's ds_reads right in front
+        // of its MFMAs with s_waitcnt lgkmcnt(0), exposing the LDS latency once per 8-16 MFMAs.
+        {
+            constexpr int NSTEP = TAPS * (KC / 8);
+            float4 av[2][MT], bv[2][NT];
+            auto lds_load = [&](int step, float4 (&ax)[MT], float4 (&bx)[NT]) {
+                const int tp = step / (KC / 8), j = step % (KC / 8);
+                const int dy = (TAPS == 9) ? tp / 3 : 0, dx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp) {
-            const int dy = (TAPS == 9) ? tp / 3 : 0, dx = (TAPS == 9) ? tp % 3 : 0;
+                for (int i = 0; i < MT; ++i) ax[i] = xs[(2 * j + half) * NPIX + (wm * MT + i + dy) * HC + dx + l31];
 #pragma unroll
-            for (int j = 0; j < KC / 8; ++j) {
-                float4 av[MT], bv[NT];
+                for (int i = 0; i < NT; ++i) bx[i] = ws[(tp * KQ + 2 * j + half) * BN + (wn * NT + i) * 32 + l31];
+            };
+            lds_load(0, av[0], bv[0]);
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    av[i] = xs[(2 * j + half) * NPIX + (wm * MT + i + dy) * HC + dx + l31];
-#pragma unroll
-                for (int i = 0; i < NT; ++i)
-                    bv[i] = ws[(tp * KQ + 2 * j + half) * BN + (wn * NT + i) * 32 + l31];
+            for (int step = 0; step < NSTEP; ++step) {
+                if (step + 1 < NSTEP) {
+                    lds_load(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
+                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);      // the next step's DS reads first ...
+                }
+                const float4 (&ax)[MT] = av[step & 1];
+                const float4 (&bx)[NT] = bv[step & 1];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int k = 0; k < NT; ++k) {
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].x, bv[k].x, acc[i][k], 0, 0, 0);
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].y, bv[k].y, acc[i][k], 0, 0, 0);
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].z, bv[k].z, acc[i][k], 0, 0, 0);
-                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i].w, bv[k].w, acc[i][k], 0, 0, 0);
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].x, bx[k].x, acc[i][k], 0, 0, 0);
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].y, bx[k].y, acc[i][k], 0, 0, 0);
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].z, bx[k].z, acc[i][k], 0, 0, 0);
+                        acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].w, bx[k].w, acc[i][k], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);          // ... then this step's MFMAs
             }
         }
         if (g == nchunks - 1) {
