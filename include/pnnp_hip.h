@@ -192,6 +192,14 @@ int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
 
+/* ---------------------------------------------------------------- eval epilogue
+ * IlluminanceCorrect.correct (data_process/__init__.py:165-175) and the raw-domain PSNR / SSIM of
+ * quality_assess(tensor2im(.), tensor2im(.), data_range=255) (utils/visualization.py:9-31). */
+int pnnp_illuminance_correct_f32(const float* pred, const float* src, float* out, int64_t n,
+                                 double* workspace /* >= 512 doubles */, void* stream);
+int pnnp_psnr_ssim_f32(const float* a, const float* b, float* out2 /* {psnr, ssim} */, int C, int H, int W,
+                       double* workspace /* >= 2*C*ceil(H/32)*ceil(W/32) doubles */, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,8 @@ class ResUnetEngine:
         self.bufs = {}
         self.packed = {}
         self.saved = None
+        self._pack_key = None
+        self._dirty_epoch = 0
         nf = module.nf
         if nf % 8:
             raise PnnpError('ResUnet on HIP needs nf % 8 == 0')
@@ -98,6 +100,10 @@ class ResUnetEngine:
         conv('conv10', 'conv10.weight', cout_pad=self.cout_pad)
         self.W = W
 
+    def mark_dirty(self):
+        """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
+        self._dirty_epoch += 1
+
     # ---------------------------------------------------------------- forward
     def forward(self, x, train):
         if not x.is_cuda:
@@ -108,7 +114,12 @@ class ResUnetEngine:
             raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
         dev = x.device
         self.params.ensure(dev)
-        self.pack_weights(train)
+        # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
+        # tensor._version, the fused Adam kernel goes through mark_dirty()
+        key = (train, dev, self._dirty_epoch) + tuple(p._version for p in self.m.parameters())
+        if key != self._pack_key:
+            self.pack_weights(train)
+            self._pack_key = key
         bufs = self.bufs.setdefault((B, H, Wd, dev), _Bufs())
         P = dict(self.m.named_parameters())
         ch, W = self.ch, self.W

@@ -75,6 +75,8 @@ class UNetEngine:
         self.bufs = {}
         self.packed = {}
         self.saved = None
+        self._pack_key = None
+        self._dirty_epoch = 0
         nf = module.nf
         self.ch = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
         if nf % 8:
@@ -117,6 +119,10 @@ class UNetEngine:
     def _w(self, name):
         return self.packed[(name, self.params.flat.device)]
 
+    def mark_dirty(self):
+        """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
+        self._dirty_epoch += 1
+
     # ------------------------------------------------------------------ forward
     def forward(self, x, train):
         if not x.is_cuda:
@@ -127,7 +133,12 @@ class UNetEngine:
             raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
         dev = x.device
         self.params.ensure(dev)
-        self.pack_weights(need_dgrad=train)
+        # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
+        # tensor._version, the fused Adam kernel goes through mark_dirty()
+        key = (train, dev, self._dirty_epoch) + tuple(p._version for p in self.m.parameters())
+        if key != self._pack_key:
+            self.pack_weights(need_dgrad=train)
+            self._pack_key = key
         bufs = self.bufs.setdefault((B, H, W, dev), _Bufs())
         P = dict(self.m.named_parameters())
         ch = self.ch

@@ -189,6 +189,7 @@ class HipTrainStep:
         self.step_count += 1
         ops.adam_step(e.params.flat, e.params.grad, self.m, self.v, self.lr if lr is None else lr, self.step_count,
                       grad_scale=1.0 / self.world)
+        e.mark_dirty()
         self._loss = loss
         return loss
 
