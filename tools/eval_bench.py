@@ -11,8 +11,12 @@ def run(cls, gf, B, H, W, reps=10):
     net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda().eval()
     x = torch.rand(B, 4, H, W, device='cuda')
     with torch.no_grad():
-        for _ in range(3): net(x)
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.5:      # warm-up long enough for the clocks to ramp after the idle set-up
+            net(x); torch.cuda.synchronize()
+        net(x); torch.cuda.synchronize(); t0 = time.perf_counter(); net(x); torch.cuda.synchronize()
+        reps = max(reps, int(0.5 / (time.perf_counter() - t0)))
+        t0 = time.perf_counter()
         for _ in range(reps): y = net(x)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     fl = gf * 1e9 * B * H * W / (512 * 512)
