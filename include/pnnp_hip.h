@@ -192,6 +192,18 @@ int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
 
+/* ---------------------------------------------------------------- dataset-side crop / augment
+ * init_random_crop_point + random_crop + data_aug (data_process/syn_datasets.py:69-107,162-173; the 4-way
+ * variant real_datasets.py:98-137), fused behind raw2bayer (utils/isp_ops.py:84-96), the linear dark-shading
+ * subtraction (real_datasets.py:360-368) and the random_gains white-balance augmentation
+ * (syn_datasets.py:313-322).  desc [device, n x 4 int32] = {h0, w0, rot90 k, flip}; gains [device, n x 3 f64]
+ * = {rgb, red, blue} or NULL; dark [device, H x W] f32/f64 or NULL. */
+int pnnp_crop_pack_bayer_u16(const uint16_t* frame, int H, int W, const void* dark, int dark_is_f64, double dark_add,
+                             float* dst /* [n][4][ps][ps] */, int n, int ps, const int* desc, const double* gains,
+                             const double* black4, double wp, int norm, int clip, int post_clip, void* stream);
+int pnnp_crop_aug_f32(const float* img /* [C][h][w] */, int C, int h, int w, float* dst /* [n][C][ps][ps] */,
+                      int n, int ps, const int* desc, const double* gains, int post_clip, void* stream);
+
 /* ---------------------------------------------------------------- eval epilogue
  * IlluminanceCorrect.correct (data_process/__init__.py:165-175) and the raw-domain PSNR / SSIM of
  * quality_assess(tensor2im(.), tensor2im(.), data_range=255) (utils/visualization.py:9-31). */

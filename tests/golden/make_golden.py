@@ -382,15 +382,80 @@ def gen_noiseflow():
     np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
 
 
+def gen_augment(data_process, isp):
+    """Rows f2/f3: crop points + 8-/4-way augmentation + WB gains + dark shading, as the datasets do them
+    (syn_datasets.py:69-107,162-173,296-322; real_datasets.py:98-137,360-372)."""
+    import torch
+    from data_process.syn_datasets import SynBase_Dataset
+    from data_process.real_datasets import RealBase_Dataset
+    from data_process.unprocess import random_gains
+    out, meta = {}, {}
+    rng = np.random.RandomState(11)
+    H, W = 160, 224
+    frame = rng.randint(0, 16384, size=(H, W)).astype(np.uint16)
+    out['frame'] = frame
+    for tag, cls, ps, cpi, mode in (('syn_random', SynBase_Dataset, 48, 6, 'random'),
+                                    ('syn_grid', SynBase_Dataset, 32, 6, 'non-overlapped'),
+                                    ('real_random', RealBase_Dataset, 40, 5, 'random')):
+        ds = cls({'H': H, 'W': W, 'patch_size': ps, 'crop_per_image': cpi})
+        ds.get_shape()
+        np.random.seed(5)
+        ds.init_random_crop_point(mode=mode, raw_crop=False)
+        if mode == 'non-overlapped':      # the grid yields nh*nw points; random_crop uses the first crop_per_image
+            assert len(ds.h_start) >= cpi
+        hr = isp.raw2bayer(frame, wp=16383, bl=512, norm=True, clip=True)
+        crops = ds.random_crop(hr)
+        meta[tag] = dict(ps=ps, crop_per_image=cpi, mode=mode, seed=5, h_start=[int(v) for v in ds.h_start],
+                         w_start=[int(v) for v in ds.w_start], aug=[int(v) for v in ds.aug])
+        out[tag + '_crops'] = crops
+    # every augmentation mode on one non-square-friendly crop (data_aug directly)
+    ds = SynBase_Dataset({'H': H, 'W': W, 'patch_size': 36, 'crop_per_image': 8}); ds.get_shape()
+    hr = isp.raw2bayer(frame, wp=16383, bl=512, norm=True, clip=False)
+    out['aug8'] = np.stack([np.ascontiguousarray(ds.data_aug(hr[:, 3:39, 7:43], mode=m)) for m in range(8)])
+    dr = RealBase_Dataset({'H': H, 'W': W, 'patch_size': 36, 'crop_per_image': 4}); dr.get_shape()
+    out['aug4'] = np.stack([np.ascontiguousarray(dr.data_aug(hr[:, 3:39, 7:43], mode=m)) for m in range(4)])
+    # WB gain augmentation (syn_datasets.py:313-322) on crops, after seeded random_gains
+    torch.manual_seed(3); np.random.seed(3)
+    rgb_gain, red_gain, blue_gain = random_gains()
+    wb = np.array([2.1, 1.0, 1.6], np.float32)
+    meta['gains'] = dict(rgb=float(rgb_gain.numpy()[0]), red_raw=float(red_gain.numpy()[0]), blue_raw=float(blue_gain.numpy()[0]),
+                         wb=[float(v) for v in wb], torch_seed=3, np_seed=3)
+    hr_crops = out['syn_random_crops'].copy()
+    red = wb[0] / red_gain.numpy(); blue = wb[2] / blue_gain.numpy()
+    hr_crops *= rgb_gain.numpy()
+    hr_crops[:, 0] = hr_crops[:, 0] * red
+    hr_crops[:, 2] = hr_crops[:, 2] * blue
+    meta['gains'].update(red=float(red[0]), blue=float(blue[0]), red_dtype=str(red.dtype))
+    out['gain_crops'] = hr_crops
+    out['gain_crops_clip'] = hr_crops.clip(0, 1)
+    # linear dark shading in front of the pack (real_datasets.py:360-372), float32 maps, noise code with 'd'
+    ds_k = (rng.rand(H, W).astype(np.float32) - 0.5) * 1e-3
+    ds_b = (rng.rand(H, W).astype(np.float32) - 0.5) * 4
+    iso, BLE = 1600, 0.37
+    dark = ds_k * iso + ds_b + BLE
+    out['dark'] = dark; meta['dark'] = dict(dtype=str(dark.dtype), iso=iso, BLE=BLE)
+    lr_raw = frame - dark
+    out['dark_lr'] = isp.raw2bayer(lr_raw, wp=16383, bl=512, norm=True, clip=False)
+    lr_raw2 = lr_raw + dark.mean()
+    meta['dark']['mean'] = float(dark.mean()); meta['dark']['mean_dtype'] = str(np.asarray(dark.mean()).dtype)
+    out['dark_lr_d'] = isp.raw2bayer(lr_raw2, wp=16383, bl=512, norm=True, clip=False)
+    dark64 = dark.astype(np.float64) * 1.000001
+    # (dark64 is re-derived in the test: dark.astype(float64) * 1.000001)
+    out['dark64_lr'] = isp.raw2bayer(frame - dark64, wp=16383, bl=512, norm=True, clip=False)
+    np.savez_compressed(os.path.join(HERE, 'augment.npz'), **out)
+    json.dump(meta, open(os.path.join(HERE, 'augment.json'), 'w'), indent=1)
+
+
 def main():
     archs, proc, isp, losses, data_process, base_trainer = import_reference()
-    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow']
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment']
     if 'pack' in which: gen_pack(isp)
     if 'params' in which: gen_params(proc)
     if 'noise' in which: gen_noise(proc)
     if 'nets' in which: gen_nets(archs, losses)
     if 'misc' in which: gen_misc(base_trainer, losses, data_process)
     if 'noiseflow' in which: gen_noiseflow()
+    if 'augment' in which: gen_augment(data_process, isp)
     print('golden fixtures written to', HERE)
 
 
