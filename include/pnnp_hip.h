@@ -89,6 +89,9 @@ enum {
 #define PNNP_NOISE_MODE_TORCH 0x1000u /* quirks of generate_noisy_torch (else _obs)   */
 #define PNNP_NOISE_POST_MAX1 0x2000u  /* then min(z,1): Trainer.preprocess clamp, trainer_SID.py:481-485 */
 #define PNNP_NOISE_POST_MIN0 0x4000u  /* then max(z,0) (clip other than HALF_CLIP)     */
+#define PNNP_NOISE_TORCH_TUKEY 0x8000u /* extension: allow 'g' in TORCH mode with the Tukey-lambda
+                                          read noise of generate_noisy_obs (process.py:611) instead of the
+                                          NotImplementedError of process.py:654 */
 int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, int H, int W,
                           const float* params, unsigned flags, float mfm /* sqrt(MultiFrameMean) */,
                           uint64_t seed, uint64_t offset, uint32_t crop_base, void* stream);

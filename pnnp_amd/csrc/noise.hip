@@ -204,7 +204,7 @@ extern "C" int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, i
                                      const float* params, unsigned flags, float mfm, uint64_t seed,
                                      uint64_t offset, uint32_t crop_base, void* stream) {
     if (!y || !out || !params || B < 0 || C < 0 || H < 0 || W < 0 || !(mfm > 0.f)) return PNNP_E_INVALID;
-    if ((flags & PNNP_NOISE_MODE_TORCH) && (flags & PNNP_NOISE_G)) return PNNP_E_UNSUPPORTED;   // process.py:654
+    if ((flags & PNNP_NOISE_MODE_TORCH) && (flags & PNNP_NOISE_G) && !(flags & PNNP_NOISE_TORCH_TUKEY)) return PNNP_E_UNSUPPORTED;   // process.py:654
     if ((flags & PNNP_NOISE_MODE_TORCH) && !(flags & PNNP_NOISE_P)) return PNNP_E_UNSUPPORTED;  // process.py:651
     if ((int64_t)C * H * W >= (1ll << 32)) return PNNP_E_INVALID;
     const int64_t total = (int64_t)B * C * H * ((W + 3) / 4);

@@ -209,6 +209,7 @@ def pack_raw_bayer(raw, wp=1023, clip=True):
 _FLAG = dict(p=0x01, g=0x02, r=0x04, q=0x08, d=0x10, b=0x20)
 F_ORI, F_CLIP, F_TORCH = 0x100, 0x200, 0x1000
 F_POST_MAX1, F_POST_MIN0 = 0x2000, 0x4000      # Trainer.preprocess clamp fused into the sampler
+F_TORCH_TUKEY = 0x8000                         # extension: 'g' (Tukey-lambda read noise) in torch mode
 _ORDER = ('K', 'sigGs', 'sigTL', 'lam', 'sigR', 'q', 'ratio', 'wp', 'bl')
 
 
@@ -283,21 +284,27 @@ def _as4d(y):
     raise ValueError('expected [C,H,W] or [B,C,H,W]')
 
 
-def generate_noisy_torch(y, camera_type=None, noise_code='p', param=None, MultiFrameMean=1, ori=False, clip=False):
+def generate_noisy_torch(y, camera_type=None, noise_code='p', param=None, MultiFrameMean=1, ori=False, clip=False, tukey=False):
     """process.py:634-673 on the HIP sampler.  ``y`` is a CUDA tensor [C,H,W]; a 4-D
     batch shares one parameter set and, like the reference, draws ONE row-noise pattern
     per call only if you pass it as separate crops -- here every crop of a batch gets its
     own row noise (the reference's broadcast-over-batch is an artefact the trainers
     avoid by looping per crop, trainer_SID.py:451-462).
-    Error behaviour kept: 'g' -> NotImplementedError (:654); no 'p' -> TypeError (:651)."""
+    Error behaviour kept: 'g' -> NotImplementedError (:654); no 'p' -> TypeError (:651).
+    ``tukey=True`` (extension) lifts the first: 'g' then draws the Tukey-lambda read noise of
+    generate_noisy_obs (:611, scale sigTL, shape lam) on the device, so the ELD/PMN codes ('pgrq') run on the
+    GPU path."""
     code = noise_code.lower()
     if 'p' not in code:
         raise TypeError("Normal.__init__() missing 1 required positional argument: 'scale'")
-    if 'g' in code and 'b' not in code:
+    if 'g' in code and 'b' not in code and not tukey:
         raise NotImplementedError
     _lib.require_cuda(y)
     y4, squeeze = _as4d(y.float())
-    flags = noise_flags(code.replace('g', ''), ori=ori, clip=bool(clip), torch_mode=True)
+    if tukey and 'g' in code:
+        flags = noise_flags(code, ori=ori, clip=bool(clip), torch_mode=True) | F_TORCH_TUKEY
+    else:
+        flags = noise_flags(code.replace('g', ''), ori=ori, clip=bool(clip), torch_mode=True)
     P = pack_params([param] * y4.shape[0], y.device)
     out = noise_sample(y4, P, flags, mfm=float(MultiFrameMean) ** 0.5)
     return out[0] if squeeze else out

@@ -102,12 +102,13 @@ class HipTrainStep:
     ``[loss, sse_0 .. sse_{B-1}]`` without synchronising."""
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
-                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False):
+                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False):
         self.net = net
         self.engine = net.engine
         self.lr = lr
         self.camera_type, self.noise_code, self.ori, self.clip = camera_type, noise_code, ori, clip
         self.seed = seed
+        self.tukey = tukey          # extension: let noise codes with 'g' run (Tukey-lambda read noise on the device)
         self.rank, self.world, self.group = rank, world, group
         self.bucket_bytes = bucket_bytes
         self.force_reducer = force_reducer
@@ -137,7 +138,12 @@ class HipTrainStep:
             rows = process.pack_params(plist if plist is not None else self.sample_noise_params(B), hr.device)
         # `clip: 2` (HALF_CLIP) is truthy: generate_noisy_torch clamps to [0,1] before x ratio
         # (process.py:668), then preprocess clamps the result to (-inf, 1] (trainer_SID.py:483-484)
-        flags = process.noise_flags(self.noise_code, ori=self.ori, clip=bool(self.clip), torch_mode=True)
+        code = self.noise_code.lower()
+        if 'g' in code and 'b' not in code and not self.tukey:
+            raise NotImplementedError            # process.py:654
+        flags = process.noise_flags(code if self.tukey else code.replace('g', ''), ori=self.ori, clip=bool(self.clip), torch_mode=True)
+        if self.tukey and 'g' in code:
+            flags |= process.F_TORCH_TUKEY
         if self.clip:
             flags |= process.F_POST_MAX1 | (0 if self.clip == process.HALF_CLIP else process.F_POST_MIN0)
         return process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count,

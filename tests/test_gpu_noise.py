@@ -150,3 +150,39 @@ def test_reference_api_mirror():
         P.generate_noisy_torch(y, param=host, noise_code='r')
     z = P.generate_noisy_obs(y.cpu().numpy(), noise_code='pgrq', param=host)
     assert isinstance(z, np.ndarray) and z.dtype == np.float32 and z.shape == (4, 64, 64)
+
+
+def test_tukey_extension_in_torch_mode():
+    """Row f3: with tukey=True the torch-mode sampler accepts 'g' and draws the Tukey-lambda read noise of
+    generate_noisy_obs.  (i) tier A against the C oracle with the same flag; (ii) for a code without r/q/d/b the
+    two modes are the same pipeline, so torch-mode 'pg' must equal obs-mode 'pg' bit for bit; (iii) the
+    C ABI still refuses TORCH+G without the flag (process.py:654)."""
+    from oracle import cbind
+    from pnnp_amd import _lib, process as P
+    rng = np.random.default_rng(7)
+    y = (rng.random((2, 4, 48, 72), dtype=np.float32) ** 2).astype(np.float32)
+    plist = [SONY, IMX]
+    flags = P.noise_flags('pgrq', clip=True, torch_mode=True) | P.F_TORCH_TUKEY
+    ref = cbind.noise_sample(y, cbind.param_rows(plist), flags, seed=11, offset=2)
+    got = _hip(y, plist, flags, seed=11, offset=2)
+    for b, p in enumerate(plist):
+        tol = 1e-5 * np.maximum(np.abs(ref[b]), p['ratio'] / (p['wp'] - p['bl']))
+        assert float((np.abs(got[b] - ref[b]) <= tol).mean()) >= 0.999
+    a = _hip(y, plist, P.noise_flags('pg', torch_mode=True) | P.F_TORCH_TUKEY, seed=11, offset=2)
+    b = _hip(y, plist, P.noise_flags('pg', torch_mode=False), seed=11, offset=2)
+    assert np.array_equal(a, b)
+    with pytest.raises(_lib.PnnpError):
+        _hip(y, plist, P.noise_flags('pg', torch_mode=True))
+    yd = torch.from_numpy(y[0]).cuda()
+    P.manual_seed(3); z = P.generate_noisy_torch(yd, param=SONY, noise_code='pgrq', tukey=True)
+    P.manual_seed(3); z2 = P.generate_noisy_torch(yd, param=SONY, noise_code='prq')
+    assert z.shape == yd.shape and not torch.equal(z, z2)
+    # heavier tails than the Gaussian of the same scale would give: the read term uses sigTL and lam
+    dark = torch.zeros(4, 256, 256, device='cuda')
+    P.manual_seed(4); n = P.generate_noisy_torch(dark, param=dict(SONY, lam=-0.2), noise_code='pg', tukey=True, ori=True)
+    n = n.cpu().numpy().astype(np.float64) * (SONY['wp'] - SONY['bl'])
+    n = n[n > -SONY['bl'] / SONY['wp'] * (SONY['wp'] - SONY['bl']) + 1e-3]
+    from scipy import stats
+    q = np.quantile(n, [0.05, 0.25, 0.5, 0.75, 0.95])
+    want = stats.tukeylambda.ppf([0.05, 0.25, 0.5, 0.75, 0.95], -0.2) * SONY['sigTL']
+    assert np.abs(q - want).max() < 0.08 * SONY['sigTL']
