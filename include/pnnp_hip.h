@@ -127,6 +127,19 @@ int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
                            float* dx1, int C1, const float* mask1, int mode1, int accum1,
                            float* dx2, int C2, const float* mask2, int mode2, int accum2,
                            int B, int H, int W, int taps, void* stream);
+/* The same two operators for 3x3 / stride 1 / pad 1 layers through Winograd F(2x2,3x3) (2.25x fewer MFMA passes;
+ * results differ from the direct form by fp32 rounding of the transforms, ~1e-6 relative).  Weights are packed by
+ * pnnp_pack_conv_weight_wino_f32 into U = G g G^T, 16*Cout*Cin floats each; supported when the channels read are a
+ * multiple of 8 and the channels written a multiple of 64 (pnnp_wino_supported). */
+int64_t pnnp_wino_weight_floats(int Cout, int Cin);
+int pnnp_wino_supported(int K_read, int N_written);
+int pnnp_pack_conv_weight_wino_f32(const float* w, float* fwd /*or null*/, float* dgrad /*or null*/, int Cout, int Cin, void* stream);
+int pnnp_conv3x3_wino_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* u_fwd, const float* bias,
+                              float* y, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgrad,
+                                   float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                   float* dx2, int C2, const float* mask2, int mode2, int accum2,
+                                   int B, int H, int W, void* stream);
 /* backward-weight: dW [Cout][C1+C2][taps] (+ dbias [Cout]); workspace from the query below. */
 int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps);
 int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps);

@@ -1,0 +1,333 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix cores, NHWC, stride 1, pad 1.
+//
+//   Y = A^T [ sum_k (G g_k G^T) (.) (B^T d_k B) ] A        per 2x2 output tile, 4x4 input tile
+//
+// so the 9 multiply-adds per (pixel, cin, cout) of the direct form (archs/Unet.py:16-52 via nn.Conv2d)
+// become 16 per FOUR pixels: 2.25x fewer MFMA passes for the same layer.  The 16 element-wise products
+// are 16 independent GEMMs  M_xi[tile][n] = sum_k V_xi[tile][k] * U_xi[k][n]  (xi = position in the 4x4
+// transformed tile), run on v_mfma_f32_32x32x2_f32.
+//
+// Workgroup (256 threads, 4 waves as 2x2) owns 8x8 tiles (16x16 output pixels) x 64 output channels:
+//   * K loop in chunks of 8 channels.  The 18x18x8 halo patch goes global -> registers -> LDS (raws),
+//     every thread transforms two (tile, 4-channel, row) items  B^T d B  into  Vs[xi][k/4][tile][4],
+//     the pre-transformed weights U (packed once per weight update) stream global -> registers -> Us.
+//   * each wave keeps ALL 16 xi accumulators of its 32 tiles x 32 channels in registers (256 AGPRs),
+//     so the inverse transform A^T M A runs in registers and the epilogue (bias, activation, act'
+//     mask, split destinations) stores straight to HBM -- no LDS round trip for the output.
+//   * Vs/Us are double buffered; global loads for chunk c+1 are issued before the MFMAs of chunk c.
+// LDS: 2 x (36 KB Vs + 32 KB Us) + 10 KB raws = 146 KB of the CU's 160 KB, one workgroup per CU.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int KC = 8, BN = 64, TT = 64, PATCH = 18;
+constexpr int VPLANE = TT * 4 + 32;                    // 288: the +32 keeps the two k-quads of a b128 store on disjoint banks
+constexpr int VS_STAGE = 16 * 2 * VPLANE;              // floats
+constexpr int UPLANE = BN * 4;
+constexpr int US_STAGE = 16 * 2 * UPLANE;              // 8192 floats
+constexpr int RAW_ROW = 2 * 9 * KC;                    // a patch row: [column parity][9][8 ch]
+constexpr int RAW_FLOATS = PATCH * RAW_ROW;
+constexpr int SMEM_FLOATS = 2 * VS_STAGE + 2 * US_STAGE + 2 * RAW_FLOATS;
+
+struct WinoArgs {
+    const float* src[2]; int src_cs[2]; int C1;        // K channels: [0,C1) from src[0], the rest from src[1]
+    int K, N;
+    const float* u;                                    // [N/64][K/8][16][2][64][4]
+    int B, H, W, tiles_x, tiles_y;
+    float* dst[2]; int dst_cs[2]; int n_split;         // column n < n_split -> dst[0][n] else dst[1][n - n_split]
+    const float* bias; int act;
+    const float* mask[2]; int mask_mode[2]; int accum[2];
+    const float* addsrc;
+};
+
+__device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // b + s*a
+    return make_float4(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z), fmaf(s, a.w, b.w));
+}
+__device__ __forceinline__ float4 f4_add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 f4_sub(float4 a, float4 b) { return make_float4(a.x - b.x, a.y - b.y, a.z - b.z, a.w - b.w); }
+
+// B^T d B for two (tile, channel quad, row i) items per thread: raws -> Vs stage
+__device__ __forceinline__ void input_transform(const float* __restrict__ raws, float* __restrict__ vs, int tid) {
+    const int cg = tid & 1, tx = (tid >> 1) & 7, i = (tid >> 4) & 3, tyb = tid >> 6;
+    const int ra = (i == 0) ? 0 : (i == 2 ? 2 : 1);
+    const int rb = (i == 0) ? 2 : (i == 1 ? 2 : (i == 2 ? 1 : 3));
+    const float sg = (i == 1) ? 1.f : -1.f;            // rows of B^T: d0-d2, d1+d2, d2-d1, d1-d3
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        const int ty = tyb + 4 * rep;
+        float4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int col = ((c & 1) * 9 + tx + (c >> 1)) * KC + cg * 4;
+            const float4 da = *reinterpret_cast<const float4*>(raws + (2 * ty + ra) * RAW_ROW + col);
+            const float4 db = *reinterpret_cast<const float4*>(raws + (2 * ty + rb) * RAW_ROW + col);
+            t[c] = f4_fma(db, sg, da);
+        }
+        float* o = vs + (i * 8 + cg) * VPLANE + (ty * 8 + tx) * 4;
+        *reinterpret_cast<float4*>(o) = f4_sub(t[0], t[2]);
+        *reinterpret_cast<float4*>(o + 2 * VPLANE) = f4_add(t[1], t[2]);
+        *reinterpret_cast<float4*>(o + 4 * VPLANE) = f4_sub(t[2], t[1]);
+        *reinterpret_cast<float4*>(o + 6 * VPLANE) = f4_sub(t[1], t[3]);
+    }
+}
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == 1) return v > 0.f ? v : 0.2f * v;
+    if (act == 2) return fmaxf(v, 0.f);
+    return v;
+}
+
+__global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
+    extern __shared__ __align__(16) float smem[];
+    float* Vs = smem;
+    float* Us = smem + 2 * VS_STAGE;
+    float* raws = Us + 2 * US_STAGE;                   // two patch buffers
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+
+    int mt = blockIdx.x;
+    const int nb = blockIdx.y;
+    const int txi = mt % a.tiles_x; mt /= a.tiles_x;
+    const int tyi = mt % a.tiles_y;
+    const int b = mt / a.tiles_y;
+    const int y0 = tyi * 16, x0 = txi * 16;
+
+    // halo patch staging slots: 18*18 pixels x 2 channel quads = 648 float4, three per thread.
+    // Out-of-image pixels load a clamped (valid) address and are zeroed by a select: no divergent branches.
+    int roff0[3], roff1[3]; bool rok[3]; int rdst[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int q = tid + 256 * s, pl = min(q >> 1, PATCH * PATCH - 1);
+        const int py = pl / PATCH, px = pl % PATCH;
+        const int y = y0 - 1 + py, x = x0 - 1 + px;
+        rok[s] = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const int pix = (b * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1);
+        roff0[s] = pix * a.src_cs[0] + (tid & 1) * 4;
+        roff1[s] = pix * a.src_cs[1] + (tid & 1) * 4;
+        rdst[s] = py * RAW_ROW + ((px & 1) * 9 + (px >> 1)) * KC + (tid & 1) * 4;
+    }
+    const bool slot2 = tid + 512 < PATCH * PATCH * 2;
+    const int nchunks = a.K / KC;
+    const float* ug = a.u + (int64_t)nb * nchunks * US_STAGE + tid * 4;
+
+    f32x4 rr[3], ur[8];
+    auto gload_raw = [&](int c) {
+        const int k0 = c * KC;
+        const int s = k0 >= a.C1;
+        const float* p = (s ? a.src[1] : a.src[0]) + (k0 - (s ? a.C1 : 0));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p + (s ? roff1[j] : roff0[j]));
+    };
+    auto gload_u = [&](int c) {
+        const float* up = ug + (int64_t)c * US_STAGE;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ur[j] = *reinterpret_cast<const f32x4*>(up + j * 1024);
+    };
+    auto store_raw = [&](int buf) {
+        float* r = raws + buf * RAW_FLOATS;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(r + rdst[0]) = rok[0] ? rr[0] : z;
+        *reinterpret_cast<f32x4*>(r + rdst[1]) = rok[1] ? rr[1] : z;
+        if (slot2) *reinterpret_cast<f32x4*>(r + rdst[2]) = rok[2] ? rr[2] : z;
+    };
+    auto store_u = [&](int stage) {
+        float* us = Us + stage * US_STAGE + tid * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) *reinterpret_cast<f32x4*>(us + j * 1024) = ur[j];
+    };
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[xi][e] = 0.f;
+
+    // Pipeline (one barrier per chunk).  Iteration i runs  MFMA(i) || transform(i+1)  after storing U(i+1) and
+    // patch(i+2) from registers and issuing the global loads of patch(i+3) / U(i+2).
+    gload_raw(0); gload_u(0);
+    store_raw(0); store_u(0);
+    if (nchunks > 1) { gload_raw(1); store_raw(1); }
+    __syncthreads();
+    input_transform(raws, Vs, tid);
+    if (nchunks > 2) gload_raw(2);
+    if (nchunks > 1) gload_u(1);
+    __syncthreads();
+
+    const int voff = (lane >> 5) * VPLANE + (wm * 32 + (lane & 31)) * 4;
+    const int uoff = (lane >> 5) * UPLANE + (wn * 32 + (lane & 31)) * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int stage = c & 1;
+        if (c + 1 < nchunks) store_u(stage ^ 1);
+        if (c + 2 < nchunks) store_raw(stage);
+        if (c + 3 < nchunks) gload_raw(c + 3);
+        if (c + 2 < nchunks) gload_u(c + 2);
+        const float* vb = Vs + stage * VS_STAGE + voff;
+        const float* ub = Us + stage * US_STAGE + uoff;
+        float4 av[2], bv[2];
+        av[0] = *reinterpret_cast<const float4*>(vb);
+        bv[0] = *reinterpret_cast<const float4*>(ub);
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            if (xi + 1 < 16) {
+                av[(xi + 1) & 1] = *reinterpret_cast<const float4*>(vb + (xi + 1) * 2 * VPLANE);
+                bv[(xi + 1) & 1] = *reinterpret_cast<const float4*>(ub + (xi + 1) * 2 * UPLANE);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+            const float4 A = av[xi & 1], Bv = bv[xi & 1];
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bv.x, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bv.y, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bv.z, acc[xi], 0, 0, 0);
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bv.w, acc[xi], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        if (c + 1 < nchunks) input_transform(raws + (stage ^ 1) * RAW_FLOATS, Vs + (stage ^ 1) * VS_STAGE, tid);
+        __syncthreads();
+    }
+
+    // ---- inverse transform A^T M A in registers + epilogue
+    const int n = nb * BN + wn * 32 + (lane & 31);
+    const int d = (a.n_split > 0 && n >= a.n_split) ? 1 : 0;
+    const int nc = n - (d ? a.n_split : 0);
+    float* dst = d ? a.dst[1] : a.dst[0];
+    const int dcs = d ? a.dst_cs[1] : a.dst_cs[0];
+    const float* mask = d ? a.mask[1] : a.mask[0];
+    const int mmode = d ? a.mask_mode[1] : a.mask_mode[0], accum = d ? a.accum[1] : a.accum[0];
+    const float bias = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+        const int ty = m >> 3, tx = m & 7;
+        float s[4], t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
+            t[j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
+        }
+        const float yv[4] = {s[0] + s[1] + s[2], s[1] - s[2] - s[3], t[0] + t[1] + t[2], t[1] - t[2] - t[3]};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int y = y0 + 2 * ty + (p >> 1), x = x0 + 2 * tx + (p & 1);
+            if (y < a.H && x < a.W) {
+                const int64_t pix = ((int64_t)b * a.H + y) * a.W + x;
+                float v = yv[p] + bias;
+                if (a.addsrc) v += a.addsrc[pix * dcs + nc];
+                v = act_fn(v, a.act);
+                if (mmode) {
+                    const float mk = mask[pix * dcs + nc];
+                    v *= (mk > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
+                }
+                if (accum) v += dst[pix * dcs + nc];
+                dst[pix * dcs + nc] = v;
+            }
+        }
+    }
+}
+
+// U = G g G^T of every (k, n) filter, written in the kernel's chunked order [N/64][K/8][16][2][64][4].
+//   forward:  g[a][b] = w[n][k][a][b]        (w [Cout][Cin][3][3], K = Cin, N = Cout)
+//   dgrad:    g[a][b] = w[k][n][2-a][2-b]    (K = Cout, N = Cin)
+__global__ void __launch_bounds__(256)
+wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int dgrad) {
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int64_t total = (int64_t)K * N;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(t % N), k = (int)(t / N);
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                g[r][c] = dgrad ? w[((int64_t)k * Cin + n) * 9 + (2 - r) * 3 + (2 - c)] : w[((int64_t)n * Cin + k) * 9 + r * 3 + c];
+        float gg[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gg[0][c] = g[0][c];
+            gg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+            gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+            gg[3][c] = g[2][c];
+        }
+        const int nb = n / BN, nn = n % BN, kc = k / KC, kg = (k % KC) / 4, e = k % 4;
+        float* o = u + ((int64_t)nb * (K / KC) + kc) * US_STAGE + (kg * BN + nn) * 4 + e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float uu[4] = {gg[i][0], 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]), 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]), gg[i][2]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(i * 4 + j) * 2 * UPLANE] = uu[j];
+        }
+    }
+}
+
+int wino_launch(WinoArgs& a, hipStream_t st) {
+    if (a.K % KC || a.N % BN || a.C1 % KC || (a.n_split % 32)) return PNNP_E_UNSUPPORTED;
+    if ((int64_t)a.B * a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SMEM_FLOATS * 4) != hipSuccess) return PNNP_E_LAUNCH;
+        attr_set = true;
+    }
+    const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.N / BN));
+    hipLaunchKernelGGL(wino_kernel, grid, dim3(256), SMEM_FLOATS * 4, st, a);
+    return pnnp_launch_status();
+}
+
+}  // namespace
+
+extern "C" {
+
+// floats of a Winograd-packed weight: 16 * K * N  (K, N multiples of 8 / 64)
+int64_t pnnp_wino_weight_floats(int Cout, int Cin) { return (int64_t)16 * Cout * Cin; }
+
+// 1 when pnnp_conv3x3_wino_* accepts the layer (K = channels read, N = channels written)
+int pnnp_wino_supported(int K, int N) { return (K % KC == 0 && N % BN == 0) ? 1 : 0; }
+
+int pnnp_pack_conv_weight_wino_f32(const float* w, float* fwd, float* dgrad, int Cout, int Cin, void* stream) {
+    if (!w || Cout <= 0 || Cin <= 0) return PNNP_E_INVALID;
+    const int64_t total = (int64_t)Cout * Cin;
+    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    if (fwd) {
+        if (Cin % KC || Cout % BN) return PNNP_E_UNSUPPORTED;
+        hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, fwd, Cout, Cin, 0);
+    }
+    if (dgrad) {
+        if (Cout % KC || Cin % BN) return PNNP_E_UNSUPPORTED;
+        hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, dgrad, Cout, Cin, 1);
+    }
+    return pnnp_launch_status();
+}
+
+// y = act(conv3x3(cat[x1,x2]) + bias), same contract as pnnp_conv_fwd_f32 with taps = 9.
+int pnnp_conv3x3_wino_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* u_fwd, const float* bias,
+                              float* y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !u_fwd || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 <= 0)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    WinoArgs a{};
+    a.src[0] = x1; a.src_cs[0] = C1; a.src[1] = x2 ? x2 : x1; a.src_cs[1] = x2 ? C2 : C1; a.C1 = C1;
+    a.K = C1 + (x2 ? C2 : 0); a.N = Cout; a.u = u_fwd; a.B = B; a.H = H; a.W = W;
+    a.dst[0] = y; a.dst[1] = y; a.dst_cs[0] = a.dst_cs[1] = Cout; a.bias = bias; a.act = act;
+    return wino_launch(a, as_stream(stream));
+}
+
+// backward-data, same contract as pnnp_conv_bwd_data_f32 with taps = 9.
+int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgrad,
+                                   float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                   float* dx2, int C2, const float* mask2, int mode2, int accum2,
+                                   int B, int H, int W, void* stream) {
+    if (!g || !u_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    WinoArgs a{};
+    a.src[0] = g; a.src[1] = g; a.src_cs[0] = a.src_cs[1] = Cout; a.C1 = Cout;
+    a.K = Cout; a.N = C1 + (dx2 ? C2 : 0); a.u = u_dgrad; a.B = B; a.H = H; a.W = W;
+    a.dst[0] = dx1; a.dst_cs[0] = C1; a.mask[0] = mask1; a.mask_mode[0] = mask1 ? mode1 : 0; a.accum[0] = accum1;
+    a.dst[1] = dx1; a.dst_cs[1] = C1;
+    if (dx2) {
+        a.n_split = C1;
+        a.dst[1] = dx2; a.dst_cs[1] = C2; a.mask[1] = mask2; a.mask_mode[1] = mask2 ? mode2 : 0; a.accum[1] = accum2;
+    }
+    return wino_launch(a, as_stream(stream));
+}
+
+}  // extern "C"

@@ -34,6 +34,7 @@ def _prep():
     L = lib()
     if not getattr(L, '_pnnp_sigs', False):
         L.pnnp_wgrad_workspace_floats.restype = C.c_int64
+        L.pnnp_wino_weight_floats.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -67,6 +68,36 @@ def conv_bwd_data(g, w_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask
     with _Timed('conv%d_dgrad' % taps, 2.0 * B * H * W * Cout * (C1 + C2) * taps, 4.0 * B * H * W * (C1 + C2 + Cout)):
         check(_prep().pnnp_conv_bwd_data_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
                                              ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
+
+
+def wino_supported(K, N):
+    return bool(_prep().pnnp_wino_supported(int(K), int(N)))
+
+
+def pack_conv_weight_wino(w, fwd, dgrad):
+    co, ci = w.shape[:2]
+    check(_prep().pnnp_pack_conv_weight_wino_f32(ptr(w), ptr(fwd), ptr(dgrad), co, ci, stream()), 'pack_conv_weight_wino')
+
+
+def conv_wino_fwd(x1, x2, u_fwd, bias, y, cout, act):
+    """3x3 / stride 1 / pad 1 forward through the Winograd F(2x2,3x3) kernel (same contract as conv_fwd, taps=9)."""
+    require_cuda(x1, x2, u_fwd, y)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv3x3_wino_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(u_fwd), ptr(bias), ptr(y), B, H, W, cout, act,
+                                                stream()), 'conv_wino_fwd')
+    return y
+
+
+def conv_wino_bwd_data(g, u_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask2=None, mode2=0, accum2=0):
+    require_cuda(g, u_dgrad, dx1)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]
+    C2 = dx2.shape[3] if dx2 is not None else 0
+    with _Timed('conv9_dgrad', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv3x3_wino_bwd_data_f32(ptr(g), Cout, ptr(u_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
+                                                     ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv_wino_bwd_data')
 
 
 def conv_bwd_data_res(g, w_dgrad, dx, addsrc, mask=None, mode=0, taps=9):

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Per-layer timing: Winograd F(2x2,3x3) kernel vs the direct implicit-GEMM kernel on the UNet's 3x3 layers (B=16, 512^2 crops)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pnnp_amd import ops
+
+def t(fn, reps=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+B = 16
+LAYERS = [(256, 64, 0, 64), (128, 64, 0, 128), (128, 128, 0, 128), (64, 128, 0, 256), (64, 256, 0, 256),
+          (32, 256, 0, 512), (32, 512, 0, 512), (64, 256, 256, 256), (128, 128, 128, 128), (256, 64, 64, 64), (512, 32, 0, 64)]
+for (S, C1, C2, Co) in LAYERS:
+    x1 = torch.randn(B, S, S, C1, device='cuda'); x2 = torch.randn(B, S, S, C2, device='cuda') if C2 else None
+    w = torch.randn(Co, C1 + C2, 3, 3, device='cuda') * 0.05; b = torch.randn(Co, device='cuda')
+    y = torch.empty(B, S, S, Co, device='cuda'); y2 = torch.empty_like(y)
+    pk = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w, pk, None)
+    u = torch.empty(16 * Co * (C1 + C2), device='cuda'); ops.pack_conv_weight_wino(w, u, None)
+    td = t(lambda: ops.conv_fwd(x1, x2, pk, b, y, Co, 9, 1))
+    tw = t(lambda: ops.conv_wino_fwd(x1, x2, u, b, y2, Co, 1))
+    fl = 2.0 * B * S * S * Co * (C1 + C2) * 9
+    err = float((y - y2).abs().max() / y.abs().max())
+    print(f'{S:4d}^2 {C1}+{C2}->{Co}: direct {td:7.3f} ms {fl/td/1e9:7.1f} TF | wino {tw:7.3f} ms {fl/tw/1e9:7.1f} TF(alg)  x{td/tw:5.2f}  relerr {err:.2e}', flush=True)
