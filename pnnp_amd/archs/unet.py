@@ -8,6 +8,8 @@ whole network through libpnnp_hip.so (NHWC fp32 activations, fp32 MFMA) and back
 hand-sequenced pass over the same kernels, exposed to autograd as one Function so
 ``loss.backward(); optimizer.step()`` of the reference trainer works as is.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -106,7 +108,16 @@ class UNetEngine:
                 self.packed[key] = (torch.empty(taps * cip * co, dtype=torch.float32, device=dev),
                                     torch.empty(taps * cop * ci, dtype=torch.float32, device=dev))
             f, d = self.packed[key]
-            ops.pack_conv_weight(w, f, d if need_dgrad else None, cin_pad=cip, cout_pad=cop)
+            wf, wd = self._wino(name, co, ci, taps)
+            if not (wf and (wd or not need_dgrad)):
+                ops.pack_conv_weight(w, None if wf else f, d if (need_dgrad and not wd) else None, cin_pad=cip, cout_pad=cop)
+            if wf or (wd and need_dgrad):
+                wkey = (name, dev, 'wino')
+                if wkey not in self.packed:
+                    self.packed[wkey] = (torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wf else None,
+                                         torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wd else None)
+                uf, ud = self.packed[wkey]
+                ops.pack_conv_weight_wino(w, uf, ud if need_dgrad else None)
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
             key = (name, dev)
@@ -118,6 +129,18 @@ class UNetEngine:
 
     def _w(self, name):
         return self.packed[(name, self.params.flat.device)]
+
+    def _wino(self, name, co, ci, taps=9):
+        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  3x3 layers whose written channels are a
+        multiple of 64 and whose reduction is deep enough to amortise the tile prologue/epilogue.
+        PNNP_WINO=0 forces the direct implicit-GEMM kernels, PNNP_WINO_MINK sets the minimum reduction depth."""
+        if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
+            return False, False
+        mink = int(os.environ.get('PNNP_WINO_MINK', '64'))
+        return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
+
+    def _wu(self, name):
+        return self.packed[(name, self.params.flat.device, 'wino')]
 
     def mark_dirty(self):
         """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
@@ -148,6 +171,9 @@ class UNetEngine:
 
         def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
             y = out if out is not None else g(name, (B, h, w, cout))
+            cin_t = src.shape[3] + (src2.shape[3] if src2 is not None else 0)
+            if self._wino(name, cout, cin_t, taps)[0]:
+                return ops.conv_wino_fwd(src, src2, self._wu(name)[0], P[name + '.bias'], y, cout, act)
             return ops.conv_fwd(src, src2, self._w(name)[0], P[name + '.bias'], y, cout, taps, act)
 
         hs = [H >> i for i in range(5)]
@@ -192,6 +218,14 @@ class UNetEngine:
         ws = [W >> i for i in range(5)]
         wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, W),), dev)
 
+        def dgrad(name, gsrc, dx1, **kw):
+            co = gsrc.shape[3]
+            ci = dx1.shape[3] + (kw['dx2'].shape[3] if kw.get('dx2') is not None else 0)
+            if self._wino(name, co, ci)[1]:
+                ops.conv_wino_bwd_data(gsrc, self._wu(name)[1], dx1, **kw)
+            else:
+                ops.conv_bwd_data(gsrc, self._w(name)[1], dx1, **kw)
+
         def done(name):
             if on_ready is not None:
                 on_ready(self.params.slices[name + '.weight'][0])
@@ -209,12 +243,12 @@ class UNetEngine:
             lvl = 9 - i
             wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
             g_a = gb(f'c{i}a', a[f'c{i}a'].shape)
-            ops.conv_bwd_data(g_cur, self._w(f'conv{i}_2')[1], g_a, mask1=a[f'c{i}a'], mode1=LRELU)
+            dgrad(f'conv{i}_2', g_cur, g_a, mask1=a[f'c{i}a'], mode1=LRELU)
             skip = a[f'c{lvl + 1}']
             wgrad(f'conv{i}_1', g_a, ch[lvl], a[f'u{i}'], ch[lvl], x2=skip)
             g_u = gb(f'u{i}', a[f'u{i}'].shape)
             g_skip = gb(f'c{lvl + 1}', skip.shape)
-            ops.conv_bwd_data(g_a, self._w(f'conv{i}_1')[1], g_u, dx2=g_skip, mask2=skip, mode2=LRELU)
+            dgrad(f'conv{i}_1', g_a, g_u, dx2=g_skip, mask2=skip, mode2=LRELU)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
             ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc)
             ops.channel_sum(g_u, G(f'upv{i}.bias', (ch[lvl],)), wsf, accumulate=acc)
@@ -226,12 +260,12 @@ class UNetEngine:
             lvl = i - 1
             wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
             g_a = gb(f'c{i}a', a[f'c{i}a'].shape)
-            ops.conv_bwd_data(g_cur, self._w(f'conv{i}_2')[1], g_a, mask1=a[f'c{i}a'], mode1=LRELU)
+            dgrad(f'conv{i}_2', g_cur, g_a, mask1=a[f'c{i}a'], mode1=LRELU)
             if i > 1:
                 src = a[f'p{i - 1}']
                 wgrad(f'conv{i}_1', g_a, ch[lvl], src, ch[lvl - 1])
                 g_p = gb(f'p{i - 1}', src.shape)
-                ops.conv_bwd_data(g_a, self._w(f'conv{i}_1')[1], g_p)
+                dgrad(f'conv{i}_1', g_a, g_p)
                 g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
                 ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1)
             else:

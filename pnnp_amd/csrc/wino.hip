@@ -108,7 +108,6 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         roff1[s] = pix * a.src_cs[1] + (tid & 1) * 4;
         rdst[s] = py * RAW_ROW + ((px & 1) * 9 + (px >> 1)) * KC + (tid & 1) * 4;
     }
-    const bool slot2 = tid + 512 < PATCH * PATCH * 2;
     const int nchunks = a.K / KC;
     const float* ug = a.u + (int64_t)nb * nchunks * US_STAGE + tid * 4;
 
@@ -130,7 +129,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(r + rdst[0]) = rok[0] ? rr[0] : z;
         *reinterpret_cast<f32x4*>(r + rdst[1]) = rok[1] ? rr[1] : z;
-        if (slot2) *reinterpret_cast<f32x4*>(r + rdst[2]) = rok[2] ? rr[2] : z;
+        *reinterpret_cast<f32x4*>(r + rdst[2]) = rok[2] ? rr[2] : z;     // slots past the 648th duplicate the last one
     };
     auto store_u = [&](int stage) {
         float* us = Us + stage * US_STAGE + tid * 4;
@@ -157,32 +156,92 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
 
     const int voff = (lane >> 5) * VPLANE + (wm * 32 + (lane & 31)) * 4;
     const int uoff = (lane >> 5) * UPLANE + (wn * 32 + (lane & 31)) * 4;
+    // per-thread constants of the two input-transform items (tile row ty = tyb, tyb+4; channel quad cg; row i of B^T)
+    const int it_cg = tid & 1, it_tx = (tid >> 1) & 7, it_i = (tid >> 4) & 3, it_ty = tid >> 6;
+    const int it_ra = (it_i == 0) ? 0 : (it_i == 2 ? 2 : 1);
+    const int it_rb = (it_i == 0) ? 2 : (it_i == 1 ? 2 : (it_i == 2 ? 1 : 3));
+    const float it_sg = (it_i == 1) ? 1.f : -1.f;
+    const int it_a = (2 * it_ty + it_ra) * RAW_ROW + it_tx * KC + it_cg * 4;      // + item*8*RAW_ROW + column offset
+    const int it_b = (2 * it_ty + it_rb) * RAW_ROW + it_tx * KC + it_cg * 4;
+    const int it_o = (it_i * 8 + it_cg) * VPLANE + (it_ty * 8 + it_tx) * 4;        // + item*32*4 + j*2*VPLANE
+    const int us_w = tid * 4;
+
+    // One branch-free basic block per chunk: the 64 MFMAs of chunk c with, in their shadow, the input transform of
+    // chunk c+1, the LDS stores of U(c+1)/patch(c+2) and the global loads of U(c+2)/patch(c+3).  Past the last
+    // chunk the same instructions run on clamped (valid) addresses and write LDS buffers nobody reads.
     for (int c = 0; c < nchunks; ++c) {
         const int stage = c & 1;
-        if (c + 1 < nchunks) store_u(stage ^ 1);
-        if (c + 2 < nchunks) store_raw(stage);
-        if (c + 3 < nchunks) gload_raw(c + 3);
-        if (c + 2 < nchunks) gload_u(c + 2);
         const float* vb = Vs + stage * VS_STAGE + voff;
         const float* ub = Us + stage * US_STAGE + uoff;
+        const float* rsrc = raws + (stage ^ 1) * RAW_FLOATS;         // patch(c+1)
+        float* vdst = Vs + (stage ^ 1) * VS_STAGE + it_o;
+        float* usdst = Us + (stage ^ 1) * US_STAGE + us_w;
+        float* rdstb = raws + stage * RAW_FLOATS;                    // receives patch(c+2)
+        const float* unext = ug + (int64_t)min(c + 2, nchunks - 1) * US_STAGE;
+        const int k3 = min(c + 3, nchunks - 1) * KC;
+        const int s3 = k3 >= a.C1;
+        const float* rnext = (s3 ? a.src[1] : a.src[0]) + (k3 - (s3 ? a.C1 : 0));
         float4 av[2], bv[2];
+        float4 da[2], db[2], tt[4];
         av[0] = *reinterpret_cast<const float4*>(vb);
         bv[0] = *reinterpret_cast<const float4*>(ub);
-#pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
-            if (xi + 1 < 16) {
-                av[(xi + 1) & 1] = *reinterpret_cast<const float4*>(vb + (xi + 1) * 2 * VPLANE);
-                bv[(xi + 1) & 1] = *reinterpret_cast<const float4*>(ub + (xi + 1) * 2 * UPLANE);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            const float4 A = av[xi & 1], Bv = bv[xi & 1];
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bv.x, acc[xi], 0, 0, 0);
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bv.y, acc[xi], 0, 0, 0);
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bv.z, acc[xi], 0, 0, 0);
-            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bv.w, acc[xi], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        // one step = the 4 MFMAs of transformed position xi plus a fixed slice of the other work
+#define WINO_STEP(XI)                                                                                                  \
+        {                                                                                                              \
+            constexpr int xi = XI;                                                                                     \
+            constexpr int ur_ = (xi < 4) ? xi : ((xi >= 6 && xi < 10) ? xi - 2 : -1);    /* unit whose LDS reads go here */ \
+            constexpr int uf_ = (xi >= 1 && xi < 5) ? xi - 1 : ((xi >= 7 && xi < 11) ? xi - 3 : -1);   /* unit whose fma goes here */ \
+            constexpr bool out_ = (xi == 5 || xi == 11), ust_ = xi < 8, pst_ = (xi >= 12 && xi < 15);                  \
+            constexpr int n_read = (xi + 1 < 16 ? 2 : 0) + (ur_ >= 0 ? 2 : 0);                                         \
+            constexpr int n_valu = (uf_ >= 0 ? 4 : 0) + (ust_ ? 2 : 0) + (out_ ? 16 : 0) + (pst_ ? 8 : 0);             \
+            constexpr int n_write = (ust_ ? 1 : 0) + (out_ ? 4 : 0) + (pst_ ? 1 : 0);                                  \
+            constexpr int n_vmem = (ust_ ? 1 : 0) + (pst_ ? 1 : 0);                                                    \
+            if constexpr (xi + 1 < 16) {                                                                               \
+                av[(xi + 1) & 1] = *reinterpret_cast<const float4*>(vb + (xi + 1) * 2 * VPLANE);                       \
+                bv[(xi + 1) & 1] = *reinterpret_cast<const float4*>(ub + (xi + 1) * 2 * UPLANE);                       \
+            }                                                                                                          \
+            if constexpr (ur_ >= 0) {                                                                                  \
+                constexpr int col = (((ur_ & 3) & 1) * 9 + ((ur_ & 3) >> 1)) * KC + (ur_ >> 2) * 8 * RAW_ROW;          \
+                da[ur_ & 1] = *reinterpret_cast<const float4*>(rsrc + it_a + col);                                     \
+                db[ur_ & 1] = *reinterpret_cast<const float4*>(rsrc + it_b + col);                                     \
+            }                                                                                                          \
+            const float4 A = av[xi & 1], Bv = bv[xi & 1];                                                              \
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bv.x, acc[xi], 0, 0, 0);                               \
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bv.y, acc[xi], 0, 0, 0);                               \
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bv.z, acc[xi], 0, 0, 0);                               \
+            acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bv.w, acc[xi], 0, 0, 0);                               \
+            if constexpr (uf_ >= 0) tt[uf_ & 3] = f4_fma(db[uf_ & 1], it_sg, da[uf_ & 1]);                             \
+            if constexpr (ust_) {                                           /* U(c+1) -> LDS, U(c+2) -> registers */   \
+                *reinterpret_cast<f32x4*>(usdst + (xi & 7) * 1024) = ur[xi & 7];                                       \
+                ur[xi & 7] = *reinterpret_cast<const f32x4*>(unext + (xi & 7) * 1024);                                 \
+            }                                                                                                          \
+            if constexpr (out_) {                                           /* outputs of item 0 / item 1 */           \
+                float* o = vdst + (xi == 11 ? 32 * 4 : 0);                                                             \
+                *reinterpret_cast<float4*>(o) = f4_sub(tt[0], tt[2]);                                                  \
+                *reinterpret_cast<float4*>(o + 2 * VPLANE) = f4_add(tt[1], tt[2]);                                     \
+                *reinterpret_cast<float4*>(o + 4 * VPLANE) = f4_sub(tt[2], tt[1]);                                     \
+                *reinterpret_cast<float4*>(o + 6 * VPLANE) = f4_sub(tt[1], tt[3]);                                     \
+            }                                                                                                          \
+            if constexpr (pst_) {                                           /* patch(c+2) -> LDS, patch(c+3) -> registers */ \
+                constexpr int j = pst_ ? xi - 12 : 0;                                                                  \
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                                  \
+                *reinterpret_cast<f32x4*>(rdstb + rdst[j]) = rok[j] ? rr[j] : z;                                       \
+                rr[j] = *reinterpret_cast<const f32x4*>(rnext + (s3 ? roff1[j] : roff0[j]));                           \
+            }                                                                                                          \
+            /* pin the order: this step's LDS reads, then the MFMAs with the other work in their shadow */             \
+            if constexpr (n_read > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_read, 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            if constexpr (n_valu > 0) __builtin_amdgcn_sched_group_barrier(0x002, (n_valu + 1) / 2, 0);                \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            if constexpr (n_write > 0) __builtin_amdgcn_sched_group_barrier(0x200, n_write, 0);                        \
+            if constexpr (n_vmem > 0) __builtin_amdgcn_sched_group_barrier(0x020, n_vmem, 0);                          \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            if constexpr (n_valu > 1) __builtin_amdgcn_sched_group_barrier(0x002, n_valu / 2, 0);                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
         }
-        if (c + 1 < nchunks) input_transform(raws + (stage ^ 1) * RAW_FLOATS, Vs + (stage ^ 1) * VS_STAGE, tid);
+        WINO_STEP(0) WINO_STEP(1) WINO_STEP(2) WINO_STEP(3) WINO_STEP(4) WINO_STEP(5) WINO_STEP(6) WINO_STEP(7)
+        WINO_STEP(8) WINO_STEP(9) WINO_STEP(10) WINO_STEP(11) WINO_STEP(12) WINO_STEP(13) WINO_STEP(14) WINO_STEP(15)
+#undef WINO_STEP
         __syncthreads();
     }
 
@@ -195,6 +254,21 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     const float* mask = d ? a.mask[1] : a.mask[0];
     const int mmode = d ? a.mask_mode[1] : a.mask_mode[0], accum = d ? a.accum[1] : a.accum[0];
     const float bias = a.bias ? a.bias[n] : 0.f;
+    const int64_t img = (int64_t)b * a.H * a.W;
+    // act' masks: all 64 loads of this thread in flight at once (one HBM latency instead of 64)
+    float mk[16][4];
+    if (mmode) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            const int ty = m >> 3, tx = m & 7;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int y = min(y0 + 2 * ty + (p >> 1), a.H - 1), x = min(x0 + 2 * tx + (p & 1), a.W - 1);
+                mk[e][p] = __builtin_nontemporal_load(mask + (img + (int64_t)y * a.W + x) * dcs + nc);
+            }
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
@@ -210,16 +284,13 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         for (int p = 0; p < 4; ++p) {
             const int y = y0 + 2 * ty + (p >> 1), x = x0 + 2 * tx + (p & 1);
             if (y < a.H && x < a.W) {
-                const int64_t pix = ((int64_t)b * a.H + y) * a.W + x;
+                const int64_t o = (img + (int64_t)y * a.W + x) * dcs + nc;
                 float v = yv[p] + bias;
-                if (a.addsrc) v += a.addsrc[pix * dcs + nc];
+                if (a.addsrc) v += a.addsrc[o];
                 v = act_fn(v, a.act);
-                if (mmode) {
-                    const float mk = mask[pix * dcs + nc];
-                    v *= (mk > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
-                }
-                if (accum) v += dst[pix * dcs + nc];
-                dst[pix * dcs + nc] = v;
+                if (mmode) v *= (mk[e][p] > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
+                if (accum) v += dst[o];
+                dst[o] = v;
             }
         }
     }

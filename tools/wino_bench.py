@@ -28,3 +28,19 @@ for (S, C1, C2, Co) in LAYERS:
     fl = 2.0 * B * S * S * Co * (C1 + C2) * 9
     err = float((y - y2).abs().max() / y.abs().max())
     print(f'{S:4d}^2 {C1}+{C2}->{Co}: direct {td:7.3f} ms {fl/td/1e9:7.1f} TF | wino {tw:7.3f} ms {fl/tw/1e9:7.1f} TF(alg)  x{td/tw:5.2f}  relerr {err:.2e}', flush=True)
+print('--- backward-data (act\' mask on the written tensor; concat layers split into two destinations)')
+for (S, C1, C2, Co) in LAYERS:
+    if C1 % 64 or (C2 and C2 % 64):
+        continue
+    g = torch.randn(B, S, S, Co, device='cuda'); w = torch.randn(Co, C1 + C2, 3, 3, device='cuda') * 0.05
+    pk = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w, None, pk)
+    u = torch.empty(16 * Co * (C1 + C2), device='cuda'); ops.pack_conv_weight_wino(w, None, u)
+    d1 = torch.empty(B, S, S, C1, device='cuda'); e1 = torch.empty_like(d1); m1 = torch.randn_like(d1)
+    d2 = torch.empty(B, S, S, C2, device='cuda') if C2 else None; e2 = torch.empty_like(d2) if C2 else None
+    m2 = torch.randn_like(d2) if C2 else None
+    kw = dict(mask1=None if C2 else m1, mode1=0 if C2 else 1, mask2=m2, mode2=1 if C2 else 0)
+    td = t(lambda: ops.conv_bwd_data(g, pk, d1, dx2=d2, **kw))
+    tw = t(lambda: ops.conv_wino_bwd_data(g, u, e1, dx2=e2, **kw))
+    fl = 2.0 * B * S * S * Co * (C1 + C2) * 9
+    err = float((d1 - e1).abs().max() / d1.abs().max())
+    print(f'{S:4d}^2 {Co}->{C1}+{C2}: direct {td:7.3f} ms {fl/td/1e9:7.1f} TF | wino {tw:7.3f} ms {fl/tw/1e9:7.1f} TF(alg)  x{td/tw:5.2f}  relerr {err:.2e}', flush=True)
