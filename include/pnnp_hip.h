@@ -140,6 +140,14 @@ int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgra
                                    float* dx1, int C1, const float* mask1, int mode1, int accum1,
                                    float* dx2, int C2, const float* mask2, int mode2, int accum2,
                                    int B, int H, int W, void* stream);
+/* Winograd backward-weight (dg = G^T [sum_tiles (A dY A^T) (.) (B^T d B)] G): same contract as
+ * pnnp_conv_bwd_weight_f32 with taps = 9; needs H % 4 == 0, W % 8 == 0 and Cout, C1, C2 multiples of 64. */
+int pnnp_wino_wgrad_supported(int H, int W, int Cout, int C1, int C2);
+int64_t pnnp_wino_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
+int pnnp_conv3x3_wino_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
+                                     const float* x2, int x2_cs, int C2, float* dW, float* dbias /*or null*/,
+                                     int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats,
+                                     void* stream);
 /* backward-weight: dW [Cout][C1+C2][taps] (+ dbias [Cout]); workspace from the query below. */
 int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps);
 int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps);

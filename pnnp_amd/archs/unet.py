@@ -139,6 +139,12 @@ class UNetEngine:
         mink = int(os.environ.get('PNNP_WINO_MINK', '64'))
         return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
 
+    def _wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
+        """Backward-weight through the Winograd kernel?  (PNNP_WINO=0 / PNNP_WINO_WGRAD=0 force the direct kernel.)"""
+        if os.environ.get('PNNP_WINO', '1') == '0' or os.environ.get('PNNP_WINO_WGRAD', '1') == '0':
+            return False
+        return g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
+
     def _wu(self, name):
         return self.packed[(name, self.params.flat.device, 'wino')]
 
@@ -231,8 +237,13 @@ class UNetEngine:
                 on_ready(self.params.slices[name + '.weight'][0])
 
         def wgrad(name, gpre, cout, x1, c1, x2=None, taps=9):
-            ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
-                                G(name + '.bias', (cout,)), taps, wsf, accumulate=acc)
+            c2 = x2.shape[3] if x2 is not None else 0
+            if taps == 9 and self._wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
+                ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
+                                         G(name + '.bias', (cout,)), wsf, accumulate=acc)
+            else:
+                ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
+                                    G(name + '.bias', (cout,)), taps, wsf, accumulate=acc)
             done(name)
 
         # conv10_1 (1x1, no activation); its input c9 is a LeakyReLU output
@@ -282,7 +293,8 @@ class UNetEngine:
             c = ch[lvl]
             cin = self.cin if lvl == 0 else ch[lvl - 1]
             need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, cin, 9),
-                       ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9))
+                       ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9), ops.wino_wgrad_workspace_floats(B, h, w, c, c),
+                       ops.wino_wgrad_workspace_floats(B, h, w, c, cin), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c))
             if lvl < 4:
                 need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lvl + 1], c, 4))
         need = max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))

@@ -35,6 +35,7 @@ def _prep():
     if not getattr(L, '_pnnp_sigs', False):
         L.pnnp_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_wino_weight_floats.restype = C.c_int64
+        L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -98,6 +99,25 @@ def conv_wino_bwd_data(g, u_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None,
     with _Timed('conv9_dgrad', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
         check(_prep().pnnp_conv3x3_wino_bwd_data_f32(ptr(g), Cout, ptr(u_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
                                                      ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv_wino_bwd_data')
+
+
+def wino_wgrad_supported(H, W, cout, c1, c2=0):
+    return bool(_prep().pnnp_wino_wgrad_supported(int(H), int(W), int(cout), int(c1), int(c2)))
+
+
+def wino_wgrad_workspace_floats(B, H, W, cout, cin):
+    return int(_prep().pnnp_wino_wgrad_workspace_floats(B, H, W, cout, cin))
+
+
+def conv_wino_bwd_weight(g, cout, x1, c1, x2, dW, dbias, workspace, accumulate=0):
+    """dW [cout][c1+c2][3][3] (+ dbias) through the Winograd backward-weight kernel (same contract as conv_bwd_weight, taps=9)."""
+    require_cuda(g, x1, dW, workspace)
+    B, H, W, gcs = g.shape
+    c2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_wgrad', 2.0 * B * H * W * cout * (c1 + c2) * 9, 4.0 * B * H * W * (gcs + x1.shape[3] + c2)):
+        check(_prep().pnnp_conv3x3_wino_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), c2, c2, ptr(dW), ptr(dbias),
+                                                       B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
+              'conv_wino_bwd_weight')
 
 
 def conv_bwd_data_res(g, w_dgrad, dx, addsrc, mask=None, mode=0, taps=9):

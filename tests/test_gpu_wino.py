@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 CASES = [  # B, H, W, C1, C2, Cout
     (1, 16, 16, 8, 0, 64), (2, 32, 48, 32, 0, 64), (1, 20, 36, 64, 0, 128), (1, 9, 33, 64, 64, 64),
     (1, 5, 7, 128, 128, 128), (2, 16, 16, 256, 0, 256), (1, 89, 133, 16, 0, 64), (1, 2, 2, 64, 0, 64),
+    (3, 160, 176, 8, 0, 64),          # many workgroups per channel block
 ]
 
 
@@ -68,3 +69,38 @@ def test_wino_unsupported_shapes():
     w = torch.zeros(32, 64, 3, 3, device='cuda')
     with pytest.raises(_lib.PnnpError):
         ops.pack_conv_weight_wino(w, torch.empty(16 * 32 * 64, device='cuda'), None)
+
+
+WG_CASES = [  # B, H, W, C1, C2, Cout
+    (1, 4, 8, 64, 0, 64), (2, 16, 24, 64, 0, 128), (1, 12, 40, 128, 0, 64), (2, 8, 16, 64, 64, 64),
+    (1, 20, 32, 128, 128, 128), (3, 32, 32, 64, 0, 64), (1, 64, 64, 64, 0, 64),
+]
+
+
+@pytest.mark.parametrize('case', WG_CASES)
+def test_wino_bwd_weight(case):
+    """dW and dbias of conv3x3 on cat[x1,x2] against torch autograd (CPU, fp32).  Sums run over up to B*H*W pixels in a
+    different order (and through the 4x4 transforms): rtol 3e-4 / atol 3e-5 x magnitude."""
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    assert ops.wino_wgrad_supported(H, W, Co, C1, C2)
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    g = _rand(B, Co, H, W, seed=5)
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2).requires_grad_(True)
+    b = _rand(Co, seed=4).requires_grad_(True)
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    (F.conv2d(xin, w, b, padding=1) * g).sum().backward()
+    ws = torch.empty(ops.wino_wgrad_workspace_floats(B, H, W, Co, C1 + C2), device='cuda')
+    dW = torch.full((Co, C1 + C2, 3, 3), float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_wino_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW, db, ws)
+    close(dW, w.grad, rtol=3e-4, atol=3e-5, what=f'wino wgrad {case}')
+    close(db, b.grad, rtol=3e-4, atol=3e-5, what=f'wino bgrad {case}')
+    ops.conv_wino_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW, db, ws, accumulate=1)
+    close(dW, 2 * w.grad, rtol=3e-4, atol=3e-5, what='wino wgrad accumulate')
+    close(db, 2 * b.grad, rtol=3e-4, atol=3e-5, what='wino bgrad accumulate')
+
+
+def test_wino_bwd_weight_unsupported():
+    from pnnp_amd import ops
+    assert not ops.wino_wgrad_supported(6, 8, 64, 64) and not ops.wino_wgrad_supported(8, 12, 64, 64)
+    assert not ops.wino_wgrad_supported(8, 8, 32, 64) and not ops.wino_wgrad_supported(8, 8, 64, 64, 32)

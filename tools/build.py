@@ -13,7 +13,9 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
           '-I', os.path.join(REPO, 'include')]
 # per-file extra flags: the sampler keeps every float32 rounding explicit (matches oracle/pnnp_oracle.c)
-EXTRA = {'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off'], 'cropaug.hip': ['-ffp-contract=off']}
+EXTRA = {'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off'], 'cropaug.hip': ['-ffp-contract=off'],
+         # the Winograd backward-weight kernel's source order is its schedule (slots fenced with sched_barrier)
+         'wino_wgrad.hip': ['-mllvm', '-pre-RA-sched=source']}
 
 
 def newer(a, deps):

@@ -44,3 +44,17 @@ for (S, C1, C2, Co) in LAYERS:
     fl = 2.0 * B * S * S * Co * (C1 + C2) * 9
     err = float((d1 - e1).abs().max() / d1.abs().max())
     print(f'{S:4d}^2 {Co}->{C1}+{C2}: direct {td:7.3f} ms {fl/td/1e9:7.1f} TF | wino {tw:7.3f} ms {fl/tw/1e9:7.1f} TF(alg)  x{td/tw:5.2f}  relerr {err:.2e}', flush=True)
+print('--- backward-weight')
+for (S, C1, C2, Co) in LAYERS:
+    if not ops.wino_wgrad_supported(S, S, Co, C1, C2):
+        continue
+    g = torch.randn(B, S, S, Co, device='cuda'); x1 = torch.randn(B, S, S, C1, device='cuda')
+    x2 = torch.randn(B, S, S, C2, device='cuda') if C2 else None
+    dW = torch.empty(Co, C1 + C2, 3, 3, device='cuda'); dW2 = torch.empty_like(dW); db = torch.empty(Co, device='cuda')
+    ws = torch.empty(ops.wgrad_workspace_floats(B, S, S, Co, C1 + C2, 9), device='cuda')
+    ws2 = torch.empty(ops.wino_wgrad_workspace_floats(B, S, S, Co, C1 + C2), device='cuda')
+    td = t(lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws))
+    tw = t(lambda: ops.conv_wino_bwd_weight(g, Co, x1, C1, x2, dW2, db, ws2))
+    fl = 2.0 * B * S * S * Co * (C1 + C2) * 9
+    err = float((dW - dW2).abs().max() / dW.abs().max())
+    print(f'{S:4d}^2 {C1}+{C2}->{Co}: direct {td:7.3f} ms {fl/td/1e9:7.1f} TF | wino {tw:7.3f} ms {fl/tw/1e9:7.1f} TF(alg)  x{td/tw:5.2f}  relerr {err:.2e}', flush=True)
