@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WwArgs a) {
         gprow[s] = px >> 3; gpcol[s] = px & 7; gdst[s] = px * 64 + (q & 15) * 4;
     }
     f32x4 xr[4], gr[2];
-    bool xok[4], xok_n[4];
+    bool xok[4];
     auto chunk_pos = [&](int c, int& b, int& y0, int& x0) {
         const int cx = c % a.chunks_x; c /= a.chunks_x;
         const int cy = c % a.chunks_y;
@@ -124,75 +124,37 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WwArgs a) {
         for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(graw + gdst[s]) = gr[s];
     };
 
-    // ---- transforms: lane = channel; Z = A dY A^T, V = B^T d B for one tile row, raw LDS -> [xi][tq][lane][4 tiles].
-    // Every piece is small enough (<= ~10 instructions) to hide behind ONE MFMA: a slot that overruns the 64 cycles
-    // of its MFMA stalls the matrix pipe, so the work is cut fine and spread over the chunk's 64 slots.
-    float y0r[2][8], y1r[2][8], dar[2][10], dbr[2][10], zr[8], vtt[10];
+    // ---- transforms: lane = channel; Z = A dY A^T, V = B^T d B for one tile row, raw LDS -> [xi][tq][lane][4 tiles]
+    float y0r[8], y1r[8], dar[10], dbr[10];
     float bsum = 0.f;
-    auto z_read4 = [&](int tq, int part) {                            // part 0..3: 4 of the 16 LDS reads
-        const int r = part >> 1, c0 = (part & 1) * 4;
+    auto z_read = [&](int tq) {
 #pragma unroll
-        for (int cc = c0; cc < c0 + 4; ++cc) (r ? y1r : y0r)[tq][cc] = graw[((2 * tq + r) * 8 + cc) * 64 + lane];
+        for (int cc = 0; cc < 8; ++cc) { y0r[cc] = graw[((2 * tq) * 8 + cc) * 64 + lane]; y1r[cc] = graw[((2 * tq + 1) * 8 + cc) * 64 + lane]; }
     };
-    auto z_comb = [&](int tq, int half) {
+    auto z_write = [&](float* zt, int tq, float wsum) {
+        float r[8];
 #pragma unroll
-        for (int cc = half * 4; cc < half * 4 + 4; ++cc) zr[cc] = za * y0r[tq][cc] + zb * y1r[tq][cc];
+        for (int cc = 0; cc < 8; ++cc) r[cc] = za * y0r[cc] + zb * y1r[cc];
+        bsum = fmaf(wsum, ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7])), bsum);   // wave 1: sum of g
+        float* o = zt + ((i * 4) * 2 + tq) * PLANE + lane * 4;
+        *reinterpret_cast<float4*>(o) = make_float4(r[0], r[2], r[4], r[6]);
+        *reinterpret_cast<float4*>(o + 2 * PLANE) = make_float4(r[0] + r[1], r[2] + r[3], r[4] + r[5], r[6] + r[7]);
+        *reinterpret_cast<float4*>(o + 4 * PLANE) = make_float4(r[0] - r[1], r[2] - r[3], r[4] - r[5], r[6] - r[7]);
+        *reinterpret_cast<float4*>(o + 6 * PLANE) = make_float4(-r[1], -r[3], -r[5], -r[7]);
     };
-    auto z_sum = [&](float wsum) {
-        bsum = fmaf(wsum, ((zr[0] + zr[1]) + (zr[2] + zr[3])) + ((zr[4] + zr[5]) + (zr[6] + zr[7])), bsum);   // wave 1: sum of g
-    };
-    auto z_store = [&](float* zt, int tq, int j) {
-        float* o = zt + ((i * 4 + j) * 2 + tq) * PLANE + lane * 4;
-        if (j == 0) *reinterpret_cast<float4*>(o) = make_float4(zr[0], zr[2], zr[4], zr[6]);
-        else if (j == 1) *reinterpret_cast<float4*>(o) = make_float4(zr[0] + zr[1], zr[2] + zr[3], zr[4] + zr[5], zr[6] + zr[7]);
-        else if (j == 2) *reinterpret_cast<float4*>(o) = make_float4(zr[0] - zr[1], zr[2] - zr[3], zr[4] - zr[5], zr[6] - zr[7]);
-        else *reinterpret_cast<float4*>(o) = make_float4(-zr[1], -zr[3], -zr[5], -zr[7]);
-    };
-    auto v_read4 = [&](int tq, int part) {                            // part 0..4: columns 2*part, 2*part+1 of both rows
+    auto v_read = [&](int tq) {
 #pragma unroll
-        for (int cc = 2 * part; cc < 2 * part + 2; ++cc) {
-            dar[tq][cc] = xraw[((2 * tq + ra) * 10 + cc) * 64 + lane];
-            dbr[tq][cc] = xraw[((2 * tq + rb) * 10 + cc) * 64 + lane];
-        }
+        for (int cc = 0; cc < 10; ++cc) { dar[cc] = xraw[((2 * tq + ra) * 10 + cc) * 64 + lane]; dbr[cc] = xraw[((2 * tq + rb) * 10 + cc) * 64 + lane]; }
     };
-    auto v_comb = [&](int tq, int half) {
+    auto v_write = [&](float* vt, int tq) {
+        float t[10];
 #pragma unroll
-        for (int cc = half * 5; cc < half * 5 + 5; ++cc) vtt[cc] = fmaf(sg, dbr[tq][cc], dar[tq][cc]);
-    };
-    auto v_store = [&](float* vt, int tq, int j) {
-        float* o = vt + ((i * 4 + j) * 2 + tq) * PLANE + lane * 4;
-        const float* t = vtt;
-        if (j == 0) *reinterpret_cast<float4*>(o) = make_float4(t[0] - t[2], t[2] - t[4], t[4] - t[6], t[6] - t[8]);
-        else if (j == 1) *reinterpret_cast<float4*>(o) = make_float4(t[1] + t[2], t[3] + t[4], t[5] + t[6], t[7] + t[8]);
-        else if (j == 2) *reinterpret_cast<float4*>(o) = make_float4(t[2] - t[1], t[4] - t[3], t[6] - t[5], t[8] - t[7]);
-        else *reinterpret_cast<float4*>(o) = make_float4(t[1] - t[3], t[3] - t[5], t[5] - t[7], t[7] - t[9]);
-    };
-    auto transform_all = [&](float* zt, float* vt) {                  // prologue only
-#pragma unroll
-        for (int tq = 0; tq < 2; ++tq) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) z_read4(tq, q);
-            z_comb(tq, 0); z_comb(tq, 1); z_sum(1.f);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) z_store(zt, tq, j);
-#pragma unroll
-            for (int q = 0; q < 5; ++q) v_read4(tq, q);
-            v_comb(tq, 0); v_comb(tq, 1);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v_store(vt, tq, j);
-        }
-    };
-    // staging split per slot: addresses, load, store
-    int xoff[4], goff[2];
-    auto addr_x = [&](int c, int s) {
-        int b, y0, x0; chunk_pos(c, b, y0, x0);
-        const int y = y0 - 1 + xprow[s], x = x0 - 1 + xpcol[s];
-        xok_n[s] = y >= 0 && y < a.H && x >= 0 && x < a.W;
-        xoff[s] = ((b * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1)) * xcs + (tid & 15) * 4;
-    };
-    auto addr_g = [&](int c, int s) {
-        int b, y0, x0; chunk_pos(c, b, y0, x0);
-        goff[s] = ((b * a.H + y0 + gprow[s]) * a.W + x0 + gpcol[s]) * gcs + (tid & 15) * 4;
+        for (int cc = 0; cc < 10; ++cc) t[cc] = fmaf(sg, dbr[cc], dar[cc]);
+        float* o = vt + ((i * 4) * 2 + tq) * PLANE + lane * 4;
+        *reinterpret_cast<float4*>(o) = make_float4(t[0] - t[2], t[2] - t[4], t[4] - t[6], t[6] - t[8]);
+        *reinterpret_cast<float4*>(o + 2 * PLANE) = make_float4(t[1] + t[2], t[3] + t[4], t[5] + t[6], t[7] + t[8]);
+        *reinterpret_cast<float4*>(o + 4 * PLANE) = make_float4(t[2] - t[1], t[4] - t[3], t[6] - t[5], t[8] - t[7]);
+        *reinterpret_cast<float4*>(o + 6 * PLANE) = make_float4(t[1] - t[3], t[3] - t[5], t[5] - t[7], t[7] - t[9]);
     };
 
     f32x16 acc[16];
@@ -204,7 +166,8 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WwArgs a) {
     // ---- prologue: chunk 0 -> Zt/Vt stage 0, chunk 1 -> raw, chunk 2 -> registers (indices park on the last chunk)
     gload(c_begin); lstore();
     __syncthreads();
-    transform_all(Zt, Vt);
+    z_read(0); z_write(Zt, 0, 1.f); z_read(1); z_write(Zt, 1, 1.f);
+    v_read(0); v_write(Vt, 0); v_read(1); v_write(Vt, 1);
     __syncthreads();
     gload(min(c_begin + 1, c_end - 1)); lstore();
     gload(min(c_begin + 2, c_end - 1));
@@ -229,35 +192,19 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WwArgs a) {
         //   step  5      barrier: every wave is done reading raw
         //   steps 6,7    chunk p+2: registers -> raw;  steps 8,9  chunk p+3: global -> registers
         auto slot = [&](auto IC) {
-            constexpr int id = (WW_EXPERIMENT & 1) ? 999 : decltype(IC)::value;
-            // 0-7 Z reads | 8-21 Z math + stores | 22-31 V reads | 32-43 V math + stores | 44 barrier |
-            // 45-50 chunk p+2 registers -> raw | 51-62 chunk p+3 addresses + global loads
-            if constexpr (id < 8) z_read4(id >> 2, id & 3);
-            else if constexpr (id == 8 || id == 9) z_comb(0, id - 8);
-            else if constexpr (id == 10) z_sum(wsum);
-            else if constexpr (id >= 11 && id <= 14) z_store(zt, 0, id - 11);
-            else if constexpr (id == 15 || id == 16) z_comb(1, id - 15);
-            else if constexpr (id == 17) z_sum(wsum);
-            else if constexpr (id >= 18 && id <= 21) z_store(zt, 1, id - 18);
-            else if constexpr (id >= 22 && id <= 31) v_read4((id - 22) / 5, (id - 22) % 5);
-            else if constexpr (id == 32 || id == 33) v_comb(0, id - 32);
-            else if constexpr (id >= 34 && id <= 37) v_store(vt, 0, id - 34);
-            else if constexpr (id == 38 || id == 39) v_comb(1, id - 38);
-            else if constexpr (id >= 40 && id <= 43) v_store(vt, 1, id - 40);
-            else if constexpr (id == 44) __syncthreads();
-            else if constexpr (id >= 45 && id <= 48) {
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(xraw + xdst[id - 45]) = xok[id - 45] ? xr[id - 45] : z4;
-            } else if constexpr (id == 49 || id == 50) *reinterpret_cast<f32x4*>(graw + gdst[id - 49]) = gr[id - 49];
-            else if constexpr (id >= 51 && id <= 58) {
-                constexpr int s = (id - 51) >> 1;
-                if constexpr (((id - 51) & 1) == 0) addr_x(cnext, s);
-                else { xr[s] = *reinterpret_cast<const f32x4*>(xsrc + xoff[s]); xok[s] = xok_n[s]; }
-            } else if constexpr (id >= 59 && id <= 62) {
-                constexpr int s = (id - 59) >> 1;
-                if constexpr (((id - 59) & 1) == 0) addr_g(cnext, s);
-                else gr[s] = *reinterpret_cast<const f32x4*>(gsrc + goff[s]);
-            }
+            constexpr int id = decltype(IC)::value;
+            constexpr int st = (WW_EXPERIMENT & 1) ? 99 : (id >> 2), k = id & 3;
+            if constexpr (st == 0 && k == 0) z_read(0);
+            if constexpr (st == 1 && k == 0) z_write(zt, 0, wsum);
+            if constexpr (st == 1 && k == 2) z_read(1);
+            if constexpr (st == 2 && k == 0) z_write(zt, 1, wsum);
+            if constexpr (st == 2 && k == 2) v_read(0);
+            if constexpr (st == 3 && k == 0) v_write(vt, 0);
+            if constexpr (st == 3 && k == 2) v_read(1);
+            if constexpr (st == 4 && k == 0) v_write(vt, 1);
+            if constexpr (st == 5 && k == 0) __syncthreads();
+            if constexpr (st == 6 && k == 0) lstore();
+            if constexpr (st == 8 && k == 0) gload(cnext);
         };
 #define WW_STEP(XI)                                                                                                    \
         {                                                                                                              \
