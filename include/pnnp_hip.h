@@ -135,7 +135,9 @@ int64_t pnnp_wino_weight_floats(int Cout, int Cin);
 int pnnp_wino_supported(int K_read, int N_written);
 int pnnp_pack_conv_weight_wino_f32(const float* w, float* fwd /*or null*/, float* dgrad /*or null*/, int Cout, int Cin, void* stream);
 int pnnp_conv3x3_wino_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* u_fwd, const float* bias,
-                              float* y, int B, int H, int W, int Cout, int act, void* stream);
+                              const float* residual /*or null*/, float* y, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3_wino_bwd_data_res_f32(const float* g, int Cout, const float* u_dgrad, float* dx, int C1,
+                                       const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream);
 int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgrad,
                                    float* dx1, int C1, const float* mask1, int mode1, int accum1,
                                    float* dx2, int C2, const float* mask2, int mode2, int accum2,

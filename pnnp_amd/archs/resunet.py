@@ -12,6 +12,8 @@ Reference quirks kept: ``conv3x3`` attaches its ReLU as a child of nn.Conv2d, wh
 """
 from collections import OrderedDict
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -68,14 +70,23 @@ class ResUnetEngine:
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
         W = {}
+        self.WU = {}
         def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True):
             w = P[pname]
             co, ci, kh, kw = w.shape
             t = kh * kw
             f = self._buf(name + ':f', t * (cin_pad or ci) * co, dev)
             d = self._buf(name + ':d', t * (cout_pad or co) * ci, dev) if (train and dgrad) else None
-            ops.pack_conv_weight(w, f, d, cin_pad=cin_pad, cout_pad=cout_pad)
+            wf, wd = self._wino(co, ci, t)
+            wd = wd and train and dgrad
+            if not wf or (d is not None and not wd):
+                ops.pack_conv_weight(w, None if wf else f, d if not wd else None, cin_pad=cin_pad, cout_pad=cout_pad)
+            uf = self._buf(name + ':uf', 16 * co * ci, dev) if wf else None
+            ud = self._buf(name + ':ud', 16 * co * ci, dev) if wd else None
+            if wf or wd:
+                ops.pack_conv_weight_wino(w, uf, ud)
             W[name] = (f, d)
+            self.WU[name] = (uf, ud)
         conv('conv_in', 'conv_in.weight', cin_pad=self.cin_pad, dgrad=False)
         for i in range(1, 10):
             conv(f'b{i}_0', f'conv{i}.block.0.conv.conv.weight')
@@ -99,6 +110,27 @@ class ResUnetEngine:
             W[f'upv{i}'] = (f, d)
         conv('conv10', 'conv10.weight', cout_pad=self.cout_pad)
         self.W = W
+
+    @staticmethod
+    def _wino(co, ci, taps=9):
+        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  Same rule as the UNet engine."""
+        if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
+            return False, False
+        mink = int(os.environ.get('PNNP_WINO_MINK', '64'))
+        return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
+
+    def _cf(self, name, src, src2, bias, out, cout, act, residual=None):
+        """3x3 forward: Winograd kernel where packed for it, else the direct implicit GEMM."""
+        u = self.WU.get(name, (None, None))[0]
+        if u is not None:
+            return ops.conv_wino_fwd(src, src2, u, bias, out, cout, act, residual=residual)
+        return ops.conv_fwd(src, src2, self.W[name][0], bias, out, cout, 9, act, residual=residual)
+
+    def _dg(self, name, gsrc, dx1, **kw):
+        u = self.WU.get(name, (None, None))[1]
+        if u is not None:
+            return ops.conv_wino_bwd_data(gsrc, u, dx1, **kw)
+        return ops.conv_bwd_data(gsrc, self.W[name][1], dx1, **kw)
 
     def mark_dirty(self):
         """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
@@ -132,8 +164,8 @@ class ResUnetEngine:
         for l in range(1, 6):
             lv = l - 1
             shp = (B, hs[lv], ws[lv], ch[lv])
-            a[f't{l}'] = ops.conv_fwd(xin, None, W[f'b{l}_0'][0], None, g(f't{l}', shp), ch[lv], 9, RELU)
-            a[f'c{l}'] = ops.conv_fwd(a[f't{l}'], None, W[f'b{l}_1'][0], None, g(f'c{l}', shp), ch[lv], 9, 0, residual=xin)
+            a[f't{l}'] = self._cf(f'b{l}_0', xin, None, None, g(f't{l}', shp), ch[lv], RELU)
+            a[f'c{l}'] = self._cf(f'b{l}_1', a[f't{l}'], None, None, g(f'c{l}', shp), ch[lv], 0, residual=xin)
             if l < 5:
                 a[f'd{l}'] = ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
                                              g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
@@ -145,9 +177,9 @@ class ResUnetEngine:
             u = ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
             skip = a[f'c{lv + 1}']
             a[f'u{i}'] = u
-            a[f't{i}'] = ops.conv_fwd(u, skip, W[f'b{i}_0'][0], None, g(f't{i}', shp), ch[lv], 9, RELU)
+            a[f't{i}'] = self._cf(f'b{i}_0', u, skip, None, g(f't{i}', shp), ch[lv], RELU)
             sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
-            a[f'c{i}'] = ops.conv_fwd(a[f't{i}'], None, W[f'b{i}_1'][0], None, g(f'c{i}', shp), ch[lv], 9, 0, residual=sc)
+            a[f'c{i}'] = self._cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
             cur = a[f'c{i}']
         o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
@@ -172,7 +204,12 @@ class ResUnetEngine:
                 on_ready(self.params.slices[pname][0])
 
         def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
-            ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
+            c2 = x2.shape[3] if x2 is not None else 0
+            if (taps == 9 and os.environ.get('PNNP_WINO', '1') != '0' and os.environ.get('PNNP_WINO_WGRAD', '1') != '0'
+                    and gpre.shape[3] == cout and x1.shape[3] == c1 and ops.wino_wgrad_supported(gpre.shape[1], gpre.shape[2], cout, c1, c2)):
+                ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+            else:
+                ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
 
         # head
         wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
@@ -185,11 +222,11 @@ class ResUnetEngine:
             wgrad(f'conv{i}.short_cut.0.conv.conv.weight', g, ch[lv], u, ch[lv], x2=skip, taps=1)
             wgrad(f'conv{i}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
             g_t = gb(f't{i}', t)
-            ops.conv_bwd_data(g, W[f'b{i}_1'][1], g_t, mask1=t, mode1=RELU)
+            self._dg(f'b{i}_1', g, g_t, mask1=t, mode1=RELU)
             wgrad(f'conv{i}.block.0.conv.conv.weight', g_t, ch[lv], u, ch[lv], x2=skip)
             done(f'conv{i}.block.0.conv.conv.weight')
             g_u, g_skip = gb(f'u{i}', u), gb(f'c{lv + 1}', skip)
-            ops.conv_bwd_data(g_t, W[f'b{i}_0'][1], g_u, dx2=g_skip)
+            self._dg(f'b{i}_0', g_t, g_u, dx2=g_skip)
             ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
             ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc)
@@ -203,12 +240,16 @@ class ResUnetEngine:
             xin = a['t0'] if l == 1 else a[f'd{l - 1}']
             wgrad(f'conv{l}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
             g_t = gb(f't{l}', t)
-            ops.conv_bwd_data(g, W[f'b{l}_1'][1], g_t, mask1=t, mode1=RELU)
+            self._dg(f'b{l}_1', g, g_t, mask1=t, mode1=RELU)
             wgrad(f'conv{l}.block.0.conv.conv.weight', g_t, ch[lv], xin, ch[lv])
             done(f'conv{l}.block.0.conv.conv.weight')
             g_x = gb('t0' if l == 1 else f'd{l - 1}', xin)
             # identity shortcut: d/d(xin) = dgrad(block) + g ; xin = t0 is a ReLU output (mask), d_l is not
-            ops.conv_bwd_data_res(g_t, W[f'b{l}_0'][1], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+            ud = self.WU.get(f'b{l}_0', (None, None))[1]
+            if ud is not None:
+                ops.conv_wino_bwd_data_res(g_t, ud, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+            else:
+                ops.conv_bwd_data_res(g_t, W[f'b{l}_0'][1], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
             if l > 1:
                 c_prev = a[f'c{l - 1}']
                 ops.conv_s2_bwd_weight(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
@@ -227,6 +268,7 @@ class ResUnetEngine:
         need = 1024 * max(ch)
         for lv in range(5):
             h, w, c = H >> lv, W >> lv, ch[lv]
+            need = max(need, ops.wino_wgrad_workspace_floats(B, h, w, c, c), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c))
             need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9),
                        ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 1), ops.wgrad_workspace_floats(B, h, w, c, self.cin, 9))
             if lv < 4:

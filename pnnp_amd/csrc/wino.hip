@@ -269,6 +269,19 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             }
         }
     }
+    float ad[16][4];                                   // residual / shortcut-gradient term, same batching
+    if (a.addsrc) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
+            const int ty = m >> 3, tx = m & 7;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int y = min(y0 + 2 * ty + (p >> 1), a.H - 1), x = min(x0 + 2 * tx + (p & 1), a.W - 1);
+                ad[e][p] = __builtin_nontemporal_load(a.addsrc + (img + (int64_t)y * a.W + x) * dcs + nc);
+            }
+        }
+    }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
@@ -286,7 +299,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             if (y < a.H && x < a.W) {
                 const int64_t o = (img + (int64_t)y * a.W + x) * dcs + nc;
                 float v = yv[p] + bias;
-                if (a.addsrc) v += a.addsrc[o];
+                if (a.addsrc) v += ad[e][p];
                 v = act_fn(v, a.act);
                 if (mmode) v *= (mk[e][p] > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
                 if (accum) v += dst[o];
@@ -372,13 +385,13 @@ int pnnp_pack_conv_weight_wino_f32(const float* w, float* fwd, float* dgrad, int
 
 // y = act(conv3x3(cat[x1,x2]) + bias), same contract as pnnp_conv_fwd_f32 with taps = 9.
 int pnnp_conv3x3_wino_fwd_f32(const float* x1, int C1, const float* x2, int C2, const float* u_fwd, const float* bias,
-                              float* y, int B, int H, int W, int Cout, int act, void* stream) {
+                              const float* residual, float* y, int B, int H, int W, int Cout, int act, void* stream) {
     if (!x1 || !u_fwd || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 <= 0)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     WinoArgs a{};
     a.src[0] = x1; a.src_cs[0] = C1; a.src[1] = x2 ? x2 : x1; a.src_cs[1] = x2 ? C2 : C1; a.C1 = C1;
     a.K = C1 + (x2 ? C2 : 0); a.N = Cout; a.u = u_fwd; a.B = B; a.H = H; a.W = W;
-    a.dst[0] = y; a.dst[1] = y; a.dst_cs[0] = a.dst_cs[1] = Cout; a.bias = bias; a.act = act;
+    a.dst[0] = y; a.dst[1] = y; a.dst_cs[0] = a.dst_cs[1] = Cout; a.bias = bias; a.act = act; a.addsrc = residual;
     return wino_launch(a, as_stream(stream));
 }
 
@@ -398,6 +411,20 @@ int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgra
         a.n_split = C1;
         a.dst[1] = dx2; a.dst_cs[1] = C2; a.mask[1] = mask2; a.mask_mode[1] = mask2 ? mode2 : 0; a.accum[1] = accum2;
     }
+    return wino_launch(a, as_stream(stream));
+}
+
+// backward-data through an identity shortcut: dx = (conv_bwd_data(g) + addsrc) * act'(mask), same contract as
+// pnnp_conv_bwd_data_res_f32 with taps = 9.
+int pnnp_conv3x3_wino_bwd_data_res_f32(const float* g, int Cout, const float* u_dgrad, float* dx, int C1,
+                                       const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream) {
+    if (!g || !u_dgrad || !dx || !addsrc || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    WinoArgs a{};
+    a.src[0] = g; a.src[1] = g; a.src_cs[0] = a.src_cs[1] = Cout; a.C1 = Cout;
+    a.K = Cout; a.N = C1; a.u = u_dgrad; a.B = B; a.H = H; a.W = W;
+    a.dst[0] = a.dst[1] = dx; a.dst_cs[0] = a.dst_cs[1] = C1; a.addsrc = addsrc;
+    a.mask[0] = a.mask[1] = mask; a.mask_mode[0] = a.mask_mode[1] = mask ? mode : 0;
     return wino_launch(a, as_stream(stream));
 }
 

@@ -80,13 +80,13 @@ def pack_conv_weight_wino(w, fwd, dgrad):
     check(_prep().pnnp_pack_conv_weight_wino_f32(ptr(w), ptr(fwd), ptr(dgrad), co, ci, stream()), 'pack_conv_weight_wino')
 
 
-def conv_wino_fwd(x1, x2, u_fwd, bias, y, cout, act):
+def conv_wino_fwd(x1, x2, u_fwd, bias, y, cout, act, residual=None):
     """3x3 / stride 1 / pad 1 forward through the Winograd F(2x2,3x3) kernel (same contract as conv_fwd, taps=9)."""
     require_cuda(x1, x2, u_fwd, y)
     B, H, W, C1 = x1.shape
     C2 = x2.shape[3] if x2 is not None else 0
     with _Timed('conv9_fwd', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
-        check(_prep().pnnp_conv3x3_wino_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(u_fwd), ptr(bias), ptr(y), B, H, W, cout, act,
+        check(_prep().pnnp_conv3x3_wino_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(u_fwd), ptr(bias), ptr(residual), ptr(y), B, H, W, cout, act,
                                                 stream()), 'conv_wino_fwd')
     return y
 
@@ -118,6 +118,16 @@ def conv_wino_bwd_weight(g, cout, x1, c1, x2, dW, dbias, workspace, accumulate=0
         check(_prep().pnnp_conv3x3_wino_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), c2, c2, ptr(dW), ptr(dbias),
                                                        B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
               'conv_wino_bwd_weight')
+
+
+def conv_wino_bwd_data_res(g, u_dgrad, dx, addsrc, mask=None, mode=0):
+    """dx = (conv_bwd_data(g) + addsrc) * act'(mask) through the Winograd kernel."""
+    require_cuda(g, u_dgrad, dx, addsrc)
+    B, H, W, Cout = g.shape
+    C1 = dx.shape[3]
+    with _Timed('conv9_dgrad', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
+        check(_prep().pnnp_conv3x3_wino_bwd_data_res_f32(ptr(g), Cout, ptr(u_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
+                                                         B, H, W, stream()), 'conv_wino_bwd_data_res')
 
 
 def conv_bwd_data_res(g, w_dgrad, dx, addsrc, mask=None, mode=0, taps=9):

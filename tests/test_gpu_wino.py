@@ -104,3 +104,23 @@ def test_wino_bwd_weight_unsupported():
     from pnnp_amd import ops
     assert not ops.wino_wgrad_supported(6, 8, 64, 64) and not ops.wino_wgrad_supported(8, 12, 64, 64)
     assert not ops.wino_wgrad_supported(8, 8, 32, 64) and not ops.wino_wgrad_supported(8, 8, 64, 64, 32)
+
+
+def test_wino_residual_and_shortcut_gradient():
+    """ResidualBlock forms (archs/modules.py:176-197): forward y = conv(x) + residual; backward through the identity
+    shortcut dx = (conv_bwd_data(g) + g_skip) * relu'(saved)."""
+    from pnnp_amd import ops
+    B, H, W, C = 2, 20, 24, 64
+    x = _rand(B, C, H, W, seed=1); r = _rand(B, C, H, W, seed=2); w = _rand(C, C, 3, 3, seed=3, scale=0.2)
+    uf = torch.empty(16 * C * C, device='cuda'); ud = torch.empty(16 * C * C, device='cuda')
+    ops.pack_conv_weight_wino(w.cuda(), uf, ud)
+    y = torch.full((B, H, W, C), float('nan'), device='cuda')
+    ops.conv_wino_fwd(nhwc(x).cuda(), None, uf, None, y, C, 0, residual=nhwc(r).cuda())
+    close(nchw(y), F.conv2d(x, w, None, padding=1) + r, rtol=2e-4, atol=2e-5, what='wino fwd + residual')
+    g = _rand(B, C, H, W, seed=5); gs = _rand(B, C, H, W, seed=6); saved = _rand(B, C, H, W, seed=7)
+    ref = (F.conv_transpose2d(g, w, padding=1) + gs) * (saved > 0).float()
+    dx = torch.full((B, H, W, C), float('nan'), device='cuda')
+    ops.conv_wino_bwd_data_res(nhwc(g).cuda(), ud, dx, addsrc=nhwc(gs).cuda(), mask=nhwc(saved).cuda(), mode=2)
+    close(nchw(dx), ref, rtol=2e-4, atol=2e-5, what='wino dgrad + shortcut')
+    ops.conv_wino_bwd_data_res(nhwc(g).cuda(), ud, dx, addsrc=nhwc(gs).cuda())
+    close(nchw(dx), F.conv_transpose2d(g, w, padding=1) + gs, rtol=2e-4, atol=2e-5, what='wino dgrad + shortcut, no mask')
