@@ -162,19 +162,32 @@ def main():
             for kind, fl, by, e0, e1 in prof:
                 c = classes.setdefault(kind, [0, 0.0, 0.0, 0.0])
                 c[0] += 1; c[1] += fl; c[2] += by; c[3] += e0.elapsed_time(e1) * 1e-3
-            dom = [k for k in classes if k.startswith('conv9_fwd') or k.startswith('conv9_dgrad')]
+            # dominant kernel = the one with the largest share of the step: wino_kernel (Winograd F(2x2,3x3) conv3x3
+            # forward + backward-data) when the engine uses it, else the direct implicit-GEMM igemm_kernel<9,...>
+            wino = [k for k in classes if k in ('conv9_fwd_wino', 'conv9_dgrad_wino')]
+            direct = [k for k in classes if k in ('conv9_fwd', 'conv9_dgrad')]
+            t_of = lambda ks: sum(classes[k][3] for k in ks)
+            use_wino = bool(wino) and t_of(wino) >= t_of(direct)
+            dom = wino if use_wino else direct
             n = sum(classes[k][0] for k in dom); fl = sum(classes[k][1] for k in dom); sec = sum(classes[k][3] for k in dom)
             traffic = None     # HBM bytes per launch from the PMC passes of this command (tools/traffic_from_pmc.py)
             tj = os.path.join(REPO, 'profiles', 'traffic.json')
             if os.path.exists(tj) and args.arch == 'unet' and args.noise == 'physics' and B == 16 and S == 512:
-                traffic = json.load(open(tj)).get('igemm9', {}).get('hbm_bytes_per_launch')
+                traffic = json.load(open(tj)).get('wino' if use_wino else 'igemm9', {}).get('hbm_bytes_per_launch')
             by = sum(classes[k][2] for k in dom)
             out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                                "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                                "alg_bytes_per_launch": by / n,
-                               "kernel": "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
+                               "kernel": ("wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3): 16 instead of 36 MFMA "
+                                          "multiply-adds per 2x2 outputs, v_mfma_f32_32x32x2_f32)") if use_wino else
+                                         "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "alg_gflop_per_launch": fl / n / 1e9}
+            if use_wino:       # `achieved` counts the layer's ALGORITHMIC flops; the matrix pipe executes 16/36 of them
+                out["roofline"]["mfma_executed_tflops"] = fl / sec / 1e12 * 16.0 / 36.0
+            conv9 = [k for k in classes if k.startswith('conv9_')]
+            out["conv3x3_all"] = {"launches": sum(classes[k][0] for k in conv9), "ms_per_step": 1e3 * t_of(conv9) / args.steps,
+                                  "tflops": sum(classes[k][1] for k in conv9) / t_of(conv9) / 1e12}
             out["kernel_classes"] = {k: {"launches": v[0], "ms_per_step": 1e3 * v[3] / args.steps,
                                          "tflops": (v[1] / v[3] / 1e12) if v[3] > 0 else None} for k, v in sorted(classes.items())}
             out["mfma_time_frac_of_step"] = sum(v[3] for v in classes.values()) / dt

@@ -85,7 +85,7 @@ def conv_wino_fwd(x1, x2, u_fwd, bias, y, cout, act, residual=None):
     require_cuda(x1, x2, u_fwd, y)
     B, H, W, C1 = x1.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    with _Timed('conv9_fwd', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+    with _Timed('conv9_fwd_wino', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
         check(_prep().pnnp_conv3x3_wino_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(u_fwd), ptr(bias), ptr(residual), ptr(y), B, H, W, cout, act,
                                                 stream()), 'conv_wino_fwd')
     return y
@@ -96,7 +96,7 @@ def conv_wino_bwd_data(g, u_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None,
     B, H, W, Cout = g.shape
     C1 = dx1.shape[3]
     C2 = dx2.shape[3] if dx2 is not None else 0
-    with _Timed('conv9_dgrad', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
+    with _Timed('conv9_dgrad_wino', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
         check(_prep().pnnp_conv3x3_wino_bwd_data_f32(ptr(g), Cout, ptr(u_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
                                                      ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv_wino_bwd_data')
 
@@ -114,7 +114,7 @@ def conv_wino_bwd_weight(g, cout, x1, c1, x2, dW, dbias, workspace, accumulate=0
     require_cuda(g, x1, dW, workspace)
     B, H, W, gcs = g.shape
     c2 = x2.shape[3] if x2 is not None else 0
-    with _Timed('conv9_wgrad', 2.0 * B * H * W * cout * (c1 + c2) * 9, 4.0 * B * H * W * (gcs + x1.shape[3] + c2)):
+    with _Timed('conv9_wgrad_wino', 2.0 * B * H * W * cout * (c1 + c2) * 9, 4.0 * B * H * W * (gcs + x1.shape[3] + c2)):
         check(_prep().pnnp_conv3x3_wino_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), c2, c2, ptr(dW), ptr(dbias),
                                                        B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
               'conv_wino_bwd_weight')
@@ -125,7 +125,7 @@ def conv_wino_bwd_data_res(g, u_dgrad, dx, addsrc, mask=None, mode=0):
     require_cuda(g, u_dgrad, dx, addsrc)
     B, H, W, Cout = g.shape
     C1 = dx.shape[3]
-    with _Timed('conv9_dgrad', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
+    with _Timed('conv9_dgrad_wino', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
         check(_prep().pnnp_conv3x3_wino_bwd_data_res_f32(ptr(g), Cout, ptr(u_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
                                                          B, H, W, stream()), 'conv_wino_bwd_data_res')
 
