@@ -218,6 +218,12 @@ int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
 
+/* SNA_torch (data_process/process.py:562-588): shot-noise augmentation under a white-balance gain change.
+ * gt [C][H][W] -> dn (the extra Poisson noise, / (wp-bl), x ratio unless ori) and dy (the signal change); aug_wb4 is a
+ * HOST array of the four plane gains.  Counter-based RNG as in pnnp_noise_sample_f32. */
+int pnnp_sna_f32(const float* gt, float* dn, float* dy, int C, int H, int W, const float* aug_wb4, float K, float wp, float bl,
+                 float ratio, int black_lr, int ori, uint64_t seed, uint64_t offset, uint32_t crop, void* stream);
+
 /* ---------------------------------------------------------------- dataset-side crop / augment
  * init_random_crop_point + random_crop + data_aug (data_process/syn_datasets.py:69-107,162-173; the 4-way
  * variant real_datasets.py:98-137), fused behind raw2bayer (utils/isp_ops.py:84-96), the linear dark-shading

@@ -79,6 +79,16 @@ def noise_sample(y, params, flags, mfm=1.0, seed=0, offset=0, crop_base=0):
     return out
 
 
+def sna(gt, aug, K, wp, bl, ratio, black_lr, ori, seed=0, offset=0, crop=0):
+    gt = np.ascontiguousarray(gt, np.float32)
+    Cc, H, W = gt.shape
+    dn = np.empty_like(gt); dy = np.empty_like(gt)
+    a = np.ascontiguousarray(aug, np.float32)
+    lib().pnnp_oracle_sna(_p(gt), _p(dn), _p(dy), Cc, H, W, _p(a), C.c_float(K), C.c_float(wp), C.c_float(bl), C.c_float(ratio),
+                          int(black_lr), int(ori), C.c_uint64(seed), C.c_uint64(offset), C.c_uint32(crop))
+    return dn, dy
+
+
 def philox(ctr, key):
     c = np.asarray(ctr, np.uint32); k = np.asarray(key, np.uint32); o = np.zeros(4, np.uint32)
     lib().pnnp_oracle_philox(_p(c), _p(k), _p(o))

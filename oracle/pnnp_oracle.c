@@ -127,6 +127,29 @@ static float tukey(float u, float lam) {
     return (expm1f(lam * lu) - expm1f(lam * l1u)) / lam;
 }
 
+/* SNA_torch (data_process/process.py:562-588) with the HIP kernel's counter RNG; mirrors pnnp_sna_f32. */
+void pnnp_oracle_sna(const float* gt, float* dn, float* dy, int C, int H, int W, const float* aug, float K, float wp, float bl,
+                     float ratio, int black_lr, int ori, uint64_t seed, uint64_t offset, uint32_t crop) {
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), off = (uint32_t)offset;
+    const ctx_t cx = {k0, k1, crop, off};
+    const float span = wp - bl;
+    const long plane = (long)H * W, total = (long)C * plane;
+    for (long t = 0; t < total; ++t) {
+        const int c = (int)(t / plane) & 3;
+        const uint32_t elem = (uint32_t)t;
+        const u4 r = philox(elem, crop, 0x20000000u, off, k0, k1);
+        volatile float g = gt[t] * span; g = g / ratio;
+        volatile float y = g * aug[c];
+        volatile float lam = y / K;
+        volatile float n = poisson(lam, elem, &cx, r.v[0], r.v[1]) * K;
+        if (black_lr) y = y - g;
+        y = y * ratio; y = y / span;
+        n = n / span;
+        if (!ori) n = n * ratio;
+        dn[t] = n; dy[t] = y;
+    }
+}
+
 /* y, out: [B][C][H][W]; params: [B][NPARAM].  Mirrors pnnp_noise_sample_f32 (include/pnnp_hip.h). */
 void pnnp_oracle_noise_sample(const float* y, float* out, int B, int C, int H, int W, const float* params,
                               unsigned flags, float mfm, uint64_t seed, uint64_t offset, uint32_t crop_base) {

@@ -200,6 +200,46 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
 
 }  // namespace
 
+// SNA_torch (data_process/process.py:562-588): shot-noise augmentation of a paired crop under a white-balance gain
+// change.  Per pixel of plane c:  g = gt*(wp-bl)/ratio;  dy = g*aug[c];  dn = Poisson(dy/K)*K;  if black_lr dy -= g;
+// dy = dy*ratio/(wp-bl);  dn = dn/(wp-bl);  if !ori dn *= ratio.   gt, dn, dy: [C][H][W] (C = 4 planes R,G1,B,G2).
+__global__ void __launch_bounds__(256)
+sna_kernel(const float* __restrict__ gt, float* __restrict__ dn, float* __restrict__ dy, int C, int64_t plane,
+           float a0, float a1, float a2, float a3, float K, float span, float ratio, int black_lr, int ori,
+           uint32_t k0, uint32_t k1, uint32_t off, uint32_t crop) {
+    const int64_t total = (int64_t)C * plane;
+    const Ctx ctx{k0, k1, crop, off};
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t / plane) & 3;
+        const float aug = c == 0 ? a0 : (c == 1 ? a1 : (c == 2 ? a2 : a3));
+        const uint32_t elem = (uint32_t)t;
+        const uint4 r = philox4x32_10(elem, crop, 0x20000000u, off, k0, k1);
+        const float g = __fdiv_rn(__fmul_rn(gt[t], span), ratio);
+        float y = __fmul_rn(g, aug);
+        float n = __fmul_rn(poisson_f32(__fdiv_rn(y, K), elem, ctx, r.x, r.y), K);
+        if (black_lr) y = __fsub_rn(y, g);
+        y = __fdiv_rn(__fmul_rn(y, ratio), span);
+        n = __fdiv_rn(n, span);
+        if (!ori) n = __fmul_rn(n, ratio);
+        dn[t] = n; dy[t] = y;
+    }
+}
+
+extern "C" int pnnp_sna_f32(const float* gt, float* dn, float* dy, int C, int H, int W, const float* aug_wb4 /* host */,
+                            float K, float wp, float bl, float ratio, int black_lr, int ori, uint64_t seed, uint64_t offset,
+                            uint32_t crop, void* stream) {
+    if (!gt || !dn || !dy || !aug_wb4 || C < 0 || H < 0 || W < 0 || !(K > 0.f) || !(ratio > 0.f)) return PNNP_E_INVALID;
+    const int64_t plane = (int64_t)H * W, total = (int64_t)C * plane;
+    if (total == 0) return PNNP_OK;
+    if (total >= (1ll << 32)) return PNNP_E_INVALID;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
+    hipLaunchKernelGGL(sna_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), gt, dn, dy, C, plane,
+                       aug_wb4[0], aug_wb4[1], aug_wb4[2], aug_wb4[3], K, wp - bl, ratio, black_lr, ori, k0, k1, (uint32_t)offset, crop);
+    return pnnp_launch_status();
+}
+
 extern "C" int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, int H, int W,
                                      const float* params, unsigned flags, float mfm, uint64_t seed,
                                      uint64_t offset, uint32_t crop_base, void* stream) {

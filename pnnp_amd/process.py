@@ -310,6 +310,31 @@ def generate_noisy_torch(y, camera_type=None, noise_code='p', param=None, MultiF
     return out[0] if squeeze else out
 
 
+def SNA_torch(gt, aug_wb, camera_type='IMX686', ratio=1, black_lr=False, ori=True, iso=None):
+    """process.py:562-588 (shot-noise augmentation, the Mix_Dataset branch of Trainer.preprocess, trainer_SID.py:429-447)
+    on the HIP sampler: gt [4,H,W] CUDA, aug_wb the four plane gains -> (dn, dy).  The gain draw K uses numpy's
+    global RNG exactly like the reference; the Poisson draw uses the library's counter RNG (statistical parity)."""
+    p = get_specific_noise_params(camera_type=camera_type, iso=iso)
+    if p is None:
+        assert camera_type == 'SonyA7S2'
+        camera_type += '_lowISO' if iso <= 1600 else '_highISO'
+        p = get_camera_noisy_params(camera_type=camera_type)
+        p['K'] = 0.0009546 * iso * (1 + np.random.uniform(low=-0.01, high=+0.01)) - 0.00193
+    else:
+        p['K'] = p['Kmax'] * (1 + np.random.uniform(low=-0.01, high=+0.01))
+    _lib.require_cuda(gt)
+    g = gt.contiguous().float()
+    Cc, H, W = g.shape
+    dn = torch.empty_like(g); dy = torch.empty_like(g)
+    aug = (C.c_float * 4)(*[float(v) for v in np.asarray(aug_wb, np.float32).reshape(-1)[:4]])
+    off = _RngState.offset
+    _RngState.offset += 1
+    _lib.check(_lib.lib().pnnp_sna_f32(_lib.ptr(g), _lib.ptr(dn), _lib.ptr(dy), Cc, H, W, aug, C.c_float(float(p['K'])),
+                                       C.c_float(float(p['wp'])), C.c_float(float(p['bl'])), C.c_float(float(ratio)), int(bool(black_lr)),
+                                       int(bool(ori)), C.c_uint64(_RngState.seed), C.c_uint64(off), C.c_uint32(0), _lib.stream()), 'sna')
+    return dn, dy
+
+
 def generate_noisy_obs(y, camera_type=None, wp=16383, noise_code='p', param=None, MultiFrameMean=1, ori=False, clip=False):
     """process.py:591-631 on the HIP sampler.  numpy in -> numpy out (staged through the
     GPU); CUDA tensor in -> CUDA tensor out."""

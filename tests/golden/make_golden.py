@@ -382,6 +382,29 @@ def gen_noiseflow():
     np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
 
 
+def gen_sna(proc):
+    """SNA_torch (process.py:562-588): K draw under np.random.seed, the deterministic signal term dy, moments of dn."""
+    import torch
+    out, meta = {}, {}
+    rng = np.random.RandomState(21)
+    gt = (rng.rand(4, 96, 128).astype(np.float32) ** 2) * 0.2
+    out['gt'] = gt
+    for tag, kw in (('imx', dict(camera_type='IMX686', ratio=4.0, black_lr=False, ori=True, iso=6400)),
+                    ('imx_black', dict(camera_type='IMX686', ratio=2.0, black_lr=True, ori=False, iso=100)),
+                    ('sony', dict(camera_type='SonyA7S2', ratio=100.0, black_lr=False, ori=False, iso=1600))):
+        aug = np.array([0.3, 0.0, 0.15, 0.0], np.float32) + (1 if kw['black_lr'] else 0)
+        np.random.seed(9); torch.manual_seed(9)
+        dn, dy = proc.SNA_torch(torch.from_numpy(gt), aug.copy(), **kw)
+        np.random.seed(9)
+        p = proc.get_specific_noise_params(camera_type=kw['camera_type'], iso=kw['iso'])
+        K = p['Kmax'] * (1 + np.random.uniform(low=-0.01, high=+0.01))
+        meta[tag] = dict(kw, aug=[float(v) for v in aug], K=float(K), wp=int(p['wp']), bl=int(p['bl']),
+                         dn_mean=[float(v) for v in dn.numpy().reshape(4, -1).mean(1)], dn_var=[float(v) for v in dn.numpy().reshape(4, -1).var(1)])
+        out[tag + '_dy'] = dy.numpy()
+    np.savez_compressed(os.path.join(HERE, 'sna.npz'), **out)
+    json.dump(meta, open(os.path.join(HERE, 'sna.json'), 'w'), indent=1)
+
+
 def gen_augment(data_process, isp):
     """Rows f2/f3: crop points + 8-/4-way augmentation + WB gains + dark shading, as the datasets do them
     (syn_datasets.py:69-107,162-173,296-322; real_datasets.py:98-137,360-372)."""
@@ -448,7 +471,7 @@ def gen_augment(data_process, isp):
 
 def main():
     archs, proc, isp, losses, data_process, base_trainer = import_reference()
-    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment']
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment', 'sna']
     if 'pack' in which: gen_pack(isp)
     if 'params' in which: gen_params(proc)
     if 'noise' in which: gen_noise(proc)
@@ -456,6 +479,7 @@ def main():
     if 'misc' in which: gen_misc(base_trainer, losses, data_process)
     if 'noiseflow' in which: gen_noiseflow()
     if 'augment' in which: gen_augment(data_process, isp)
+    if 'sna' in which: gen_sna(proc)
     print('golden fixtures written to', HERE)
 
 
