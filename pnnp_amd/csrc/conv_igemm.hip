@@ -328,9 +328,20 @@ int kc_cap() {
     return cap;
 }
 
+int kc1() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PNNP_KC1"); v = e ? atoi(e) : 16; if (v != 8 && v != 16 && v != 32) v = 16; }
+    return v;
+}
+
 int pick_bn(int ntot) { return ntot >= 128 ? 128 : (ntot >= 64 ? 64 : 32); }
 
-int pick_kc(int bn, int chan) {
+int pick_kc(int bn, int chan, int taps = 9) {
+    if (taps == 1) {                 // 1x1: the weight tile is 9x smaller, so a chunk can carry 4x the channels
+        int kc = kc1();              // (16 MFMAs per chunk and wave at KC = 8 drown in barriers and staging)
+        while (kc > 8 && (chan % kc)) kc >>= 1;
+        return kc;
+    }
     // weight tile <= 36 KB and at most 16 channels per chunk: ~40 KB of LDS per workgroup keeps
     // 3-4 workgroups resident per CU
     int kc = 1024 / bn;
@@ -345,8 +356,16 @@ int pick_kc(int bn, int chan) {
 template <int TAPS>
 int launch_taps(const IgemmArgs& a, int kc_chan, hipStream_t s) {
     const int bn = pick_bn(a.Ntot);
-    const int kc = pick_kc(bn, kc_chan);
+    const int kc = pick_kc(bn, kc_chan, TAPS);
     if (kc_chan % kc) return PNNP_E_UNSUPPORTED;
+    if constexpr (TAPS == 1) {
+        if (kc == 32) {
+            if (bn == 32) return launch_cfg<TAPS, 32, 32, 2, 1, 4, 1>(a, s);
+            if (bn == 64) return launch_cfg<TAPS, 32, 64, 2, 2, 4, 1>(a, s);
+            return launch_cfg<TAPS, 32, 128, 2, 2, 2, 2>(a, s);
+        }
+        if (kc == 16 && bn == 128) return launch_cfg<TAPS, 16, 128, 2, 2, 2, 2>(a, s);
+    }
     if (bn == 32) {
         if (kc == 16) return launch_cfg<TAPS, 16, 32, 2, 1, 4, 1>(a, s);
         return launch_cfg<TAPS, 8, 32, 2, 1, 4, 1>(a, s);
@@ -374,7 +393,7 @@ int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_
     IgemmArgs b = a;
     static const int stagger_mode = env_int("PNNP_STAGGER", 0), stagger_n = env_int("PNNP_STAGGER_N", 2);
     b.stagger_mode = stagger_mode; b.stagger_n = stagger_n;
-    const int kc = pick_kc(pick_bn(a.Ntot), chan_per_seg);
+    const int kc = pick_kc(pick_bn(a.Ntot), chan_per_seg, taps);
     b.chunks_per_seg = chan_per_seg / kc;
     if (taps == 9) return launch_taps<9>(b, chan_per_seg, s);
     if (taps == 1) return launch_taps<1>(b, chan_per_seg, s);
