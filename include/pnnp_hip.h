@@ -217,6 +217,10 @@ int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, 
 int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
+/* One [Conv2d1x1, AffineCoupling] pair of the forward (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130);
+ * partial [B][ceil(H/32)*ceil(W/32)] receives the per-workgroup sums of the pixel-wise log-det terms. */
+int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H, int W, const float* step /*[host]*/,
+                         const float* clean, float sdn_a, float sdn_b, void* stream);
 
 /* SNA_torch (data_process/process.py:562-588): shot-noise augmentation under a white-balance gain change.
  * gt [C][H][W] -> dn (the extra Poisson noise, / (wp-bl), x ratio unless ori) and dy (the signal change); aug_wb4 is a

@@ -100,3 +100,46 @@ def sample(sd, clean, iso, z):
         else:
             x = x * sdn_scale(sd, clean, iso)
     return x
+
+
+# ---------------------------------------------------------------- density direction (row f4)
+def conv1x1_matrix(sd, k):
+    """W = P L U (conv2d1x1.py:58-65)."""
+    l_mask = torch.tril(torch.ones(4, 4), -1)
+    l = sd[f'model.{k}.l'] * l_mask + torch.eye(4)
+    u = sd[f'model.{k}.u'] * l_mask.t() + torch.diag(sd[f'model.{k}.sign_s'] * torch.exp(sd[f'model.{k}.log_s']))
+    return torch.matmul(sd[f'model.{k}.p'], torch.matmul(l, u))
+
+
+def forward(sd, noise, clean, iso):
+    """noise_flow.py:113-130: x -> z and the summed log|det J| of the chain (eval-mode BatchNorm).
+    Quirk kept: Conv2d1x1's log-det is sum(log_s) * W * W (`pixels*pixels`, conv2d1x1.py:49,65: square inputs assumed)."""
+    z = noise
+    obj = torch.zeros(noise.shape[0], dtype=torch.float32)
+    for k in range(18):
+        if k in CONV_IDX:
+            z = F.conv2d(z, conv1x1_matrix(sd, k).view(4, 4, 1, 1))
+            obj = obj + sd[f'model.{k}.log_s'].sum() * noise.shape[-1] * noise.shape[-1]
+        elif k in COUPLING_IDX:
+            z0, z1 = z[:, :2], z[:, 2:]
+            shift, log_scale = shift_and_log_scale(sd, k, z0)
+            z = torch.cat([z0, z1 * torch.exp(log_scale) + shift], dim=1)
+            obj = obj + log_scale.sum(dim=[1, 2, 3])
+        elif k == 9:
+            scale = gain_scale(sd, iso) + z * 0.0
+            z = z / scale
+            obj = obj - torch.log(scale).sum(dim=[1, 2, 3])
+        else:
+            scale = sdn_scale(sd, clean, iso)
+            z = z / scale
+            obj = obj - torch.log(scale).sum(dim=[1, 2, 3])
+    return z, obj
+
+
+def loss(sd, noise, clean, iso):
+    """noise_flow.py:132-165: (mean NLL per dimension, mean std of the noise)."""
+    z, obj = forward(sd, noise, clean, iso)
+    log_z = (-0.5 * (np.log(2 * np.pi) + z ** 2)).sum(dim=[1, 2, 3])
+    nll = -(obj + log_z)
+    sd_z = torch.sqrt(torch.var(noise, dim=[1, 2, 3])).mean()
+    return nll.mean() / np.prod(noise.shape[1:]), sd_z

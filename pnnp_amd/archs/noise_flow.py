@@ -37,6 +37,13 @@ class Conv2d1x1(nn.Module):                       # flow_layers/conv2d1x1.py:19-
         self.log_s = nn.Parameter(torch.tensor(np.log(np.abs(s)).astype(np.float32)))
         self.u = nn.Parameter(torch.tensor(np.triu(u, k=1).astype(np.float32)))
 
+    def matrix(self):
+        """conv2d1x1.py:58-65: W = P L U (forward direction)."""
+        mask = torch.tril(torch.ones(4, 4), -1)
+        l = self.l.detach().cpu() * mask + torch.eye(4)
+        u = self.u.detach().cpu() * mask.t() + torch.diag(self.sign_s.cpu() * torch.exp(self.log_s.detach().cpu()))
+        return torch.matmul(self.p.cpu(), torch.matmul(l, u))
+
     def inverse_matrix(self):
         """conv2d1x1.py:66-74: U^-1 L^-1 P^-1 with float64 inverses (host side, 4x4)."""
         mask = torch.tril(torch.ones(4, 4), -1)
@@ -167,16 +174,72 @@ class NoiseFlow(nn.Module):
 
     # ------------------------------------------------------------------ API
     def forward(self, **kwargs):
+        """noise_flow.py:113-130.  mode 'sample' / 'loss' / 'inverse' dispatch like the reference; the default is the
+        density direction: kwargs noise [B,4,H,W] (CUDA), clean, iso -> (z, sum of log|det J| per crop).
+        BatchNorm runs with its running statistics (eval mode); gradients are not produced (NLL *evaluation*)."""
         mode = kwargs.get('mode', 'forward')
         if mode == 'sample':
             return self.sample(**kwargs)
-        raise NotImplementedError('only NoiseFlow.sample runs on the HIP path (NLL fitting is out of scope)')
+        if mode == 'loss':
+            return self.loss(**kwargs)
+        if mode == 'inverse':
+            return self.inverse(**kwargs)
+        x = kwargs['noise']
+        _lib.require_cuda(x)
+        x = x.contiguous().float()
+        clean = kwargs['clean'].contiguous().float() if kwargs.get('clean') is not None else None
+        iso = float(kwargs['iso'])
+        B, Cc, H, W = x.shape
+        L = _lib.lib()
+        nblk = ((H + 31) // 32) * ((W + 31) // 32)
+        partial = torch.zeros((8, B, nblk), dtype=torch.float32, device=x.device)
+        scalar = 0.0                                   # log-det terms that do not depend on the pixel
+        cur, nxt = x.clone(), torch.empty_like(x)
+        plan = self._plan()[::-1]                      # forward order: pairs from the data side to the prior side
+        tables = self._tables()[::-1]
+        for k, ((vec, _winv, g_after, s_after), (ac, cv, _g, _s)) in enumerate(zip(tables, plan)):
+            w = cv.matrix().numpy().astype(np.float32)
+            scalar += float(cv.log_s.detach().sum()) * W * W          # conv2d1x1.py:49,65 `pixels*pixels` (square inputs assumed)
+            # in the forward chain the layer that FOLLOWS this pair in the reversed plan precedes it here:
+            # SignalDependantISO before the first pair, GainISO before the fifth (both stored on the previous reversed entry)
+            a = b = np.float32(0.0); cl = None
+            if s_after is not None:
+                cam = _interp(s_after.cam_param.detach().cpu().numpy(), iso)
+                beta1 = np.exp(np.float32(s_after.beta1.item()) * cam[0]); beta2 = np.exp(np.float32(s_after.beta2.item()) * cam[1])
+                gain = np.exp(np.float32(s_after.gain.item()) * cam[2]) * np.float32(iso)
+                a, b, cl = np.float32(beta1 / gain), np.float32(beta2), clean
+                if cl is None:
+                    raise PnnpError("NoiseFlow.forward needs 'clean' for the signal-dependent layer")
+                if float(a) * float(clean.min()) + float(b) < 0:
+                    raise AssertionError('scale must be non-negative')      # signal_dependant.py:50
+            if g_after is not None:
+                gs = np.float32(np.exp(_interp(g_after.cam_param.detach().cpu().numpy(), iso) * np.float32(g_after.gain_params.item())) * np.float32(iso))
+                w = w / gs                                 # z = x / scale, then W: folded
+                scalar -= float(np.log(gs)) * Cc * H * W   # gain.py:101-108
+            vec = vec.copy(); vec[301:317] = w.reshape(-1)
+            buf = (C.c_float * 317)(*vec.tolist())
+            _lib.check(L.pnnp_nf_fwd_step_f32(_lib.ptr(cur), _lib.ptr(nxt), _lib.ptr(partial[k]), B, H, W, buf, _lib.ptr(cl),
+                                              C.c_float(a), C.c_float(b), _lib.stream()), 'nf_fwd_step')
+            cur, nxt = nxt, cur
+        objective = partial.double().sum(dim=(0, 2)).float() + scalar
+        return cur, objective
 
     def loss(self, **kwargs):
-        raise NotImplementedError('NoiseFlow.loss (NLL fitting) is out of scope of the HIP hot path')
+        """noise_flow.py:132-165: (mean NLL per dimension, mean per-crop std of the noise); evaluation only."""
+        x = kwargs['noise']
+        kw = dict(kwargs); kw['mode'] = 'forward'
+        z, objective = self.forward(**kw)
+        log_z = (-0.5 * (np.log(2 * np.pi) + z.double() ** 2)).sum(dim=[1, 2, 3])        # prior N(0, I), noise_flow.py:190-219
+        nll = -(objective.double() + log_z)
+        sd_z = torch.sqrt(torch.var(x.float(), dim=[1, 2, 3])).mean()
+        return (nll.mean() / float(np.prod(x.shape[1:]))).float(), sd_z
 
     def inverse(self, **kwargs):
-        raise NotImplementedError('NoiseFlow.inverse is out of scope of the HIP hot path')
+        """noise_flow.py:167-171: the reversed chain applied to ``noise`` (= sample() with that tensor as the draw)."""
+        kw = dict(kwargs); kw['z'] = kwargs['noise']
+        if 'clean' not in kw:
+            raise PnnpError("NoiseFlow.inverse needs 'clean' for the signal-dependent layer")
+        return self.sample(**kw)
 
     def sample(self, **kwargs):
         """noise_flow.py:173-188.  kwargs: clean [B,4,H,W] (CUDA), iso (scalar / 0-dim tensor);

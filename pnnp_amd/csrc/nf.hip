@@ -134,6 +134,111 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
     }
 }
 
+// Density direction (NoiseFlow.forward, archs/noise_flow.py:113-130): one [Conv2d1x1, AffineCoupling] pair of the forward
+// chain on x [B][4][H][W] -> y, and the per-workgroup partial sums of its pixel-wise log-det terms.
+//   x' = x / sqrt(sdn_a*clean + sdn_b)   (SignalDependantISO forward, first pair only; its log-det is -sum log scale)
+//   v  = W x'                            (p.winv holds W = P L U here, with 1/gain folded in after GainISO)
+//   z0 = v[0:2];  z1 = v[2:4] * exp(log_scale(z0)) + shift(z0)        (affine_coupling.py:36-53)
+//   partial[b][block] = sum over the block's pixels of (log_scale_a + log_scale_b - sum_c log scale_c)
+__global__ void __launch_bounds__(256)
+nf_fwd_step_kernel(const float* __restrict__ x, float* __restrict__ y, float* __restrict__ partial, int H, int W, const NfStep p,
+                   const float* __restrict__ clean, float sdn_a, float sdn_b) {
+    __shared__ float z0s[2][ZW][ZW + 1];
+    __shared__ float hs[4][HW_][HW_ + 1];
+    __shared__ float red[256];
+    const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
+    const int64_t plane = (int64_t)H * W;
+    const float* xb = x + (int64_t)b * 4 * plane;
+    const float* cb = clean ? clean + (int64_t)b * 4 * plane : nullptr;
+    // v0, v1 = rows 0,1 of W applied to x' on the tile + halo 2; zero outside the image (conv2d_1 pads with zeros)
+    for (int i = threadIdx.x; i < ZW * ZW; i += 256) {
+        const int r = i / ZW, q = i % ZW;
+        const int gy = ty0 + r - 2, gx = tx0 + q - 2;
+        float v0 = 0.f, v1 = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const int64_t pix = (int64_t)gy * W + gx;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                float xv = xb[c * plane + pix];
+                if (cb) xv = xv / sqrtf(sdn_a * cb[c * plane + pix] + sdn_b);
+                v0 += p.winv[0][c] * xv; v1 += p.winv[1][c] * xv;
+            }
+        }
+        z0s[0][r][q] = v0; z0s[1][r][q] = v1;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HW_ * HW_; i += 256) {
+        const int r = i / HW_, q = i % HW_;
+        const int gy = ty0 + r - 1, gx = tx0 + q - 1;
+        float h2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float h1[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = p.b1[o];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) s += p.w1[o][c][t] * z0s[c][r + t / 3][q + t % 3];
+                h1[o] = fmaxf(p.s1[o] * s + p.o1[o], 0.f);
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                float s = p.b2[o];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += p.w2[o][c] * h1[c];
+                h2[o] = fmaxf(p.s2[o] * s + p.o2[o], 0.f);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) hs[o][r][q] = h2[o];
+    }
+    __syncthreads();
+    float ld = 0.f;
+    for (int i = threadIdx.x; i < TS * TS; i += 256) {
+        const int r = i / TS, q = i % TS;
+        const int gy = ty0 + r, gx = tx0 + q;
+        if (gy >= H || gx >= W) continue;
+        float o3[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            float s = p.b3[o];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) s += p.w3[o][c][t] * hs[c][r + t / 3][q + t % 3];
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) s += p.w3[o][4][t];
+            }
+            o3[o] = s * p.e3[o];
+        }
+        const int64_t pix = (int64_t)gy * W + gx;
+        float v2 = 0.f, v3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float xv = xb[c * plane + pix];
+            if (cb) {
+                const float sc = sqrtf(sdn_a * cb[c * plane + pix] + sdn_b);
+                xv = xv / sc;
+                ld -= logf(sc);
+            }
+            v2 += p.winv[2][c] * xv; v3 += p.winv[3][c] * xv;
+        }
+        const float lsa = p.scale * tanhf(o3[2]), lsb = p.scale * tanhf(o3[3]);
+        ld += lsa + lsb;
+        float* yb = y + (int64_t)b * 4 * plane + pix;
+        yb[0] = z0s[0][r + 2][q + 2]; yb[plane] = z0s[1][r + 2][q + 2];
+        yb[2 * plane] = v2 * expf(lsa) + o3[0]; yb[3 * plane] = v3 * expf(lsb) + o3[1];
+    }
+    red[threadIdx.x] = ld;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (threadIdx.x < k) red[threadIdx.x] += red[threadIdx.x + k];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[((int64_t)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = red[0];
+}
+
 }  // namespace
 
 extern "C" {
@@ -162,6 +267,20 @@ int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float*
     memcpy(&p, step, sizeof p);
     hipLaunchKernelGGL(nf_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
                        x, y, H, W, p, clean, sdn_a, sdn_b, out_mul);
+    return pnnp_launch_status();
+}
+
+// One [Conv2d1x1, AffineCoupling] pair of the FORWARD (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130).
+// step [host]: struct NfStep with W (not its inverse) in the matrix slot.  partial [B][ceil(H/32)*ceil(W/32)]: the
+// pixel-wise log-det terms summed per workgroup (the caller adds them and the scalar terms).  clean: SDN forward.
+int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H, int W, const float* step /*[host]*/,
+                         const float* clean, float sdn_a, float sdn_b, void* stream) {
+    if (!x || !y || !partial || !step || B < 0 || H <= 0 || W <= 0 || x == y) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    NfStep p;
+    memcpy(&p, step, sizeof p);
+    hipLaunchKernelGGL(nf_fwd_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
+                       x, y, partial, H, W, p, clean, sdn_a, sdn_b);
     return pnnp_launch_status();
 }
 

@@ -379,6 +379,15 @@ def gen_noiseflow():
             x = net.sample(clean=clean, iso=torch.tensor(float(iso)))
         out[f'out_iso{iso}'] = x.numpy()
     NFm.gaussian_diag = orig
+    # density direction (eval-mode BatchNorm): forward() -> (z, log-det objective), loss() -> (nll per dim, sd_z)
+    noise = torch.randn(2, 4, 32, 32, generator=g) * 0.02
+    out['fw_noise'] = noise.numpy()
+    for iso in (100, 3000):
+        with torch.no_grad():
+            zf, obj = net.forward(noise=noise, clean=clean, iso=torch.tensor(float(iso)))
+            nll, sdz = net.loss(noise=noise, clean=clean, iso=torch.tensor(float(iso)))
+        out[f'fw_z_iso{iso}'] = zf.numpy(); out[f'fw_obj_iso{iso}'] = obj.numpy()
+        out[f'fw_nll_iso{iso}'] = np.array([float(nll), float(sdz)], np.float64)
     np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
 
 

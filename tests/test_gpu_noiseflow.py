@@ -64,8 +64,8 @@ def test_prior_draw_statistics_and_api(golden_dir):
     z = torch.randn(clean.shape, device='cuda')
     c = net.sample(clean=clean, iso=1600.0, z=z)
     assert abs(float(a.std()) / float(c.std()) - 1) < 0.05 and abs(float(a.mean()) - float(c.mean())) < 0.05 * float(a.std())
-    with pytest.raises(NotImplementedError):
-        net.loss(noise=clean, clean=clean, iso=1600.0)
+    nll, sdz = net.loss(noise=a, clean=clean, iso=1600.0)             # evaluation-only NLL of its own samples: finite
+    assert torch.isfinite(nll) and float(sdz) > 0
 
 
 def test_config5_resunet_with_noiseflow_proxy_step(golden_dir):
@@ -87,3 +87,39 @@ def test_config5_resunet_with_noiseflow_proxy_step(golden_dir):
         noisy, _, _ = ts.make_noisy_proxy(hr, proxy, ratio=ratio, iso=1600)
         losses.append(float(ts.step(hr, noisy=noisy)[0]))
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_forward_and_loss_match_reference_golden(golden_dir):
+    """Density direction (evaluation only): z, the log-det objective and the NLL of the reference's
+    forward()/loss() in eval mode.  z: the chain bar of _close_chain; objective / NLL: sums over 4096 pixels of eight
+    couplings' log-scales, rtol 2e-5."""
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    net = _net(g)
+    noise = torch.from_numpy(g['fw_noise']).cuda(); clean = torch.from_numpy(g['clean']).cuda()
+    for iso in (100, 3000):
+        z, obj = net.forward(noise=noise, clean=clean, iso=torch.tensor(float(iso)).cuda())
+        _close_chain(z.cpu().numpy(), g[f'fw_z_iso{iso}'])
+        np.testing.assert_allclose(obj.cpu().numpy(), g[f'fw_obj_iso{iso}'], rtol=2e-5)
+        nll, sdz = net.loss(noise=noise, clean=clean, iso=torch.tensor(float(iso)).cuda())
+        assert abs(float(nll) - g[f'fw_nll_iso{iso}'][0]) < 1e-4 * abs(g[f'fw_nll_iso{iso}'][0])
+        assert abs(float(sdz) - g[f'fw_nll_iso{iso}'][1]) < 1e-6
+        nll2, _ = net(noise=noise, clean=clean, iso=float(iso), mode='loss')           # the reference's mode dispatch
+        assert float(nll2) == float(nll)
+
+
+def test_forward_ragged_vs_oracle_and_inverse_round_trip(golden_dir):
+    from oracle import noiseflow_torch as N
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    net = _net(g)
+    sd = {k: torch.from_numpy(g['sd:' + k]) for k in [str(x) for x in g['keys']]}
+    gen = torch.Generator().manual_seed(3)
+    noise = torch.randn(3, 4, 40, 40, generator=gen) * 0.03        # square (the reference's log-det assumes it), not a multiple of 32
+    clean = torch.rand(3, 4, 40, 40, generator=gen) * 0.02
+    iso = 800.0
+    z, obj = net.forward(noise=noise.cuda(), clean=clean.cuda(), iso=iso)
+    zr, objr = N.forward(sd, noise, clean, torch.tensor(iso))
+    _close_chain(z.cpu().numpy(), zr.numpy())
+    np.testing.assert_allclose(obj.cpu().numpy(), objr.numpy(), rtol=2e-5)
+    back = net.inverse(noise=z, clean=clean.cuda(), iso=iso).cpu().numpy()         # x -> z -> x: 16 couplings in fp32
+    err = np.abs(back - noise.numpy()); scale = float(noise.abs().max())
+    assert (err <= 1e-3 * scale).mean() >= 0.99 and (err <= 5e-2 * scale).all(), (float(err.max()), float((err <= 1e-3 * scale).mean()))

@@ -23,3 +23,21 @@ def test_product_module_state_dict_contract(golden_dir):
     assert list(net.state_dict().keys()) == list(g['keys'])
     for k, v in net.state_dict().items():
         assert tuple(v.shape) == g['sd:' + k].shape, k
+
+
+def test_forward_and_loss_match_reference(golden_dir):
+    """Density direction (row f4): z, the log-det objective and the NLL of the reference's forward()/loss()."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import noiseflow_torch as O
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'), allow_pickle=False)
+    sd = {k: torch.from_numpy(g['sd:' + k]) for k in [str(x) for x in g['keys']]}
+    noise, clean = torch.from_numpy(g['fw_noise']), torch.from_numpy(g['clean'])
+    for iso in (100, 3000):
+        z, obj = O.forward(sd, noise, clean, torch.tensor(float(iso)))
+        assert torch.allclose(z, torch.from_numpy(g[f'fw_z_iso{iso}']), rtol=1e-5, atol=1e-6)
+        assert torch.allclose(obj, torch.from_numpy(g[f'fw_obj_iso{iso}']), rtol=1e-6)
+        nll, sdz = O.loss(sd, noise, clean, torch.tensor(float(iso)))
+        assert abs(float(nll) - g[f'fw_nll_iso{iso}'][0]) < 1e-5 * abs(g[f'fw_nll_iso{iso}'][0])
+        assert abs(float(sdz) - g[f'fw_nll_iso{iso}'][1]) < 1e-7
