@@ -200,15 +200,19 @@ l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, fl
 }
 
 // out[0] = mean L1 over the batch; out[1 + b] = SSE of crop b
-__global__ void l1_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int blocks_per_crop, float inv_n) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64)
+l1_finish_kernel(const float* __restrict__ partial, float* __restrict__ out, int B, int blocks_per_crop, float inv_n) {
+    const int lane = threadIdx.x;               // one wave; fixed summation order (lane-strided, then a shuffle tree)
     float tot = 0.f;
     for (int b = 0; b < B; ++b) {
         float l = 0.f, s = 0.f;
-        for (int k = 0; k < blocks_per_crop; ++k) { l += partial[2 * (b * blocks_per_crop + k)]; s += partial[2 * (b * blocks_per_crop + k) + 1]; }
-        tot += l; out[1 + b] = s;
+        for (int k = lane; k < blocks_per_crop; k += 64) { l += partial[2 * (b * blocks_per_crop + k)]; s += partial[2 * (b * blocks_per_crop + k) + 1]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { l += __shfl_xor(l, o); s += __shfl_xor(s, o); }
+        tot += l;
+        if (lane == 0) out[1 + b] = s;
     }
-    out[0] = tot * inv_n;
+    if (lane == 0) out[0] = tot * inv_n;
 }
 
 // torch.optim.Adam (defaults, no weight decay / amsgrad), one flat launch over all parameters.
