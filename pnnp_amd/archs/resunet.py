@@ -116,7 +116,7 @@ class ResUnetEngine:
         """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  Same rule as the UNet engine."""
         if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
             return False, False
-        mink = int(os.environ.get('PNNP_WINO_MINK', '64'))
+        mink = int(os.environ.get('PNNP_WINO_MINK', '32'))
         return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
 
     def _cf(self, name, src, src2, bias, out, cout, act, residual=None):

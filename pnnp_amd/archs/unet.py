@@ -136,7 +136,7 @@ class UNetEngine:
         PNNP_WINO=0 forces the direct implicit-GEMM kernels, PNNP_WINO_MINK sets the minimum reduction depth."""
         if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
             return False, False
-        mink = int(os.environ.get('PNNP_WINO_MINK', '64'))
+        mink = int(os.environ.get('PNNP_WINO_MINK', '32'))
         return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
 
     def _wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):

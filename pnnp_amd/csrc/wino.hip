@@ -245,66 +245,73 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         __syncthreads();
     }
 
-    // ---- inverse transform A^T M A in registers + epilogue
-    const int n = nb * BN + wn * 32 + (lane & 31);
-    const int d = (a.n_split > 0 && n >= a.n_split) ? 1 : 0;
-    const int nc = n - (d ? a.n_split : 0);
-    float* dst = d ? a.dst[1] : a.dst[0];
-    const int dcs = d ? a.dst_cs[1] : a.dst_cs[0];
-    const float* mask = d ? a.mask[1] : a.mask[0];
-    const int mmode = d ? a.mask_mode[1] : a.mask_mode[0], accum = d ? a.accum[1] : a.accum[0];
-    const float bias = a.bias ? a.bias[n] : 0.f;
-    const int64_t img = (int64_t)b * a.H * a.W;
-    // act' masks: all 64 loads of this thread in flight at once (one HBM latency instead of 64)
-    float mk[16][4];
-    if (mmode) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-            const int ty = m >> 3, tx = m & 7;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int y = min(y0 + 2 * ty + (p >> 1), a.H - 1), x = min(x0 + 2 * tx + (p & 1), a.W - 1);
-                mk[e][p] = __builtin_nontemporal_load(mask + (img + (int64_t)y * a.W + x) * dcs + nc);
-            }
-        }
-    }
-    float ad[16][4];                                   // residual / shortcut-gradient term, same batching
-    if (a.addsrc) {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-            const int ty = m >> 3, tx = m & 7;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const int y = min(y0 + 2 * ty + (p >> 1), a.H - 1), x = min(x0 + 2 * tx + (p & 1), a.W - 1);
-                ad[e][p] = __builtin_nontemporal_load(a.addsrc + (img + (int64_t)y * a.W + x) * dcs + nc);
-            }
-        }
-    }
+    // ---- inverse transform A^T M A in registers, then a 16-byte epilogue.
+    // The accumulator layout has the channel on the lane and pixels in registers: stored directly that is 64 dword stores
+    // per lane and tile, and dword stores run at < 1 TB/s on this chip (they were HALF of the time of a K = 64 layer).
+    // Each wave therefore turns its 128 pixels x 32 channels through a private LDS patch (the chunk buffers are free
+    // now) so that a lane owns 4 consecutive channels of a pixel: mask / residual loads and the store are dwordx4
+    // covering whole 128-byte pixel rows, 16 per lane instead of 64.
+    constexpr int TSTR = 36;                                           // floats per patch row (32 channels + pad, 16-byte aligned)
+    float* T = smem + wave * (128 * TSTR);
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-        const int m = wm * 32 + 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);
-        const int ty = m >> 3, tx = m & 7;
+        const int m = 8 * (e >> 2) + 4 * (lane >> 5) + (e & 3);       // tile of this wave's 32
         float s[4], t[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s[j] = acc[j][e] + acc[4 + j][e] + acc[8 + j][e];
             t[j] = acc[4 + j][e] - acc[8 + j][e] - acc[12 + j][e];
         }
-        const float yv[4] = {s[0] + s[1] + s[2], s[1] - s[2] - s[3], t[0] + t[1] + t[2], t[1] - t[2] - t[3]};
+        float* o = T + (m * 4) * TSTR + (lane & 31);
+        o[0] = s[0] + s[1] + s[2];                                     // output pixel (0,0) of the tile
+        o[TSTR] = s[1] - s[2] - s[3];                                  // (0,1)
+        o[2 * TSTR] = t[0] + t[1] + t[2];                              // (1,0)
+        o[3 * TSTR] = t[1] - t[2] - t[3];                              // (1,1)
+    }
+    const int cq = lane & 7;                                           // channel quad of this lane (fixed over the 16 rows it handles)
+    const int n4 = nb * BN + wn * 32 + cq * 4;
+    const int d = (a.n_split > 0 && n4 >= a.n_split) ? 1 : 0;         // wave-uniform: n_split is a multiple of 32
+    const int nc = n4 - (d ? a.n_split : 0);
+    float* dst = d ? a.dst[1] : a.dst[0];
+    const int dcs = d ? a.dst_cs[1] : a.dst_cs[0];
+    const float* mask = d ? a.mask[1] : a.mask[0];
+    const int mmode = d ? a.mask_mode[1] : a.mask_mode[0], accum = d ? a.accum[1] : a.accum[0];
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n4);
+    const int64_t img = (int64_t)b * a.H * a.W;
+    int64_t off[16]; bool ok[16];
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int y = y0 + 2 * ty + (p >> 1), x = x0 + 2 * tx + (p & 1);
-            if (y < a.H && x < a.W) {
-                const int64_t o = (img + (int64_t)y * a.W + x) * dcs + nc;
-                float v = yv[p] + bias;
-                if (a.addsrc) v += ad[e][p];
-                v = act_fn(v, a.act);
-                if (mmode) v *= (mk[e][p] > 0.f) ? 1.f : (mmode == 1 ? 0.2f : 0.f);
-                if (accum) v += dst[o];
-                dst[o] = v;
-            }
+    for (int k = 0; k < 16; ++k) {
+        const int q = (k * 64 + lane) >> 3;                            // patch row = tile * 4 + sub-pixel
+        const int m = wm * 32 + (q >> 2), p = q & 3;
+        const int y = y0 + 2 * (m >> 3) + (p >> 1), x = x0 + 2 * (m & 7) + (p & 1);
+        ok[k] = y < a.H && x < a.W;
+        off[k] = (img + (int64_t)min(y, a.H - 1) * a.W + min(x, a.W - 1)) * dcs + nc;
+    }
+    f32x4 mk[16], ad[16];                                              // batched: one HBM latency for all 16
+    if (mmode) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) mk[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mask + off[k]));
+    }
+    if (a.addsrc) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) ad[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.addsrc + off[k]));
+    }
+    const float slope = mmode == 1 ? 0.2f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int q = (k * 64 + lane) >> 3;
+        f32x4 v = *reinterpret_cast<const f32x4*>(T + q * TSTR + cq * 4) + bias4;
+        if (a.addsrc) v += ad[k];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) v[c] = act_fn(v[c], a.act);
+        if (mmode) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] *= (mk[k][c] > 0.f) ? 1.f : slope;
+        }
+        if (ok[k]) {
+            if (accum) v += *reinterpret_cast<const f32x4*>(dst + off[k]);
+            *reinterpret_cast<f32x4*>(dst + off[k]) = v;
         }
     }
 }
@@ -347,6 +354,10 @@ int wino_launch(WinoArgs& a, hipStream_t st) {
     if (a.K % KC || a.N % BN || a.C1 % KC || (a.n_split % 32)) return PNNP_E_UNSUPPORTED;
     if ((int64_t)a.B * a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16;
+    // 16-byte epilogue accesses
+    if ((a.dst_cs[0] & 3) || (a.dst_cs[1] & 3) ||
+        ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) | ((uintptr_t)a.addsrc)) & 15))
+        return PNNP_E_INVALID;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
