@@ -228,6 +228,14 @@ int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H,
 int pnnp_sna_f32(const float* gt, float* dn, float* dy, int C, int H, int W, const float* aug_wb4, float K, float wp, float bl,
                  float ratio, int black_lr, int ori, uint64_t seed, uint64_t offset, uint32_t crop, void* stream);
 
+/* HighBitRecovery.map (data_process/process.py:718-751): pixels whose rounded value x lies in [low, high) are re-drawn
+ * inside their quantisation bin, d' = ppf(cdf[x-low] + u*range[x-low]) + (d - x); d = data*in_mul; the result is
+ * divided by out_div (norm=True) or, if out_div == 0, shifted by out_add (norm=False).  cdf/range: float64 device LUTs of
+ * the host-side HB2LB_LUT; rand: optional float64 uniforms (else the counter RNG). */
+int pnnp_hbr_map_f32(const float* data, float* out, int64_t n, const double* cdf, const double* range, int low, int high,
+                     int dist /* 0 normal, 1 Tukey-lambda */, double loc, double scale, double lam, const double* rand,
+                     float in_mul, float out_div, float out_add, int keep_delta, uint64_t seed, uint64_t offset, void* stream);
+
 /* ---------------------------------------------------------------- dataset-side crop / augment
  * init_random_crop_point + random_crop + data_aug (data_process/syn_datasets.py:69-107,162-173; the 4-way
  * variant real_datasets.py:98-137), fused behind raw2bayer (utils/isp_ops.py:84-96), the linear dark-shading

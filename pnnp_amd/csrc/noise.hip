@@ -225,6 +225,52 @@ sna_kernel(const float* __restrict__ gt, float* __restrict__ dn, float* __restri
     }
 }
 
+// HighBitRecovery.map (data_process/process.py:718-751): re-draw every integer-valued pixel inside its quantisation
+// bin according to the read-noise distribution:  x = round(d);  if low <= x < high:  d' = ppf(cdf[x] + u * range[x]) + (d - x).
+// cdf/range: per-integer LUT built on the host with scipy (HB2LB_LUT, :697-716); dist 0 = normal(loc, scale),
+// 1 = Tukey-lambda(lam, loc, scale).  The quantile is evaluated in float64 (the bins 6 sigma out have ranges ~1e-9).
+__global__ void __launch_bounds__(256)
+hbr_map_kernel(const float* __restrict__ data, float* __restrict__ out, int64_t n, const double* __restrict__ cdf,
+               const double* __restrict__ range, int low, int high, int dist, double loc, double scale, double lam,
+               const double* __restrict__ rand, float in_mul, float out_div, float out_add, int keep_delta,
+               uint32_t k0, uint32_t k1, uint32_t off) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float df = __fmul_rn(data[i], in_mul);
+        float x = rintf(df);                                   // np.round: half to even
+        const float delta = keep_delta ? __fsub_rn(df, x) : 0.f;
+        const int xi = (int)x;
+        if (xi >= low && xi < high) {
+            double u;
+            if (rand) u = rand[i];
+            else {
+                const uint4 r = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), 0x48425221u, off, k0, k1);
+                u = ((double)r.x * 4294967296.0 + (double)r.y + 0.5) * (1.0 / 18446744073709551616.0);
+            }
+            const double p = cdf[xi - low] + u * range[xi - low];
+            double q;
+            if (dist == 0) q = -1.4142135623730951 * erfcinv(2.0 * p);                      // norm.ppf
+            else q = (lam == 0.0) ? log(p / (1.0 - p)) : (pow(p, lam) - pow(1.0 - p, lam)) / lam;   // tukeylambda.ppf
+            x = (float)(loc + scale * q);
+        }
+        float v = __fadd_rn(x, delta);
+        v = out_div != 0.f ? __fdiv_rn(v, out_div) : __fadd_rn(v, out_add);
+        out[i] = v;
+    }
+}
+
+extern "C" int pnnp_hbr_map_f32(const float* data, float* out, int64_t n, const double* cdf, const double* range, int low, int high,
+                                int dist, double loc, double scale, double lam, const double* rand, float in_mul, float out_div,
+                                float out_add, int keep_delta, uint64_t seed, uint64_t offset, void* stream) {
+    if (n < 0 || (n && (!data || !out)) || !cdf || !range || high < low || !(scale > 0.0)) return PNNP_E_INVALID;
+    if (n == 0) return PNNP_OK;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(hbr_map_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), data, out, n, cdf, range, low, high, dist,
+                       loc, scale, lam, rand, in_mul, out_div, out_add, keep_delta, (uint32_t)seed,
+                       (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32), (uint32_t)offset);
+    return pnnp_launch_status();
+}
+
 extern "C" int pnnp_sna_f32(const float* gt, float* dn, float* dy, int C, int H, int W, const float* aug_wb4 /* host */,
                             float K, float wp, float bl, float ratio, int black_lr, int ori, uint64_t seed, uint64_t offset,
                             uint32_t crop, void* stream) {

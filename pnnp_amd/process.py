@@ -335,6 +335,64 @@ def SNA_torch(gt, aug_wb, camera_type='IMX686', ratio=1, black_lr=False, ori=Tru
     return dn, dy
 
 
+class HighBitRecovery:
+    """process.py:675-751: maps low-bit raw values back to a high-bit distribution by re-drawing every integer-valued
+    pixel inside its quantisation bin according to the calibrated read-noise law.  The LUT is built on the host exactly
+    like the reference (scipy cdf per integer, same numpy draws in the same order); ``map`` runs on the device."""
+
+    def __init__(self, camera_type='IMX686', noise_code='prq', param=None, perturb=True, factor=6, float=True):
+        self.camera_type, self.noise_code, self.param = camera_type, noise_code, param
+        self.perturb, self.factor, self.float = perturb, factor, float
+        self.lut = {}
+
+    def get_lut(self, iso_list, blc_mean=None):
+        for iso in iso_list:
+            bias = 0 if blc_mean is None else np.mean(blc_mean[iso])
+            if self.perturb:
+                bias += np.random.randn() * 0.1
+            self.lut[iso] = self.HB2LB_LUT(iso, bias)
+
+    def HB2LB_LUT(self, iso, bias=0, param=None):
+        from scipy import stats
+        p = sample_params_max(self.camera_type, iso=iso) if param is None else param
+        info = {'param': p}
+        if 'g' in self.noise_code.lower():
+            dist, sigma, kind = stats.tukeylambda(p['lam'], loc=bias, scale=p['sigTL']), p['sigTL'], 1
+        else:
+            dist, sigma, kind = stats.norm(loc=bias, scale=p['sigGs']), p['sigGs'], 0
+        low = max(int(-sigma * self.factor + bias), -p['bl'] + 1)
+        high = int(sigma * self.factor + bias)
+        xs = np.arange(low, high)
+        c0, c1 = dist.cdf(xs - 0.5), dist.cdf(xs + 0.5)
+        info.update(dist=dist, kind=kind, low=low, high=high, bias=bias, sigma=sigma, cdf=c0, range=c1 - c0)
+        return info
+
+    def map(self, data, iso=6400, norm=True, rand=None):
+        """data: CUDA tensor (normalised if max <= 1, else DN); rand: optional float64 uniforms (testing)."""
+        L = self.lut[iso]
+        p = L['param']
+        _lib.require_cuda(data)
+        d = data.contiguous().float()
+        span = float(p['wp'] - p['bl'])
+        in_mul = span if float(d.max()) <= 1 else 1.0              # process.py:721 (one scalar sync, like np.max)
+        key = ('dev', d.device)
+        if key not in L:
+            L[key] = (torch.from_numpy(np.ascontiguousarray(L['cdf'], np.float64)).to(d.device),
+                      torch.from_numpy(np.ascontiguousarray(L['range'], np.float64)).to(d.device))
+        cdf, rng = L[key]
+        out = torch.empty_like(d)
+        r = rand.contiguous().double() if rand is not None else None
+        off = _RngState.offset
+        _RngState.offset += 1
+        lam = float(p.get('lam', 0.0)) if L['kind'] == 1 else 0.0
+        _lib.check(_lib.lib().pnnp_hbr_map_f32(_lib.ptr(d), _lib.ptr(out), C.c_int64(d.numel()), _lib.ptr(cdf), _lib.ptr(rng), int(L['low']),
+                                               int(L['high']), int(L['kind']), C.c_double(float(L['bias'])), C.c_double(float(L['sigma'])),
+                                               C.c_double(lam), _lib.ptr(r), C.c_float(in_mul), C.c_float(span if norm else 0.0),
+                                               C.c_float(float(p['bl'])), int(bool(self.float)), C.c_uint64(_RngState.seed), C.c_uint64(off),
+                                               _lib.stream()), 'hbr_map')
+        return out
+
+
 def generate_noisy_obs(y, camera_type=None, wp=16383, noise_code='p', param=None, MultiFrameMean=1, ori=False, clip=False):
     """process.py:591-631 on the HIP sampler.  numpy in -> numpy out (staged through the
     GPU); CUDA tensor in -> CUDA tensor out."""

@@ -414,6 +414,35 @@ def gen_sna(proc):
     json.dump(meta, open(os.path.join(HERE, 'sna.json'), 'w'), indent=1)
 
 
+def gen_hbr(proc):
+    """HighBitRecovery (process.py:675-751): LUT under np.random.seed, map() with the uniform draw captured."""
+    out, meta = {}, {}
+    rng = np.random.RandomState(31)
+    for tag, cam, code, iso in (('imx_gauss', 'IMX686', 'prq', 6400), ('sony_tukey', 'SonyA7S2', 'pgrq', 1600)):
+        np.random.seed(12)
+        hbr = proc.HighBitRecovery(camera_type=cam, noise_code=code)
+        hbr.get_lut([iso], blc_mean=None)
+        lut = hbr.lut[iso]
+        p = lut['param']
+        span = p['wp'] - p['bl']
+        data = (rng.randn(4, 40, 56) * lut['sigma'] * 1.5 + rng.rand(4, 40, 56) * 3).astype(np.float32) / span     # normalised, |.| <= 1
+        u = rng.uniform(0, 1, size=data.shape)
+        orig = np.random.uniform
+        np.random.uniform = lambda *a, **k: u
+        try:
+            res = hbr.map(data.copy(), iso=iso, norm=True)
+            res_dn = hbr.map(data.copy(), iso=iso, norm=False)
+        finally:
+            np.random.uniform = orig
+        xs = list(range(lut['low'], lut['high']))
+        meta[tag] = dict(camera_type=cam, noise_code=code, iso=iso, seed=12, low=int(lut['low']), high=int(lut['high']), bias=float(lut['bias']),
+                         sigma=float(lut['sigma']), lam=float(p['lam']) if 'lam' in p else 0.0, wp=int(p['wp']), bl=int(p['bl']))
+        out[tag + '_data'] = data; out[tag + '_u'] = u; out[tag + '_res'] = res.astype(np.float32); out[tag + '_res_dn'] = res_dn.astype(np.float32)
+        out[tag + '_cdf'] = np.array([lut[x]['cdf'] for x in xs]); out[tag + '_range'] = np.array([lut[x]['range'] for x in xs])
+    np.savez_compressed(os.path.join(HERE, 'hbr.npz'), **out)
+    json.dump(meta, open(os.path.join(HERE, 'hbr.json'), 'w'), indent=1)
+
+
 def gen_augment(data_process, isp):
     """Rows f2/f3: crop points + 8-/4-way augmentation + WB gains + dark shading, as the datasets do them
     (syn_datasets.py:69-107,162-173,296-322; real_datasets.py:98-137,360-372)."""
@@ -480,7 +509,7 @@ def gen_augment(data_process, isp):
 
 def main():
     archs, proc, isp, losses, data_process, base_trainer = import_reference()
-    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment', 'sna']
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment', 'sna', 'hbr']
     if 'pack' in which: gen_pack(isp)
     if 'params' in which: gen_params(proc)
     if 'noise' in which: gen_noise(proc)
@@ -489,6 +518,7 @@ def main():
     if 'noiseflow' in which: gen_noiseflow()
     if 'augment' in which: gen_augment(data_process, isp)
     if 'sna' in which: gen_sna(proc)
+    if 'hbr' in which: gen_hbr(proc)
     print('golden fixtures written to', HERE)
 
 

@@ -80,3 +80,19 @@ def test_load_weights_by_name():
     assert float(got['conv5_2.bias'].mean()) == 0.5
     assert set(pkl_convert({'module.a': 1, 'b': 2})) == {'a'}
     assert tensor_dim5to4(torch.zeros(2, 8, 4, 16, 16)).shape == (16, 4, 16, 16)
+
+
+def test_high_bit_recovery_lut_matches_reference(golden_dir):
+    """HighBitRecovery.get_lut / HB2LB_LUT (process.py:686-716) on the host: same numpy draws, same scipy cdf per integer."""
+    import json, os
+    import numpy as np
+    from pnnp_amd import process as P
+    g = np.load(os.path.join(golden_dir, 'hbr.npz')); meta = json.load(open(os.path.join(golden_dir, 'hbr.json')))
+    for tag, m in meta.items():
+        np.random.seed(m['seed'])
+        hbr = P.HighBitRecovery(camera_type=m['camera_type'], noise_code=m['noise_code'])
+        hbr.get_lut([m['iso']], blc_mean=None)
+        L = hbr.lut[m['iso']]
+        assert (L['low'], L['high'], L['bias'], L['sigma']) == (m['low'], m['high'], m['bias'], m['sigma'])
+        np.testing.assert_allclose(L['cdf'], g[tag + '_cdf'], rtol=1e-13)
+        np.testing.assert_allclose(L['range'], g[tag + '_range'], rtol=1e-10, atol=1e-300)
