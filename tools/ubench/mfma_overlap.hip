@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256, 1) k(float* out, long long* t, int iters)
         for (int xx = 0; xx < 16; ++xx) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
-                const int x = INDEP ? ((xx * 4 + rr) & 15) : xx, r = rr;      // INDEP: consecutive MFMAs hit different accumulators
+                const int x = INDEP == 1 ? ((xx * 4 + rr) & 15) : (INDEP == 2 ? ((xx & ~1) | (rr & 1)) : xx), r = rr;      // 1: round-robin over 16 accumulators, 2: pairs a,b,a,b
                 acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[x], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -70,5 +70,7 @@ int main() {
     run<8, 0, 1>("indep accs: + 8 valu");
     run<12, 0, 1>("indep accs: + 12 valu");
     run<16, 0, 1>("indep accs: + 16 valu");
+    run<0, 0, 2>("pairs a,b,a,b: mfma only");
+    run<4, 0, 2>("pairs a,b,a,b: + 4 valu");
     return 0;
 }
