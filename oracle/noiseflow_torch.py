@@ -12,7 +12,8 @@ AffineCoupling, ``model.9`` GainISO.
 * ``sdn_scale``         archs/flow_layers/signal_dependant.py:37-51
 * ``gain_scale``        archs/flow_layers/gain.py:79-86
 
-Pinned by tests/golden/noiseflow.npz (outputs of the imported reference with an injected z).
+Pinned by tests/golden/noiseflow.npz (outputs of the imported reference with an injected z; ``tr_*``: the NLL, its
+gradients and the updated BatchNorm buffers of one train-mode ``loss().backward()`` of the reference).
 """
 import numpy as np
 import torch
@@ -44,7 +45,7 @@ def sdn_scale(sd, clean, iso, k=0):
     beta2 = torch.exp(sd[f'model.{k}.beta2'] * cam[1])
     gain = torch.exp(sd[f'model.{k}.gain'] * cam[2]) * iso
     scale = beta1 * clean / gain + beta2
-    assert float(scale.min()) >= 0            # signal_dependant.py:50
+    assert float(scale.detach().min()) >= 0            # signal_dependant.py:50
     return torch.sqrt(scale)
 
 
@@ -64,17 +65,26 @@ def conv1x1_inverse_matrix(sd, k):
     return torch.matmul(ui, torch.matmul(li, sd[f'model.{k}.p'].inverse()))
 
 
-def _bn_eval(x, sd, pre):
+def _bn_eval(x, sd, pre, training=False):
+    """nn.BatchNorm2d: running statistics in eval mode; in training mode the batch statistics normalise and the running
+    ones are updated in place (momentum 0.1, unbiased variance), as the module does."""
+    if training:
+        y = F.batch_norm(x, sd[pre + '.running_mean'], sd[pre + '.running_var'], sd[pre + '.weight'], sd[pre + '.bias'],
+                         training=True, momentum=0.1, eps=BN_EPS)
+        if pre + '.num_batches_tracked' in sd:
+            sd[pre + '.num_batches_tracked'] += 1
+        return y
     return F.batch_norm(x, sd[pre + '.running_mean'], sd[pre + '.running_var'], sd[pre + '.weight'], sd[pre + '.bias'],
                         training=False, eps=BN_EPS)
 
 
-def shift_and_log_scale(sd, k, z0):
+def shift_and_log_scale(sd, k, z0, training=False):
     p = f'model.{k}._shift_and_log_scale'
-    h = F.relu(_bn_eval(F.conv2d(z0, sd[p + '.conv2d_1.weight'], sd[p + '.conv2d_1.bias'], padding=1), sd, p + '.net.1'))
-    h = F.relu(_bn_eval(F.conv2d(h, sd[p + '.conv2d_2.weight'], sd[p + '.conv2d_2.bias']), sd, p + '.net.4'))
+    h = F.relu(_bn_eval(F.conv2d(z0, sd[p + '.conv2d_1.weight'], sd[p + '.conv2d_1.bias'], padding=1), sd, p + '.net.1', training))
+    h = F.relu(_bn_eval(F.conv2d(h, sd[p + '.conv2d_2.weight'], sd[p + '.conv2d_2.bias']), sd, p + '.net.4', training))
     h = F.pad(h, (1, 1, 1, 1, 0, 1), value=0.)          # ConstantPad3d((1,1,1,1,0,1)): +1 channel, +1 px border
-    h[:, 4, :1, :] = 1.0; h[:, 4, -1:, :] = 1.0; h[:, 4, :, :1] = 1.0; h[:, 4, :, -1:] = 1.0
+    ring = torch.ones(h.shape[-2:]); ring[1:-1, 1:-1] = 0.0
+    h = torch.cat([h[:, :4], (h[:, 4] + ring).unsqueeze(1)], dim=1)        # channel 4: ones on the pad ring (:268-271, out of place)
     h = F.conv2d(h, sd[p + '.conv2d_3.weight'], sd[p + '.conv2d_3.bias'])
     h = h * torch.exp(sd[p + '.logs'] * 3)
     shift, log_scale = torch.split(h, 2, dim=1)
@@ -111,8 +121,8 @@ def conv1x1_matrix(sd, k):
     return torch.matmul(sd[f'model.{k}.p'], torch.matmul(l, u))
 
 
-def forward(sd, noise, clean, iso):
-    """noise_flow.py:113-130: x -> z and the summed log|det J| of the chain (eval-mode BatchNorm).
+def forward(sd, noise, clean, iso, training=False):
+    """noise_flow.py:113-130: x -> z and the summed log|det J| of the chain (eval-mode BatchNorm unless ``training``).
     Quirk kept: Conv2d1x1's log-det is sum(log_s) * W * W (`pixels*pixels`, conv2d1x1.py:49,65: square inputs assumed)."""
     z = noise
     obj = torch.zeros(noise.shape[0], dtype=torch.float32)
@@ -122,7 +132,7 @@ def forward(sd, noise, clean, iso):
             obj = obj + sd[f'model.{k}.log_s'].sum() * noise.shape[-1] * noise.shape[-1]
         elif k in COUPLING_IDX:
             z0, z1 = z[:, :2], z[:, 2:]
-            shift, log_scale = shift_and_log_scale(sd, k, z0)
+            shift, log_scale = shift_and_log_scale(sd, k, z0, training)
             z = torch.cat([z0, z1 * torch.exp(log_scale) + shift], dim=1)
             obj = obj + log_scale.sum(dim=[1, 2, 3])
         elif k == 9:
@@ -136,10 +146,37 @@ def forward(sd, noise, clean, iso):
     return z, obj
 
 
-def loss(sd, noise, clean, iso):
+def loss(sd, noise, clean, iso, training=False):
     """noise_flow.py:132-165: (mean NLL per dimension, mean std of the noise)."""
-    z, obj = forward(sd, noise, clean, iso)
+    z, obj = forward(sd, noise, clean, iso, training)
     log_z = (-0.5 * (np.log(2 * np.pi) + z ** 2)).sum(dim=[1, 2, 3])
     nll = -(obj + log_z)
     sd_z = torch.sqrt(torch.var(noise, dim=[1, 2, 3])).mean()
     return nll.mean() / np.prod(noise.shape[1:]), sd_z
+
+
+# ---------------------------------------------------------------- fitting (row f4): one NLL step of trainer_NF_SID.py:116-126
+TRAINABLE_SUFFIX = ('.l', '.log_s', '.u', '.scale', '.logs', 'conv2d_1.weight', 'conv2d_1.bias', 'conv2d_2.weight', 'conv2d_2.bias',
+                    'conv2d_3.weight', 'conv2d_3.bias', 'net.1.weight', 'net.1.bias', 'net.4.weight', 'net.4.bias',
+                    'model.0.gain', 'model.0.beta1', 'model.0.beta2', 'model.9.cam_param', 'model.9.gain_params')
+
+
+def trainable(key):
+    """nn.Parameters with requires_grad (model.0.cam_param is frozen, signal_dependant.py:25; p, sign_s and the BatchNorm
+    running statistics are buffers); the aliases net.0 / net.3 of conv2d_1 / conv2d_2 are the same tensors."""
+    return key.endswith(TRAINABLE_SUFFIX) and '.net.0.' not in key and '.net.3.' not in key
+
+
+def loss_and_grads(sd, noise, clean, iso):
+    """net.train(); nll, sd_z = net.loss(...); nll.backward() (trainer_NF_SID.py:102,122-125) by autograd on this
+    restatement.  Returns (nll, sd_z, {key: grad}, {key: updated BatchNorm buffer})."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    leaves = {}
+    for k in list(sd.keys()):
+        if trainable(k):
+            sd[k] = sd[k].detach().requires_grad_(True); leaves[k] = sd[k]
+    nll, sd_z = loss(sd, noise, clean, iso, training=True)
+    grads = torch.autograd.grad(nll, list(leaves.values()), allow_unused=True)
+    g = {k: (torch.zeros_like(leaves[k]) if v is None else v) for k, v in zip(leaves.keys(), grads)}
+    buffers = {k: v.detach() for k, v in sd.items() if 'running_' in k or 'num_batches' in k}
+    return nll.detach(), sd_z, g, buffers

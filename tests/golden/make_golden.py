@@ -363,7 +363,7 @@ def gen_noiseflow():
     net.load_state_dict(sd)
     out = {'keys': np.array(list(sd.keys()))}
     for k, v in net.state_dict().items():
-        out['sd:' + k] = v.numpy()
+        out['sd:' + k] = v.numpy().copy()           # a copy: the train-mode step below updates BatchNorm buffers in place
     clean = torch.rand(2, 4, 32, 32, generator=g) * 0.01
     z = torch.randn(2, 4, 32, 32, generator=g)
     out['clean'] = clean.numpy(); out['z'] = z.numpy()
@@ -388,6 +388,24 @@ def gen_noiseflow():
             nll, sdz = net.loss(noise=noise, clean=clean, iso=torch.tensor(float(iso)))
         out[f'fw_z_iso{iso}'] = zf.numpy(); out[f'fw_obj_iso{iso}'] = obj.numpy()
         out[f'fw_nll_iso{iso}'] = np.array([float(nll), float(sdz)], np.float64)
+    # fitting (trainer_NF_SID.py:102,116-126): net.train(); loss().backward() -> NLL, gradients of every trainable parameter,
+    # BatchNorm running statistics after the step.  A batch of 3 ragged-free 32x32 crops at a table ISO and an off-table one.
+    noise3 = torch.randn(3, 4, 32, 32, generator=g) * 0.02
+    clean3 = torch.rand(3, 4, 32, 32, generator=g) * 0.01
+    out['tr_noise'] = noise3.numpy(); out['tr_clean'] = clean3.numpy()
+    for iso in (1600, 3000):
+        net.load_state_dict({k: torch.from_numpy(out['sd:' + k]) for k in out['keys']})
+        net.train(); net.zero_grad()
+        nll, sdz = net.loss(noise=noise3, clean=clean3, iso=torch.tensor(float(iso)))
+        nll.backward()
+        out[f'tr_nll_iso{iso}'] = np.array([float(nll), float(sdz)], np.float64)
+        for k, prm in net.named_parameters():
+            if prm.requires_grad and '.net.0.' not in k and '.net.3.' not in k:
+                out[f'tr_grad_iso{iso}:' + k] = (torch.zeros_like(prm) if prm.grad is None else prm.grad).numpy().copy()
+        for k, v in net.state_dict().items():
+            if 'running_' in k or 'num_batches' in k:
+                out[f'tr_buf_iso{iso}:' + k] = v.numpy().copy()
+    net.eval()
     np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
 
 

@@ -41,3 +41,23 @@ def test_forward_and_loss_match_reference(golden_dir):
         nll, sdz = O.loss(sd, noise, clean, torch.tensor(float(iso)))
         assert abs(float(nll) - g[f'fw_nll_iso{iso}'][0]) < 1e-5 * abs(g[f'fw_nll_iso{iso}'][0])
         assert abs(float(sdz) - g[f'fw_nll_iso{iso}'][1]) < 1e-7
+
+
+def test_train_step_grads_match_reference(golden_dir):
+    """Fitting (row f4): one train-mode loss().backward() of the reference -> NLL, every trainable parameter's gradient,
+    the BatchNorm running statistics after the step.  Same torch ops on the same CPU: agreement to float rounding."""
+    from oracle import noiseflow_torch as O
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'), allow_pickle=False)
+    sd = {k: torch.from_numpy(g['sd:' + k]) for k in [str(x) for x in g['keys']]}
+    noise, clean = torch.from_numpy(g['tr_noise']), torch.from_numpy(g['tr_clean'])
+    for iso in (1600, 3000):
+        nll, sdz, grads, bufs = O.loss_and_grads(sd, noise, clean, torch.tensor(float(iso)))
+        assert abs(float(nll) - g[f'tr_nll_iso{iso}'][0]) < 1e-6 * abs(g[f'tr_nll_iso{iso}'][0])
+        names = [k.split(':', 1)[1] for k in g.files if k.startswith(f'tr_grad_iso{iso}:')]
+        assert sorted(names) == sorted(grads.keys()) and len(names) == 8 * 3 + 8 * 12 + 3 + 2
+        for k in names:
+            ref = g[f'tr_grad_iso{iso}:' + k]
+            tol = 1e-5 * max(1e-12, np.abs(ref).max()) + 1e-9
+            assert np.abs(grads[k].numpy() - ref).max() <= tol, (k, np.abs(grads[k].numpy() - ref).max(), np.abs(ref).max())
+        for k, v in bufs.items():
+            np.testing.assert_allclose(v.numpy(), g[f'tr_buf_iso{iso}:' + k], rtol=1e-6, atol=1e-8, err_msg=k)
