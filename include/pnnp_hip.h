@@ -222,6 +222,33 @@ int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float*
 int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H, int W, const float* step /*[host]*/,
                          const float* clean, float sdn_a, float sdn_b, void* stream);
 
+/* ---------------------------------------------------------------- NoiseFlow NLL fitting (csrc/nf_train.hip)
+ * net.train(); nll, _ = net.loss(noise=, clean=, iso=); nll.backward()  (trainer_NF_SID.py:102,116-126; archs/noise_flow.py:113-165):
+ * one [SignalDependantISO | GainISO, Conv2d1x1, AffineCoupling] pair of the forward chain with BatchNorm in training mode
+ * (batch statistics, affine_coupling.py:257-264), and its backward.  All pointers are DEVICE pointers (parameters are read
+ * from the device so that a step needs no host round trip):
+ *   wm [4][4]   the Conv2d1x1 matrix W = P L U (conv2d1x1.py:58-65), divided by the GainISO scale where that layer precedes it
+ *   ab {a, b}   SignalDependantISO scale sqrt(a*clean + b), a = beta1/gain, b = beta2 (signal_dependant.py:37-51); with clean, first pair
+ *   prm [301]   W1[4][2][9] B1[4] G1[4] BE1[4] W2[4][4] B2[4] G2[4] BE2[4] W3[4][5][9] B3[4] LOGS[4] SCALE  (G/BE = BatchNorm weight/bias)
+ *   bn [24]     out: mean1[4] rstd1[4] var1[4] mean2[4] rstd2[4] var2[4] (biased variances; eps 1e-5; means of the BIAS-FREE conv outputs)
+ *   h1, h2, out3 [B][4][H][W]  saved conv2d_1 / conv2d_2 outputs (pre-BatchNorm, without their biases, which a batch-statistics
+ *               BatchNorm cancels exactly) and conv2d_3 output * exp(3 logs)
+ *   ldpart [tiles][2]  per-workgroup (sum of the pixel log-det terms, sum z^2), tiles = pnnp_nf_train_tiles(B,H,W), crop-major
+ *   part        scratch: max(tiles*197, pblocks*28) floats covers both calls (pblocks = pnnp_nf_train_pblocks) */
+int pnnp_nf_train_tiles(int B, int H, int W);
+int pnnp_nf_train_pblocks(int B, int H, int W);
+int pnnp_nf_train_fwd_pair_f32(const float* x, const float* clean /*or null*/, const float* ab, const float* wm, const float* prm,
+                               float* bn, float* h1, float* h2, float* out3, float* z, float* ldpart, float* part, int B, int H, int W,
+                               void* stream);
+/* Backward of the pair: dz = gradient of its output (times dzmul; the last pair passes z and dzmul = -dL/dF / B for the N(0,I)
+ * prior), cobj = dL/d(objective) per crop.  dx: gradient of its input.  sums [319] (deterministic reductions):
+ *   dW3[180] dB3[4] dLOGS[4] dSCALE dBE2[4] dG2[4] | dW2[16] dB2[4] dBE1[4] dG1[4] | dW1[72] dB1[4] dWm[16] da db
+ * dy2, dy1 [B][4][H][W] and dv23 [B][2][H][W] are scratch. */
+int pnnp_nf_train_bwd_pair_f32(const float* x, const float* clean /*or null*/, const float* ab, const float* wm, const float* prm,
+                               const float* bn, const float* h1, const float* h2, const float* out3, const float* dz, float dzmul,
+                               float cobj, float* dx, float* sums, float* dy2, float* dy1, float* dv23, float* part, int B, int H,
+                               int W, void* stream);
+
 /* SNA_torch (data_process/process.py:562-588): shot-noise augmentation under a white-balance gain change.
  * gt [C][H][W] -> dn (the extra Poisson noise, / (wp-bl), x ratio unless ori) and dy (the signal change); aug_wb4 is a
  * HOST array of the four plane gains.  Counter-based RNG as in pnnp_noise_sample_f32. */

@@ -2,12 +2,15 @@
 HIP kernels (reference: archs/noise_flow.py:24-221, archs/flow_layers/{conv2d1x1,affine_coupling,
 signal_dependant,gain}.py).
 
-Only what the denoiser-training hot path uses is implemented on the device: ``sample(clean=, iso=)``
-(trainer_SID.py:464-472, trainer_LRID.py:420-427).  ``forward``/``loss``/``inverse`` (fitting the flow
-by NLL) are outside this build's scope and raise.  BatchNorm inside the coupling networks runs in
-eval mode (running statistics), as in the SID trainer which calls ``proxy_net.eval()``
-(trainer_SID.py:42); trainer_LRID.py:34-39 forgets that call and samples with batch statistics --
-a reference quirk that is NOT reproduced.
+``sample(clean=, iso=)`` is what the denoiser-training hot path uses (trainer_SID.py:464-472,
+trainer_LRID.py:420-427); ``forward``/``loss``/``inverse`` are the density direction.  In eval mode BatchNorm inside the
+coupling networks uses its running statistics, as in the SID trainer which calls ``proxy_net.eval()`` (trainer_SID.py:42);
+trainer_LRID.py:34-39 forgets that call and samples with batch statistics -- a reference quirk that is NOT reproduced.
+
+Fitting the flow (trainer_NF_SID.py:102,116-126: ``net.train(); nll, _ = net.loss(...); nll.backward(); optimizer.step()``)
+works unchanged: in training mode ``loss()`` runs the chain with batch statistics on the kernels of csrc/nf_train.hip and
+returns an autograd-connected scalar whose ``backward()`` runs the hand-written backward kernels and fills ``.grad`` of every
+trainable parameter.  Only the 4x4 / scalar parameter algebra (W = P L U, the ISO tables) is left to torch autograd.
 """
 import ctypes as C
 
@@ -105,6 +108,103 @@ def _interp(table, iso):
     return pl
 
 
+# ---------------------------------------------------------------------------------------------- fitting (training mode)
+_CPARAM_SIZES = (72, 4, 4, 4, 16, 4, 4, 4, 180, 4, 4, 1)        # the prm block of csrc/nf_train.hip, in order
+
+
+def _coupling_params(ac):
+    s = ac._shift_and_log_scale
+    return [s.conv2d_1.weight, s.conv2d_1.bias, s.net[1].weight, s.net[1].bias, s.conv2d_2.weight, s.conv2d_2.bias,
+            s.net[4].weight, s.net[4].bias, s.conv2d_3.weight, s.conv2d_3.bias, s.logs, s.scale]
+
+
+def _interp_t(table, iso):
+    """signal_dependant.py:39-43 / gain.py:74-78 as torch ops on the parameter's device (keeps the autograd graph)."""
+    legal = np.asarray(LEGAL_ISO, np.float32)
+    iso = np.float32(iso)
+    l = int(np.searchsorted(legal, iso, side='left')); r = int(np.searchsorted(legal, iso, side='right'))
+    if l >= len(legal) or r >= len(legal):
+        raise IndexError('iso beyond the calibrated table (the reference indexes out of range too)')
+    pl, pr = torch.exp(table[l]), torch.exp(table[r])
+    if legal[r] - legal[l] != 0:
+        return (float(iso - legal[l]) * pr + float(legal[r] - iso) * pl) / float(legal[r] - legal[l])
+    return pl
+
+
+class _PairChainNLL(torch.autograd.Function):
+    """F = mean_b( sum of the pixel log-det terms of crop b - 0.5 * sum z_b^2 ) through the training-mode chain.
+
+    Inputs that carry gradients: wstack [P,4,4] (Conv2d1x1 matrices, GainISO folded), ab [2] (signal-dependent scale), and the
+    12 parameters of each coupling.  Everything heavy runs in libpnnp_hip.so (pnnp_nf_train_{fwd,bwd}_pair_f32)."""
+
+    @staticmethod
+    def forward(ctx, net, noise, clean, wstack, ab, *cparams):
+        L = _lib.lib()
+        B, Cc, H, W = noise.shape
+        P = wstack.shape[0]
+        dev = noise.device
+        tiles, pb = L.pnnp_nf_train_tiles(B, H, W), L.pnnp_nf_train_pblocks(B, H, W)
+        f32 = dict(dtype=torch.float32, device=dev)
+        prm = torch.cat([t.detach().reshape(-1) for t in cparams]).view(P, 301)
+        wm = wstack.detach().contiguous().view(P, 16)
+        abd = ab.detach().contiguous()
+        xs = torch.empty((P + 1, B, 4, H, W), **f32)
+        xs[0].copy_(noise)
+        h1 = torch.empty((P, B, 4, H, W), **f32); h2 = torch.empty_like(h1); out3 = torch.empty_like(h1)
+        bn = torch.empty((P, 24), **f32)
+        ldpart = torch.empty((P, tiles, 2), **f32)
+        part = torch.empty(max(tiles * 197, pb * 28), **f32)
+        st = _lib.stream()
+        for k in range(P):
+            cl = clean if k == net._sdn_pair else None
+            _lib.check(L.pnnp_nf_train_fwd_pair_f32(_lib.ptr(xs[k]), _lib.ptr(cl), _lib.ptr(abd), _lib.ptr(wm[k]), _lib.ptr(prm[k]),
+                                                    _lib.ptr(bn[k]), _lib.ptr(h1[k]), _lib.ptr(h2[k]), _lib.ptr(out3[k]),
+                                                    _lib.ptr(xs[k + 1]), _lib.ptr(ldpart[k]), _lib.ptr(part), B, H, W, st),
+                       'nf_train_fwd_pair')
+        per = ldpart.view(P, B, tiles // B, 2).double()
+        F = (per[..., 0].sum(dim=(0, 2)) - 0.5 * per[P - 1, :, :, 1].sum(dim=1)).mean().float()
+        ctx.net, ctx.shape, ctx.clean = net, (B, H, W, P, tiles, pb), clean
+        ctx.saved = (xs, h1, h2, out3, bn, prm, wm, abd, part)
+        net._last_bn = bn                       # BatchNorm buffers are updated by the caller (needs N and the momentum)
+        return F
+
+    @staticmethod
+    def backward(ctx, gF):
+        L = _lib.lib()
+        net, clean = ctx.net, ctx.clean
+        B, H, W, P, tiles, pb = ctx.shape
+        xs, h1, h2, out3, bn, prm, wm, abd, part = ctx.saved
+        g = float(gF)                            # one host read per step (the reference's loop reads nll.item() as well)
+        cobj = g / B
+        f32 = dict(dtype=torch.float32, device=xs.device)
+        sums = torch.empty((P, 319), **f32)
+        dy2 = torch.empty((B, 4, H, W), **f32); dy1 = torch.empty_like(dy2)
+        dv23 = torch.empty((B, 2, H, W), **f32)
+        dbuf = [torch.empty((B, 4, H, W), **f32), torch.empty((B, 4, H, W), **f32)]
+        st = _lib.stream()
+        dz, dzmul = xs[P], -cobj                 # d(-0.5 z^2)/dz = -z
+        for k in range(P - 1, -1, -1):
+            cl = clean if k == net._sdn_pair else None
+            dx = dbuf[k & 1]
+            _lib.check(L.pnnp_nf_train_bwd_pair_f32(_lib.ptr(xs[k]), _lib.ptr(cl), _lib.ptr(abd), _lib.ptr(wm[k]), _lib.ptr(prm[k]),
+                                                    _lib.ptr(bn[k]), _lib.ptr(h1[k]), _lib.ptr(h2[k]), _lib.ptr(out3[k]), _lib.ptr(dz),
+                                                    C.c_float(dzmul), C.c_float(cobj), _lib.ptr(dx), _lib.ptr(sums[k]), _lib.ptr(dy2),
+                                                    _lib.ptr(dy1), _lib.ptr(dv23), _lib.ptr(part), B, H, W, st), 'nf_train_bwd_pair')
+            dz, dzmul = dx, 1.0
+        # sums -> gradients in the order of the inputs
+        o2, o3 = 197, 225
+        cg = []
+        for k in range(P):
+            r = sums[k]
+            cg += [r[o3:o3 + 72].view(4, 2, 3, 3), r[o3 + 72:o3 + 76], r[o2 + 24:o2 + 28], r[o2 + 20:o2 + 24],
+                   r[o2:o2 + 16].view(4, 4, 1, 1), r[o2 + 16:o2 + 20], r[193:197], r[189:193],
+                   r[0:180].view(4, 5, 3, 3), r[180:184], r[184:188].view(1, 4, 1, 1), r[188:189]]
+        dw = sums[:, o3 + 76:o3 + 92].reshape(P, 4, 4)
+        dab = sums[net._sdn_pair, o3 + 92:o3 + 94].clone() if net._sdn_pair is not None else torch.zeros(2, **f32)
+        dnoise = dz if ctx.needs_input_grad[1] else None
+        return (None, dnoise, None, dw, dab) + tuple(cg)
+
+
 class NoiseFlow(nn.Module):
     """Drop-in for archs/noise_flow.py:24 (args keys: x_shape, arch, flow_permutation, param_inits, lu_decomp)."""
 
@@ -130,6 +230,7 @@ class NoiseFlow(nn.Module):
         self._steps = None
         self._steps_key = None
         self.seed, self.offset = 1997, 0
+        self._sdn_pair, self._last_bn = None, None
 
     # ------------------------------------------------------------------ host-side step tables
     def _plan(self):
@@ -225,14 +326,74 @@ class NoiseFlow(nn.Module):
         return cur, objective
 
     def loss(self, **kwargs):
-        """noise_flow.py:132-165: (mean NLL per dimension, mean per-crop std of the noise); evaluation only."""
+        """noise_flow.py:132-165: (mean NLL per dimension, mean per-crop std of the noise).  Eval mode: running BatchNorm
+        statistics, no gradients.  Training mode: batch statistics, autograd-connected (see the module docstring)."""
         x = kwargs['noise']
+        if self.training:
+            return self._loss_train(**kwargs)
         kw = dict(kwargs); kw['mode'] = 'forward'
         z, objective = self.forward(**kw)
         log_z = (-0.5 * (np.log(2 * np.pi) + z.double() ** 2)).sum(dim=[1, 2, 3])        # prior N(0, I), noise_flow.py:190-219
         nll = -(objective.double() + log_z)
         sd_z = torch.sqrt(torch.var(x.float(), dim=[1, 2, 3])).mean()
         return (nll.mean() / float(np.prod(x.shape[1:]))).float(), sd_z
+
+    def _forward_plan(self):
+        """Forward-order pairs [(coupling, conv1x1, gain_before | None, sdn_before | None)] and the index of the sdn pair."""
+        plan = self._plan()[::-1]
+        self._sdn_pair = next((k for k, e in enumerate(plan) if e[3] is not None), None)
+        return plan
+
+    def _loss_train(self, **kwargs):
+        """One training-mode evaluation of loss() (trainer_NF_SID.py:116-123).  The per-pixel work is in HIP; the 4x4
+        matrices W = P L U (conv2d1x1.py:58-65), the ISO-table scalars and the pixel-independent log-det terms are torch
+        expressions of the parameters so that autograd finishes the chain rule for l, u, log_s, gain, beta1/2, cam_param."""
+        x = kwargs['noise']
+        _lib.require_cuda(x)
+        x = x.contiguous().float()
+        clean = kwargs['clean'].contiguous().float() if kwargs.get('clean') is not None else None
+        iso = float(kwargs['iso'])
+        B, Cc, H, W = x.shape
+        dev = x.device
+        plan = self._forward_plan()
+        mask = torch.tril(torch.ones(4, 4, device=dev), -1); eye = torch.eye(4, device=dev)
+        ws, scalar = [], torch.zeros((), device=dev)
+        ab = torch.zeros(2, device=dev)
+        for ac, cv, g_before, s_before in plan:
+            l = cv.l * mask + eye
+            u = cv.u * mask.t() + torch.diag(cv.sign_s * torch.exp(cv.log_s))
+            w = torch.matmul(cv.p, torch.matmul(l, u))
+            scalar = scalar + cv.log_s.sum() * float(W * W)              # conv2d1x1.py:49,65 `pixels*pixels`
+            if g_before is not None:                                     # gain.py:79-110: z = x / scale, log-det -log(scale) per element
+                gs = torch.exp(_interp_t(g_before.cam_param, iso) * g_before.gain_params) * iso
+                w = w / gs
+                scalar = scalar - torch.log(gs) * float(Cc * H * W)
+            if s_before is not None:                                     # signal_dependant.py:37-51
+                if clean is None:
+                    raise PnnpError("NoiseFlow.loss needs 'clean' for the signal-dependent layer")
+                cam = _interp_t(s_before.cam_param, iso)
+                beta1 = torch.exp(s_before.beta1 * cam[0]); beta2 = torch.exp(s_before.beta2 * cam[1])
+                gain = torch.exp(s_before.gain * cam[2]) * iso
+                ab = torch.stack([beta1 / gain, beta2])
+                if float((ab[0].detach() * clean.min() + ab[1].detach())) < 0:
+                    raise AssertionError('scale must be non-negative')  # signal_dependant.py:50
+            ws.append(w)
+        wstack = torch.stack(ws)
+        cparams = [t for ac, _cv, _g, _s in plan for t in _coupling_params(ac)]
+        F = _PairChainNLL.apply(self, x, clean, wstack, ab, *cparams)
+        D = float(Cc * H * W)
+        nll = -(F + scalar - 0.5 * D * float(np.log(2 * np.pi))) / D
+        # BatchNorm buffers (nn.BatchNorm2d, momentum 0.1, unbiased variance)
+        n = float(B * H * W)
+        with torch.no_grad():
+            for k, (ac, _cv, _g, _s) in enumerate(plan):
+                sl = ac._shift_and_log_scale
+                for bnm, conv, off in ((sl.net[1], sl.conv2d_1, 0), (sl.net[4], sl.conv2d_2, 12)):
+                    bnm.running_mean.mul_(0.9).add_(self._last_bn[k, off:off + 4] + conv.bias, alpha=0.1)   # kernel means are bias-free
+                    bnm.running_var.mul_(0.9).add_(self._last_bn[k, off + 8:off + 12], alpha=0.1 * n / max(n - 1.0, 1.0))
+                    bnm.num_batches_tracked += 1
+        sd_z = torch.sqrt(torch.var(x, dim=[1, 2, 3])).mean()
+        return nll, sd_z
 
     def inverse(self, **kwargs):
         """noise_flow.py:167-171: the reversed chain applied to ``noise`` (= sample() with that tensor as the draw)."""

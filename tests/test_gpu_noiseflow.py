@@ -123,3 +123,91 @@ def test_forward_ragged_vs_oracle_and_inverse_round_trip(golden_dir):
     back = net.inverse(noise=z, clean=clean.cuda(), iso=iso).cpu().numpy()         # x -> z -> x: 16 couplings in fp32
     err = np.abs(back - noise.numpy()); scale = float(noise.abs().max())
     assert (err <= 1e-3 * scale).mean() >= 0.99 and (err <= 5e-2 * scale).all(), (float(err.max()), float((err <= 1e-3 * scale).mean()))
+
+
+# ------------------------------------------------------------------------------------------------ fitting (row f4)
+def _grad_close(got, ref, name, rtol=2e-4):
+    """Gradients are sums over B*H*W pixels of fp32 products; bar: rtol of the tensor's largest reference entry, plus an
+    absolute floor for gradients that are mathematically zero (conv biases in front of a training-mode BatchNorm)."""
+    tol = rtol * float(np.abs(ref).max()) + 2e-6
+    err = float(np.abs(got - ref).max())
+    assert err <= tol, (name, err, tol, float(np.abs(ref).max()))
+
+
+def test_train_mode_loss_backward_matches_reference_golden(golden_dir):
+    """net.train(); nll, sd = net.loss(...); nll.backward() (trainer_NF_SID.py:102,116-126): NLL, all 125 parameter
+    gradients and the BatchNorm buffers after the step, against the reference's own autograd on CPU."""
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    noise = torch.from_numpy(g['tr_noise']).cuda(); clean = torch.from_numpy(g['tr_clean']).cuda()
+    for iso in (1600, 3000):
+        net = _net(g).train()
+        net.zero_grad()
+        nll, sdz = net.loss(noise=noise, clean=clean, iso=torch.tensor(float(iso)).cuda())
+        ref = g[f'tr_nll_iso{iso}']
+        assert abs(float(nll.detach()) - ref[0]) < 2e-5 * abs(ref[0]) and abs(float(sdz) - ref[1]) < 1e-6
+        nll.backward()
+        named = dict(net.named_parameters())
+        names = [k.split(':', 1)[1] for k in g.files if k.startswith(f'tr_grad_iso{iso}:')]
+        assert len(names) == 125
+        for k in names:
+            assert named[k].grad is not None, k
+            _grad_close(named[k].grad.cpu().numpy(), g[f'tr_grad_iso{iso}:' + k], k)
+        assert named['model.0.cam_param'].grad is None                       # frozen in the reference (signal_dependant.py:25)
+        sd = net.state_dict()
+        for k in g.files:
+            if k.startswith(f'tr_buf_iso{iso}:'):
+                np.testing.assert_allclose(sd[k.split(':', 1)[1]].cpu().numpy(), g[k], rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+def test_train_mode_ragged_batch_vs_oracle(golden_dir):
+    """Shapes that are not multiples of the 32x32 tile, several tiles per crop, batch of 5: against autograd on the oracle."""
+    from oracle import noiseflow_torch as O
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    sd = {k: torch.from_numpy(g['sd:' + k]) for k in [str(x) for x in g['keys']]}
+    gen = torch.Generator().manual_seed(11)
+    for (B, H, W) in ((5, 48, 48), (2, 40, 72)):
+        noise = torch.randn(B, 4, H, W, generator=gen) * 0.03
+        clean = torch.rand(B, 4, H, W, generator=gen) * 0.02
+        iso = 800.0
+        rn, rs, rg, rb = O.loss_and_grads(sd, noise, clean, torch.tensor(iso))
+        net = _net(g).train()
+        nll, sdz = net(noise=noise.cuda(), clean=clean.cuda(), iso=iso, mode='loss')
+        assert abs(float(nll) - float(rn)) < 2e-5 * abs(float(rn))
+        nll.backward()
+        named = dict(net.named_parameters())
+        for k, v in rg.items():
+            _grad_close(named[k].grad.cpu().numpy(), v.numpy(), k)
+        cur = net.state_dict()
+        for k, v in rb.items():
+            np.testing.assert_allclose(cur[k].cpu().numpy(), v.numpy(), rtol=2e-5, atol=1e-7, err_msg=k)
+
+
+def test_fit_steps_follow_oracle_trajectory(golden_dir):
+    """Three Adam steps (lr 2e-3, runfiles/SonyA7S2/NoiseFlow.yml:56) on a fixed batch: the NLL sequence follows the
+    CPU oracle's (autograd + torch.optim.Adam) and decreases."""
+    from oracle import noiseflow_torch as O
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    noise = torch.from_numpy(g['tr_noise']); clean = torch.from_numpy(g['tr_clean'])
+    sd = {k: torch.from_numpy(g['sd:' + k]).clone() for k in [str(x) for x in g['keys']]}
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in sd if O.trainable(k)}
+    opt_ref = torch.optim.Adam(list(leaves.values()), lr=2e-3)
+    ref = []
+    for _ in range(3):
+        cur = dict(sd); cur.update(leaves)
+        for k in list(cur.keys()):                                         # the net.0 / net.3 aliases follow conv2d_1 / conv2d_2
+            if '.net.0.' in k: cur[k] = cur[k.replace('.net.0.', '.conv2d_1.')]
+            if '.net.3.' in k: cur[k] = cur[k.replace('.net.3.', '.conv2d_2.')]
+        opt_ref.zero_grad()
+        nll, _ = O.loss(cur, noise, clean, torch.tensor(1600.0), training=True)
+        nll.backward(); opt_ref.step(); ref.append(float(nll))
+        for k in sd:                                                       # carry the updated BatchNorm buffers
+            if 'running_' in k or 'num_batches' in k: sd[k] = cur[k].detach()
+    net = _net(g).train()
+    opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=2e-3)
+    got = []
+    for _ in range(3):
+        opt.zero_grad()
+        nll, _ = net.loss(noise=noise.cuda(), clean=clean.cuda(), iso=1600.0)
+        nll.backward(); opt.step(); got.append(float(nll))
+    assert got[-1] < got[0]
+    np.testing.assert_allclose(got, ref, rtol=5e-4)
