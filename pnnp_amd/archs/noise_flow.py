@@ -356,17 +356,21 @@ class NoiseFlow(nn.Module):
         B, Cc, H, W = x.shape
         dev = x.device
         plan = self._forward_plan()
+        P = len(plan)
         mask = torch.tril(torch.ones(4, 4, device=dev), -1); eye = torch.eye(4, device=dev)
-        ws, scalar = [], torch.zeros((), device=dev)
+        # the eight W = P L U at once (conv2d1x1.py:58-65), batched so that the step launches a handful of tiny kernels
+        cvs = [e[1] for e in plan]
+        ls = torch.stack([cv.l for cv in cvs]) * mask + eye
+        log_s = torch.stack([cv.log_s for cv in cvs])
+        us = torch.stack([cv.u for cv in cvs]) * mask.t() + torch.diag_embed(torch.stack([cv.sign_s for cv in cvs]) * torch.exp(log_s))
+        wstack = torch.matmul(torch.stack([cv.p for cv in cvs]), torch.matmul(ls, us))
+        scalar = log_s.sum() * float(W * W)                              # conv2d1x1.py:49,65 `pixels*pixels`
         ab = torch.zeros(2, device=dev)
-        for ac, cv, g_before, s_before in plan:
-            l = cv.l * mask + eye
-            u = cv.u * mask.t() + torch.diag(cv.sign_s * torch.exp(cv.log_s))
-            w = torch.matmul(cv.p, torch.matmul(l, u))
-            scalar = scalar + cv.log_s.sum() * float(W * W)              # conv2d1x1.py:49,65 `pixels*pixels`
+        for k, (ac, cv, g_before, s_before) in enumerate(plan):
             if g_before is not None:                                     # gain.py:79-110: z = x / scale, log-det -log(scale) per element
                 gs = torch.exp(_interp_t(g_before.cam_param, iso) * g_before.gain_params) * iso
-                w = w / gs
+                div = torch.ones(P, 1, 1, device=dev).index_put((torch.tensor([k], device=dev),), gs.reshape(1, 1, 1))
+                wstack = wstack / div
                 scalar = scalar - torch.log(gs) * float(Cc * H * W)
             if s_before is not None:                                     # signal_dependant.py:37-51
                 if clean is None:
@@ -377,21 +381,23 @@ class NoiseFlow(nn.Module):
                 ab = torch.stack([beta1 / gain, beta2])
                 if float((ab[0].detach() * clean.min() + ab[1].detach())) < 0:
                     raise AssertionError('scale must be non-negative')  # signal_dependant.py:50
-            ws.append(w)
-        wstack = torch.stack(ws)
         cparams = [t for ac, _cv, _g, _s in plan for t in _coupling_params(ac)]
         F = _PairChainNLL.apply(self, x, clean, wstack, ab, *cparams)
         D = float(Cc * H * W)
         nll = -(F + scalar - 0.5 * D * float(np.log(2 * np.pi))) / D
-        # BatchNorm buffers (nn.BatchNorm2d, momentum 0.1, unbiased variance)
+        # BatchNorm buffers (nn.BatchNorm2d, momentum 0.1, unbiased variance); the kernels' means are bias-free
         n = float(B * H * W)
         with torch.no_grad():
-            for k, (ac, _cv, _g, _s) in enumerate(plan):
-                sl = ac._shift_and_log_scale
-                for bnm, conv, off in ((sl.net[1], sl.conv2d_1, 0), (sl.net[4], sl.conv2d_2, 12)):
-                    bnm.running_mean.mul_(0.9).add_(self._last_bn[k, off:off + 4] + conv.bias, alpha=0.1)   # kernel means are bias-free
-                    bnm.running_var.mul_(0.9).add_(self._last_bn[k, off + 8:off + 12], alpha=0.1 * n / max(n - 1.0, 1.0))
-                    bnm.num_batches_tracked += 1
+            bn = self._last_bn.view(P, 2, 3, 4)                          # [pair][layer][mean, rstd, var][channel]
+            sls = [e[0]._shift_and_log_scale for e in plan]
+            bias = torch.stack([torch.stack([sl.conv2d_1.bias, sl.conv2d_2.bias]) for sl in sls])
+            mean = ((bn[:, :, 0] + bias) * 0.1).reshape(2 * P, 4).unbind(0)
+            var = (bn[:, :, 2] * (0.1 * n / max(n - 1.0, 1.0))).reshape(2 * P, 4).unbind(0)
+            bns = [m for sl in sls for m in (sl.net[1], sl.net[4])]
+            rm, rv = [m.running_mean for m in bns], [m.running_var for m in bns]
+            torch._foreach_mul_(rm, 0.9); torch._foreach_add_(rm, list(mean))
+            torch._foreach_mul_(rv, 0.9); torch._foreach_add_(rv, list(var))
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         sd_z = torch.sqrt(torch.var(x, dim=[1, 2, 3])).mean()
         return nll, sd_z
 
