@@ -20,7 +20,7 @@ import torch
 import yaml
 
 from . import archs, process
-from .trainer import HipTrainStep, get_cos_lr
+from .trainer import HipTrainStep, NoiseFlowFitStep, get_cos_lr
 
 
 def load(path):
@@ -43,10 +43,17 @@ def build(cfg, device='cuda', rank=0, world=1, group=None):
     if cls is None:
         raise KeyError(arch['name'])
     net = cls(arch)
-    archs.initialize_weights(net)                                   # trainer_SID.py:31
-    net = net.to(device)
     dst = cfg.get('dst_train', cfg.get('dst'))
     hyper = cfg['hyper']
+    if arch['name'] == 'NoiseFlow':                                 # trainer_NF_SID.py: the proxy itself is fitted (NLL)
+        net = net.to(device)
+        step = NoiseFlowFitStep(net, lr=float(hyper['learning_rate']), camera_type=dst['camera_type'], noise_code=dst['noise_code'],
+                                ori=bool(dst.get('ori', False)), clip=dst.get('clip', False), rank=rank, world=world, group=group)
+        shapes = dict(batch=int(hyper.get('batch_size', 1)) * int(dst.get('crop_per_image', 1)), patch=int(dst['patch_size']),
+                      channels=int(arch['x_shape'][0]))
+        return net, step, lr_schedule(hyper), shapes
+    archs.initialize_weights(net)                                   # trainer_SID.py:31
+    net = net.to(device)
     step = HipTrainStep(net, lr=float(hyper['learning_rate']), camera_type=dst['camera_type'], noise_code=dst['noise_code'],
                         ori=bool(dst.get('ori', False)), clip=dst.get('clip', False), rank=rank, world=world, group=group)
     shapes = dict(batch=int(hyper.get('batch_size', 1)) * int(dst.get('crop_per_image', 1)), patch=int(dst['patch_size']),
@@ -76,9 +83,16 @@ def main(argv=None):
         for k in range(a.steps):
             np.random.seed(1997 + epoch * 1000 + k)
             hr = torch.rand(sh['batch'], sh['channels'], S, S, device='cuda', generator=g)
+            if isinstance(step, NoiseFlowFitStep):                  # log line of trainer_NF_SID.py:136: nll, std
+                nll, sd = step.step(hr * 0.1, iso=(800, 1600, 3200)[k % 3], lr=lr)
+                losses.append(float(nll)); psnrs.append(float(sd))
+                continue
             out = step.step(hr, lr=lr)
             losses.append(float(out[0])); psnrs.append(step.psnr_from(out, sh['channels'] * S * S))
         # base_trainer / trainer_SID log line format: epoch, lr, loss, psnr
+        if isinstance(step, NoiseFlowFitStep):
+            print(f"Epoch {epoch:04d} | lr {lr:.3e} | nll {np.mean(losses):.5f} | std {np.mean(psnrs):.4f}", flush=True)
+            continue
         print(f"Epoch {epoch:04d} | lr {lr:.3e} | loss {np.mean(losses):.5f} | psnr {np.mean(psnrs):.2f}", flush=True)
     return 0
 

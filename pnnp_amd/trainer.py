@@ -204,3 +204,57 @@ class HipTrainStep:
         """PSNR_Loss (losses/__init__.py:4-15) from the SSE the loss kernel returns."""
         sse = loss_out[1:].double()
         return float((-10.0 * torch.log10(sse / elems_per_crop)).mean())
+
+
+class NoiseFlowFitStep:
+    """One NLL fitting step of the NoiseFlow proxy on synthetic pairs (trainer_NF_SID.py:97-126 with the `Raw_Dataset`
+    preprocess branch :431-446): physics-sampler noise at a table ISO on the clean crops ``hr`` [B,4,H,W] (CUDA), then
+
+        noise = (lr - hr) / ratio;  clean = hr / ratio;  nll, sd_z = net.loss(noise=, clean=, iso=);  nll.backward();  Adam
+
+    with ``net`` in training mode (BatchNorm batch statistics, :102).  ``step`` returns the device scalars
+    ``(nll + mean log ratio, sd_z * mean ratio)`` that the reference logs (:129-133)."""
+
+    def __init__(self, net, lr=2e-3, camera_type='SonyA7S2', noise_code='pgrq', ori=False, clip=False, seed=1997,
+                 rank=0, world=1, group=None, tukey=True):
+        self.net = net
+        self.lr = lr
+        self.camera_type, self.noise_code, self.ori, self.clip = camera_type, noise_code, ori, clip
+        self.seed, self.rank, self.world, self.group = seed, rank, world, group
+        self.tukey = tukey                       # 'g' in the run files' noise_code: drawn on the device (row f3)
+        self.step_count = 0
+        self.optimizer = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=lr)      # trainer_NF_SID.py:34
+
+    def make_pair(self, hr, iso):
+        B = hr.shape[0]
+        plist = [process.sample_params_max(camera_type=self.camera_type, ratio=None, iso=iso) for _ in range(B)]
+        rows = process.pack_params(plist, hr.device)
+        code = self.noise_code.lower()
+        if 'g' in code and 'b' not in code and not self.tukey:
+            raise NotImplementedError            # process.py:654
+        flags = process.noise_flags(code if self.tukey else code.replace('g', ''), ori=self.ori, clip=bool(self.clip), torch_mode=True)
+        if self.tukey and 'g' in code:
+            flags |= process.F_TORCH_TUKEY
+        lr_img = process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count, crop_base=self.rank * B)
+        ratio = torch.ones(B, 1, 1, 1, device=hr.device) if self.ori else rows[:, 6].reshape(B, 1, 1, 1)    # column order of process.pack_params: K sigGs sigTL lam sigR q ratio wp bl
+        return lr_img, ratio
+
+    def step(self, hr, iso=1600, lr=None):
+        if not hr.is_cuda:
+            raise PnnpError('NoiseFlowFitStep needs CUDA tensors (no CPU path)')
+        if lr is not None:
+            for g in self.optimizer.param_groups:
+                g['lr'] = lr
+        self.net.train()
+        imgs_lr, ratio = self.make_pair(hr, iso)
+        self.optimizer.zero_grad(set_to_none=True)
+        nll, sd_z = self.net.loss(noise=(imgs_lr - hr) / ratio, clean=hr / ratio, iso=float(iso))
+        nll.backward()
+        if self.world > 1:                       # replicas average their gradients (BatchNorm statistics stay per replica,
+            import torch.distributed as dist     # as under the reference's nn.DataParallel)
+            for p in self.net.parameters():
+                if p.grad is not None:
+                    dist.all_reduce(p.grad, group=self.group); p.grad.div_(self.world)
+        self.optimizer.step()
+        self.step_count += 1
+        return nll.detach() + torch.log(ratio).mean(), sd_z * ratio.mean()

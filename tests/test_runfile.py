@@ -38,3 +38,17 @@ def test_cli_runs_and_learns(capsys):
     assert len(lines) == 3 and lines[0].startswith('Epoch 0021')
     losses = [float(l.split('loss')[1].split('|')[0]) for l in lines]
     assert losses[-1] < losses[0]
+
+
+@pytest.mark.gpu
+def test_noiseflow_runfile_fits_the_proxy(capsys):
+    """runfiles/*/NoiseFlow.yml schema -> NoiseFlow + NLL fitting step (trainer_NF_SID.py:97-126) on synthetic pairs from the
+    physics sampler ('pgrq'): the NLL goes down and the flow's sample std approaches the data's."""
+    from pnnp_amd import runfile
+    rf = os.path.join(HERE, 'fixtures', 'runfile_noiseflow.yml')
+    np.random.seed(0); torch.manual_seed(0)
+    assert runfile.main([rf, '--synthetic', '--epochs', '4', '--steps', '12']) == 0
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith('Epoch')]
+    assert len(lines) == 4 and lines[0].startswith('Epoch 0001')
+    nll = [float(l.split('nll')[1].split('|')[0]) for l in lines]
+    assert np.isfinite(nll).all() and nll[-1] < nll[0] - 0.05, nll
