@@ -144,6 +144,9 @@ int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgra
                                    int B, int H, int W, void* stream);
 /* Winograd backward-weight (dg = G^T [sum_tiles (A dY A^T) (.) (B^T d B)] G): same contract as
  * pnnp_conv_bwd_weight_f32 with taps = 9; needs H % 4 == 0, W % 8 == 0 and Cout, C1, C2 multiples of 64. */
+/* Profiling hook of the Winograd forward / backward-data kernel (no reference counterpart): every later launch writes per-workgroup
+ * clock64() stamps at entry, main-loop entry, epilogue entry and exit to buf[4*workgroup .. +3]; null switches it off. */
+int pnnp_wino_set_debug(long long* buf);
 int pnnp_wino_wgrad_supported(int H, int W, int Cout, int C1, int C2);
 int64_t pnnp_wino_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
 int pnnp_conv3x3_wino_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,

@@ -23,6 +23,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
+#ifndef WINO_FENCED
+#define WINO_FENCED 1
+#endif
 constexpr int KC = 8, BN = 64, TT = 64, PATCH = 18;
 constexpr int VPLANE = TT * 4 + 32;                    // 288: the +32 keeps the two k-quads of a b128 store on disjoint banks
 constexpr int VS_STAGE = 16 * 2 * VPLANE;              // floats
@@ -41,6 +44,7 @@ struct WinoArgs {
     const float* bias; int act;
     const float* mask[2]; int mask_mode[2]; int accum[2];
     const float* addsrc;
+    long long* dbg;                                    // profiling hook (pnnp_wino_set_debug): per-workgroup cycle stamps, or null
 };
 
 __device__ __forceinline__ float4 f4_fma(float4 a, float s, float4 b) {      // b + s*a
@@ -86,6 +90,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     float* Us = smem + 2 * VS_STAGE;
     float* raws = Us + 2 * US_STAGE;                   // two patch buffers
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const long long t_start = a.dbg ? clock64() : 0;
 
     int mt = blockIdx.x;
     const int nb = blockIdx.y;
@@ -96,7 +101,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
 
     // halo patch staging slots: 18*18 pixels x 2 channel quads = 648 float4, three per thread.
     // Out-of-image pixels load a clamped (valid) address and are zeroed by a select: no divergent branches.
-    int roff0[3], roff1[3]; bool rok[3]; int rdst[3];
+    unsigned roff0[3], roff1[3]; bool rok[3]; int rdst[3];     // unsigned: uniform base + zero-extended lane offset = saddr loads
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int q = tid + 256 * s, pl = min(q >> 1, PATCH * PATCH - 1);
@@ -109,7 +114,8 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         rdst[s] = py * RAW_ROW + ((px & 1) * 9 + (px >> 1)) * KC + (tid & 1) * 4;
     }
     const int nchunks = a.K / KC;
-    const float* ug = a.u + (int64_t)nb * nchunks * US_STAGE + tid * 4;
+    const float* ug = a.u + (int64_t)nb * nchunks * US_STAGE;          // uniform; the lane offset utid is added per load
+    const unsigned utid = tid * 4;
 
     f32x4 rr[3], ur[8];
     auto gload_raw = [&](int c) {
@@ -122,7 +128,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     auto gload_u = [&](int c) {
         const float* up = ug + (int64_t)c * US_STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ur[j] = *reinterpret_cast<const f32x4*>(up + j * 1024);
+        for (int j = 0; j < 8; ++j) ur[j] = *reinterpret_cast<const f32x4*>(up + j * 1024 + utid);
     };
     auto store_raw = [&](int buf) {
         float* r = raws + buf * RAW_FLOATS;
@@ -169,6 +175,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     // One branch-free basic block per chunk: the 64 MFMAs of chunk c with, in their shadow, the input transform of
     // chunk c+1, the LDS stores of U(c+1)/patch(c+2) and the global loads of U(c+2)/patch(c+3).  Past the last
     // chunk the same instructions run on clamped (valid) addresses and write LDS buffers nobody reads.
+    const long long t_loop = a.dbg ? clock64() : 0;
     for (int c = 0; c < nchunks; ++c) {
         const int stage = c & 1;
         const float* vb = Vs + stage * VS_STAGE + voff;
@@ -181,10 +188,10 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         const int k3 = min(c + 3, nchunks - 1) * KC;
         const int s3 = k3 >= a.C1;
         const float* rnext = (s3 ? a.src[1] : a.src[0]) + (k3 - (s3 ? a.C1 : 0));
-        float4 av[2], bv[2];
-        float4 da[2], db[2], tt[4];
-        av[0] = *reinterpret_cast<const float4*>(vb);
-        bv[0] = *reinterpret_cast<const float4*>(ub);
+        f32x4 av[2], bv[2];
+        f32x4 da[2], db[2], tt[4];
+        av[0] = *reinterpret_cast<const f32x4*>(vb);
+        bv[0] = *reinterpret_cast<const f32x4*>(ub);
         // one step = the 4 MFMAs of transformed position xi plus a fixed slice of the other work
 #define WINO_STEP(XI)                                                                                                  \
         {                                                                                                              \
@@ -197,30 +204,31 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             constexpr int n_write = (ust_ ? 1 : 0) + (out_ ? 4 : 0) + (pst_ ? 1 : 0);                                  \
             constexpr int n_vmem = (ust_ ? 1 : 0) + (pst_ ? 1 : 0);                                                    \
             if constexpr (xi + 1 < 16) {                                                                               \
-                av[(xi + 1) & 1] = *reinterpret_cast<const float4*>(vb + (xi + 1) * 2 * VPLANE);                       \
-                bv[(xi + 1) & 1] = *reinterpret_cast<const float4*>(ub + (xi + 1) * 2 * UPLANE);                       \
+                av[(xi + 1) & 1] = *reinterpret_cast<const f32x4*>(vb + (xi + 1) * 2 * VPLANE);                        \
+                bv[(xi + 1) & 1] = *reinterpret_cast<const f32x4*>(ub + (xi + 1) * 2 * UPLANE);                        \
             }                                                                                                          \
             if constexpr (ur_ >= 0) {                                                                                  \
                 constexpr int col = (((ur_ & 3) & 1) * 9 + ((ur_ & 3) >> 1)) * KC + (ur_ >> 2) * 8 * RAW_ROW;          \
-                da[ur_ & 1] = *reinterpret_cast<const float4*>(rsrc + it_a + col);                                     \
-                db[ur_ & 1] = *reinterpret_cast<const float4*>(rsrc + it_b + col);                                     \
+                da[ur_ & 1] = *reinterpret_cast<const f32x4*>(rsrc + it_a + col);                                      \
+                db[ur_ & 1] = *reinterpret_cast<const f32x4*>(rsrc + it_b + col);                                      \
             }                                                                                                          \
-            const float4 A = av[xi & 1], Bv = bv[xi & 1];                                                              \
+            if constexpr (WINO_FENCED) __builtin_amdgcn_sched_barrier(0);   /* the reads above lead the step */          \
+            const f32x4 A = av[xi & 1], Bv = bv[xi & 1];                                                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, Bv.x, acc[xi], 0, 0, 0);                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bv.y, acc[xi], 0, 0, 0);                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bv.z, acc[xi], 0, 0, 0);                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bv.w, acc[xi], 0, 0, 0);                               \
-            if constexpr (uf_ >= 0) tt[uf_ & 3] = f4_fma(db[uf_ & 1], it_sg, da[uf_ & 1]);                             \
+            if constexpr (uf_ >= 0) tt[uf_ & 3] = db[uf_ & 1] * it_sg + da[uf_ & 1];                                   \
             if constexpr (ust_) {                                           /* U(c+1) -> LDS, U(c+2) -> registers */   \
                 *reinterpret_cast<f32x4*>(usdst + (xi & 7) * 1024) = ur[xi & 7];                                       \
-                ur[xi & 7] = *reinterpret_cast<const f32x4*>(unext + (xi & 7) * 1024);                                 \
+                ur[xi & 7] = *reinterpret_cast<const f32x4*>(unext + (xi & 7) * 1024 + utid);                          \
             }                                                                                                          \
             if constexpr (out_) {                                           /* outputs of item 0 / item 1 */           \
                 float* o = vdst + (xi == 11 ? 32 * 4 : 0);                                                             \
-                *reinterpret_cast<float4*>(o) = f4_sub(tt[0], tt[2]);                                                  \
-                *reinterpret_cast<float4*>(o + 2 * VPLANE) = f4_add(tt[1], tt[2]);                                     \
-                *reinterpret_cast<float4*>(o + 4 * VPLANE) = f4_sub(tt[2], tt[1]);                                     \
-                *reinterpret_cast<float4*>(o + 6 * VPLANE) = f4_sub(tt[1], tt[3]);                                     \
+                *reinterpret_cast<f32x4*>(o) = tt[0] - tt[2];                                                   \
+                *reinterpret_cast<f32x4*>(o + 2 * VPLANE) = tt[1] + tt[2];                                      \
+                *reinterpret_cast<f32x4*>(o + 4 * VPLANE) = tt[2] - tt[1];                                      \
+                *reinterpret_cast<f32x4*>(o + 6 * VPLANE) = tt[1] - tt[3];                                      \
             }                                                                                                          \
             if constexpr (pst_) {                                           /* patch(c+2) -> LDS, patch(c+3) -> registers */ \
                 constexpr int j = pst_ ? xi - 12 : 0;                                                                  \
@@ -228,6 +236,9 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
                 *reinterpret_cast<f32x4*>(rdstb + rdst[j]) = rok[j] ? rr[j] : z;                                       \
                 rr[j] = *reinterpret_cast<const f32x4*>(rnext + (s3 ? roff1[j] : roff0[j]));                           \
             }                                                                                                          \
+            if constexpr (WINO_FENCED) {                                                                               \
+                __builtin_amdgcn_sched_barrier(0);      /* nothing crosses a step boundary */                          \
+            } else {                                                                                                   \
             /* pin the order: this step's LDS reads, then the MFMAs with the other work in their shadow */             \
             if constexpr (n_read > 0) __builtin_amdgcn_sched_group_barrier(0x100, n_read, 0);                          \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
@@ -238,12 +249,14 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
             if constexpr (n_valu > 1) __builtin_amdgcn_sched_group_barrier(0x002, n_valu / 2, 0);                      \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                         \
+            }                                                                                                          \
         }
         WINO_STEP(0) WINO_STEP(1) WINO_STEP(2) WINO_STEP(3) WINO_STEP(4) WINO_STEP(5) WINO_STEP(6) WINO_STEP(7)
         WINO_STEP(8) WINO_STEP(9) WINO_STEP(10) WINO_STEP(11) WINO_STEP(12) WINO_STEP(13) WINO_STEP(14) WINO_STEP(15)
 #undef WINO_STEP
         __syncthreads();
     }
+    const long long t_epi = a.dbg ? clock64() : 0;
 
     // ---- inverse transform A^T M A in registers, then a 16-byte epilogue.
     // The accumulator layout has the channel on the lane and pixels in registers: stored directly that is 64 dword stores
@@ -314,6 +327,10 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             *reinterpret_cast<f32x4*>(dst + off[k]) = v;
         }
     }
+    if (a.dbg && tid == 0) {
+        long long* d = a.dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
+        d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = clock64();
+    }
 }
 
 // U = G g G^T of every (k, n) filter, written in the kernel's chunked order [N/64][K/8][16][2][64][4].
@@ -350,7 +367,10 @@ wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, i
     }
 }
 
+long long* g_wino_dbg = nullptr;       // set by pnnp_wino_set_debug; profiling only
+
 int wino_launch(WinoArgs& a, hipStream_t st) {
+    a.dbg = g_wino_dbg;
     if (a.K % KC || a.N % BN || a.C1 % KC || (a.n_split % 32)) return PNNP_E_UNSUPPORTED;
     if ((int64_t)a.B * a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16;
@@ -438,5 +458,9 @@ int pnnp_conv3x3_wino_bwd_data_res_f32(const float* g, int Cout, const float* u_
     a.mask[0] = a.mask[1] = mask; a.mask_mode[0] = a.mask_mode[1] = mask ? mode : 0;
     return wino_launch(a, as_stream(stream));
 }
+
+// Profiling hook: when buf is non-null every later Winograd launch writes, per workgroup w (= blockIdx.y*gridDim.x+blockIdx.x),
+// buf[4w..4w+3] = clock64() at kernel entry, main-loop entry, epilogue entry and exit.  buf must hold 4 * workgroups entries.
+int pnnp_wino_set_debug(long long* buf) { g_wino_dbg = buf; return PNNP_OK; }
 
 }  // extern "C"

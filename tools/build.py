@@ -11,7 +11,7 @@ OBJ = os.path.join(SRC, '_build')
 OUT = os.path.join(REPO, 'pnnp_amd', 'libpnnp_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
-          '-I', os.path.join(REPO, 'include')]
+          '-I', os.path.join(REPO, 'include')] + os.environ.get('PNNP_HIPCC_EXTRA', '').split()     # A/B experiments (-DWINO_FENCED=0 ...)
 # per-file extra flags: the sampler keeps every float32 rounding explicit (matches oracle/pnnp_oracle.c)
 EXTRA = {'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off'], 'cropaug.hip': ['-ffp-contract=off'],
          # the Winograd backward-weight kernel's source order is its schedule (slots fenced with sched_barrier)
