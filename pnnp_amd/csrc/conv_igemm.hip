@@ -43,8 +43,8 @@ igemm_kernel(const IgemmArgs a) {
     constexpr int P = Cfg::P, TH = Cfg::TH, HC = Cfg::HC, NPIX = Cfg::NPIX, KQ = Cfg::KQ;
     constexpr int NA = Cfg::NA, NB = Cfg::NB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float4* xs = reinterpret_cast<float4*>(smem);
-    float4* ws = xs + Cfg::XS_F4;
+    f32x4* xs = reinterpret_cast<f32x4*>(smem);       // ext-vector type: see the note at lds_load
+    f32x4* ws = xs + Cfg::XS_F4;
     float* epi = reinterpret_cast<float*>(ws + Cfg::WS_F4);     // 4 waves x 32x32 floats (epilogue transpose)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -57,9 +57,9 @@ igemm_kernel(const IgemmArgs a) {
     const int G = gridDim.x;
     const int nchunks = a.nseg * a.chunks_per_seg;
     const int K4 = nchunks * KQ;                       // Ktot / 4
-    const float4* w4 = reinterpret_cast<const float4*>(a.w);
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w);
 
-    float4 ra[NA], rb[NB];                             // staging registers of the NEXT work item
+    f32x4 ra[NA], rb[NB];                             // staging registers of the NEXT work item
 
     // Per-thread constants of the staging pattern (which halo pixel / channel quad / weight slot each
     // of this thread's float4s is): computed once, so the per-item address arithmetic is a few
@@ -99,15 +99,15 @@ igemm_kernel(const IgemmArgs a) {
         for (int k = 0; k < NA; ++k) {
             const int r = (int)(signed char)(pa[k] >> 16), q = (int)(signed char)(pa[k] >> 8), cq = pa[k] & 0xff;
             const int gy = (tl.y0 + r) * a.in_mul + sg.yoff, gx = (tl.x0 + q) * a.in_mul + sg.xoff;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pa[k] >= 0 && gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
-                v = *reinterpret_cast<const float4*>(sg.ptr + (((rowbase + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq));
+                v = *reinterpret_cast<const f32x4*>(sg.ptr + (((rowbase + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq));
             ra[k] = v;
         }
         const int wb = g * KQ * a.Ntot + tl.n0;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (pb[k] >= 0 && tl.n0 + (tid + 256 * k) % BN < a.Ntot) v = w4[wb + pb[k]];
             rb[k] = v;
         }
@@ -159,11 +159,13 @@ igemm_kernel(const IgemmArgs a) {
         if (nt < total) prefetch(nxt, nsi, ncc, ng);
         // ---- MFMA over taps x channel octets.  The LDS reads of step s+1 are issued BEFORE the MFMAs of
         // step s (register double buffer): left to itself hipcc issues each step's ds_reads right in front
-        // of its MFMAs with s_waitcnt lgkmcnt(0), exposing the LDS latency once per 8-16 MFMAs.
+        // of its MFMAs with s_waitcnt lgkmcnt(0), exposing the LDS latency once per 8-16 MFMAs.  The operands must be
+        // ext_vector_type(4) values: loads of HIP's float4 STRUCT are four scalar loads that the SLP vectoriser re-emits
+        // next to their first use, which silently undoes the prefetch.
         {
             constexpr int NSTEP = TAPS * (KC / 8);
-            float4 av[2][MT], bv[2][NT];
-            auto lds_load = [&](int step, float4 (&ax)[MT], float4 (&bx)[NT]) {
+            f32x4 av[2][MT], bv[2][NT];
+            auto lds_load = [&](int step, f32x4 (&ax)[MT], f32x4 (&bx)[NT]) {
                 const int tp = step / (KC / 8), j = step % (KC / 8);
                 const int dy = (TAPS == 9) ? tp / 3 : 0, dx = (TAPS == 9) ? tp % 3 : 0;
 #pragma unroll
@@ -175,11 +177,12 @@ igemm_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int step = 0; step < NSTEP; ++step) {
                 if (step + 1 < NSTEP) {
-                    lds_load(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);
-                    __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);      // the next step's DS reads first ...
+                    lds_load(step + 1, av[(step + 1) & 1], bv[(step + 1) & 1]);      // the next step's DS reads first ...
                 }
-                const float4 (&ax)[MT] = av[step & 1];
-                const float4 (&bx)[NT] = bv[step & 1];
+                __builtin_amdgcn_sched_barrier(0);     // (a fence, not a sched_group_barrier: a group of "n DS reads" is
+                                                       //  satisfied by THIS step's reads just as well)
+                const f32x4 (&ax)[MT] = av[step & 1];
+                const f32x4 (&bx)[NT] = bv[step & 1];
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -189,7 +192,7 @@ igemm_kernel(const IgemmArgs a) {
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].z, bx[k].z, acc[i][k], 0, 0, 0);
                         acc[i][k] = __builtin_amdgcn_mfma_f32_32x32x2f32(ax[i].w, bx[k].w, acc[i][k], 0, 0, 0);
                     }
-                __builtin_amdgcn_sched_group_barrier(0x008, 4 * MT * NT, 0);          // ... then this step's MFMAs
+                __builtin_amdgcn_sched_barrier(0);                                    // ... then this step's MFMAs
             }
         }
         if (g == nchunks - 1) {
