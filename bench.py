@@ -85,8 +85,14 @@ def main():
             ge.build()
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        backend = os.environ.get('PNNP_BENCH_BACKEND', 'nccl')       # 'gloo': rehearsal of the N>1 path on a box with fewer GPUs than ranks
+        if backend != 'nccl':
+            local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
         dist.barrier()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
