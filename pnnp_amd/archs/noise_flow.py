@@ -269,7 +269,14 @@ class NoiseFlow(nn.Module):
                                   f(s.conv2d_3.weight), f(s.conv2d_3.bias), np.exp(3.0 * f(s.logs)),
                                   f(s.scale), np.zeros(16, np.float32)]).astype(np.float32)
             assert vec.size == 317
-            steps.append((vec, cv.inverse_matrix().numpy().astype(np.float32), g_after, s_after))
+            host = {'w': cv.matrix().numpy().astype(np.float32), 'log_s_sum': float(cv.log_s.detach().sum())}
+            if g_after is not None:
+                host['g_cam'] = g_after.cam_param.detach().cpu().numpy(); host['g_gain'] = np.float32(g_after.gain_params.item())
+            if s_after is not None:
+                host['s_cam'] = s_after.cam_param.detach().cpu().numpy()
+                host['s_beta1'], host['s_beta2'], host['s_gain'] = (np.float32(s_after.beta1.item()), np.float32(s_after.beta2.item()),
+                                                                   np.float32(s_after.gain.item()))
+            steps.append((vec, cv.inverse_matrix().numpy().astype(np.float32), g_after, s_after, host))
         self._steps, self._steps_key = steps, key
         return steps
 
@@ -296,25 +303,24 @@ class NoiseFlow(nn.Module):
         partial = torch.zeros((8, B, nblk), dtype=torch.float32, device=x.device)
         scalar = 0.0                                   # log-det terms that do not depend on the pixel
         cur, nxt = x.clone(), torch.empty_like(x)
-        plan = self._plan()[::-1]                      # forward order: pairs from the data side to the prior side
-        tables = self._tables()[::-1]
-        for k, ((vec, _winv, g_after, s_after), (ac, cv, _g, _s)) in enumerate(zip(tables, plan)):
-            w = cv.matrix().numpy().astype(np.float32)
-            scalar += float(cv.log_s.detach().sum()) * W * W          # conv2d1x1.py:49,65 `pixels*pixels` (square inputs assumed)
+        tables = self._tables()[::-1]                  # forward order: pairs from the data side to the prior side
+        for k, (vec, _winv, g_after, s_after, host) in enumerate(tables):    # parameters come from the cached host copies: no D2H here
+            w = host['w']
+            scalar += host['log_s_sum'] * W * W                       # conv2d1x1.py:49,65 `pixels*pixels` (square inputs assumed)
             # in the forward chain the layer that FOLLOWS this pair in the reversed plan precedes it here:
             # SignalDependantISO before the first pair, GainISO before the fifth (both stored on the previous reversed entry)
             a = b = np.float32(0.0); cl = None
             if s_after is not None:
-                cam = _interp(s_after.cam_param.detach().cpu().numpy(), iso)
-                beta1 = np.exp(np.float32(s_after.beta1.item()) * cam[0]); beta2 = np.exp(np.float32(s_after.beta2.item()) * cam[1])
-                gain = np.exp(np.float32(s_after.gain.item()) * cam[2]) * np.float32(iso)
+                cam = _interp(host['s_cam'], iso)
+                beta1 = np.exp(host['s_beta1'] * cam[0]); beta2 = np.exp(host['s_beta2'] * cam[1])
+                gain = np.exp(host['s_gain'] * cam[2]) * np.float32(iso)
                 a, b, cl = np.float32(beta1 / gain), np.float32(beta2), clean
                 if cl is None:
                     raise PnnpError("NoiseFlow.forward needs 'clean' for the signal-dependent layer")
                 if float(a) * float(clean.min()) + float(b) < 0:
                     raise AssertionError('scale must be non-negative')      # signal_dependant.py:50
             if g_after is not None:
-                gs = np.float32(np.exp(_interp(g_after.cam_param.detach().cpu().numpy(), iso) * np.float32(g_after.gain_params.item())) * np.float32(iso))
+                gs = np.float32(np.exp(_interp(host['g_cam'], iso) * host['g_gain']) * np.float32(iso))
                 w = w / gs                                 # z = x / scale, then W: folded
                 scalar -= float(np.log(gs)) * Cc * H * W   # gain.py:101-108
             vec = vec.copy(); vec[301:317] = w.reshape(-1)
@@ -426,17 +432,16 @@ class NoiseFlow(nn.Module):
         else:
             z = z.contiguous().float().clone()       # the ping-pong below overwrites its buffers
         cur, nxt = z, torch.empty_like(clean)
-        for vec, winv, g_after, s_after in self._tables():
+        for vec, winv, g_after, s_after, host in self._tables():
             w = winv.copy()
             if g_after is not None:        # gain.py:79-86: x * exp(cam*gain_params) * iso  (scalar: folded into W^-1)
-                w *= np.float32(np.exp(_interp(g_after.cam_param.detach().cpu().numpy(), iso) *
-                                       np.float32(g_after.gain_params.item())) * np.float32(iso))
+                w *= np.float32(np.exp(_interp(host['g_cam'], iso) * host['g_gain']) * np.float32(iso))
             vec = vec.copy(); vec[301:317] = w.reshape(-1)
             a = b = np.float32(0.0); cl = None
             if s_after is not None:        # signal_dependant.py:37-51: sqrt(beta1*clean/gain + beta2)
-                cam = _interp(s_after.cam_param.detach().cpu().numpy(), iso)
-                beta1 = np.exp(np.float32(s_after.beta1.item()) * cam[0]); beta2 = np.exp(np.float32(s_after.beta2.item()) * cam[1])
-                gain = np.exp(np.float32(s_after.gain.item()) * cam[2]) * np.float32(iso)
+                cam = _interp(host['s_cam'], iso)
+                beta1 = np.exp(host['s_beta1'] * cam[0]); beta2 = np.exp(host['s_beta2'] * cam[1])
+                gain = np.exp(host['s_gain'] * cam[2]) * np.float32(iso)
                 a, b, cl = np.float32(beta1 / gain), np.float32(beta2), clean
                 if float(a) * float(clean.min()) + float(b) < 0:
                     raise AssertionError('scale must be non-negative')      # signal_dependant.py:50

@@ -14,6 +14,7 @@ namespace {
 
 struct CropArgs {
     double black[4];
+    double den[4], rcp[4];   // wp - black and its correctly rounded reciprocal (host division)
     double wp;
     int norm, clip, post_clip;
     int H, W;            // raw frame (mode 0) or packed plane (mode 1) size
@@ -23,10 +24,12 @@ struct CropArgs {
     double ds_add;       // added back after the subtraction (its mean for noise code 'd', + a random bias)
 };
 
-__device__ __forceinline__ float pack_value(float x, double black, double wp, int norm, int clip) {
-    // numpy: float32 plane - int64/float64 black -> float64; / (wp - black); clip; -> float32
+__device__ __forceinline__ float pack_value(float x, double black, double den, double rcp, int norm, int clip) {
+    // numpy: float32 plane - int64/float64 black -> float64; / (wp - black); clip; -> float32.  The division by the per-plane
+    // constant is the correctly rounded 3-operation sequence of csrc/pack.hip (div_const): bit-identical, no fp64 divide.
     if (!norm) return clip ? fminf(fmaxf(x, 0.f), 1.f) : x;
-    double v = ((double)x - black) / (wp - black);
+    const double n = (double)x - black, q = n * rcp;
+    double v = fma(fma(-q, den, n), rcp, q);
     if (clip) v = fmin(fmax(v, 0.0), 1.0);
     return (float)v;
 }
@@ -62,7 +65,7 @@ crop_aug_kernel(const void* __restrict__ src_, const void* __restrict__ ds_, flo
                         if (a.ds_f64) raw = (float)(((double)src[off[c]] - ((const double*)ds_)[off[c]]) + a.ds_add);
                         else raw = __fadd_rn(__fsub_rn(raw, ((const float*)ds_)[off[c]]), (float)a.ds_add);
                     }
-                    v[c] = pack_value(raw, a.black[c], a.wp, a.norm, a.clip);
+                    v[c] = pack_value(raw, a.black[c], a.den[c], a.rcp[c], a.norm, a.clip);
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) t[c][r][l] = v[c];
@@ -122,7 +125,7 @@ int pnnp_crop_pack_bayer_u16(const uint16_t* frame, int H, int W, const void* da
     if (st != PNNP_OK) return st < 0 ? st : PNNP_OK;
     if (!black4 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || 2 * ps > H || 2 * ps > W) return PNNP_E_INVALID;
     CropArgs a{};
-    for (int c = 0; c < 4; ++c) a.black[c] = black4[c];
+    for (int c = 0; c < 4; ++c) { a.black[c] = black4[c]; a.den[c] = wp - black4[c]; a.rcp[c] = 1.0 / a.den[c]; }
     a.wp = wp; a.norm = norm; a.clip = clip; a.post_clip = post_clip; a.H = H; a.W = W; a.C = 4; a.ps = ps;
     a.ds_f64 = dark_is_f64; a.ds_add = dark_add;
     const dim3 grid((ps + 31) / 32, (ps + 31) / 32, n);

@@ -42,11 +42,14 @@ illum_apply_kernel(const float* __restrict__ pred, float* __restrict__ out, cons
         out[i] = scale * fminf(fmaxf(pred[i], 0.f), 1.f);
 }
 
-// One 32x32 tile of one channel: squared error over the tile and SSIM map over the window-valid pixels.
+// One 32x32 tile of one channel: squared error over the tile and SSIM map over the window-valid pixels.  The 7x7 window sums
+// of x, y, x^2, y^2, xy are separable: 7-tap row sums of the 38x38 halo tile into LDS (5 x 38 x 32), then 7-tap column sums
+// per pixel -- 14 + 35 LDS reads per pixel instead of 98, 77 additions instead of 245.
 __global__ void __launch_bounds__(256)
 psnr_ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, double* __restrict__ partial,
                          int H, int W, float c1, float c2) {
     __shared__ float xs[38][39], ys[38][39];
+    __shared__ float hs[5][38][33];
     const int c = blockIdx.z, ty0 = blockIdx.y * 32, tx0 = blockIdx.x * 32;
     const float* ac = a + (int64_t)c * H * W;
     const float* bc = b + (int64_t)c * H * W;
@@ -56,6 +59,17 @@ psnr_ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ 
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
         xs[r][q] = in ? fminf(fmaxf(ac[(int64_t)gy * W + gx] * 255.f, 0.f), 255.f) : 0.f;    // tensor2im: x255, clip
         ys[r][q] = in ? fminf(fmaxf(bc[(int64_t)gy * W + gx] * 255.f, 0.f), 255.f) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 38 * 32; i += 256) {                 // row sums: hs[.][r][q] = sum_v f(r, q + v)
+        const int r = i >> 5, q = i & 31;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int v = 0; v < 7; ++v) {
+            const float x = xs[r][q + v], y = ys[r][q + v];
+            sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
+        }
+        hs[0][r][q] = sx; hs[1][r][q] = sy; hs[2][r][q] = sxx; hs[3][r][q] = syy; hs[4][r][q] = sxy;
     }
     __syncthreads();
     double se = 0.0, ss = 0.0;
@@ -68,12 +82,9 @@ psnr_ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ 
         if (gy >= 3 && gy < H - 3 && gx >= 3 && gx < W - 3) {          // crop(S, (win-1)//2)
             float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
 #pragma unroll
-            for (int u = 0; u < 7; ++u)
-#pragma unroll
-                for (int v = 0; v < 7; ++v) {
-                    const float x = xs[r + u][q + v], y = ys[r + u][q + v];
-                    sx += x; sy += y; sxx += x * x; syy += y * y; sxy += x * y;
-                }
+            for (int u = 0; u < 7; ++u) {
+                sx += hs[0][r + u][q]; sy += hs[1][r + u][q]; sxx += hs[2][r + u][q]; syy += hs[3][r + u][q]; sxy += hs[4][r + u][q];
+            }
             const float inv = 1.f / 49.f, covn = 49.f / 48.f;              // use_sample_covariance=True
             const float ux = sx * inv, uy = sy * inv;
             const float vx = covn * (sxx * inv - ux * ux), vy = covn * (syy * inv - uy * uy), vxy = covn * (sxy * inv - ux * uy);
@@ -94,19 +105,32 @@ psnr_ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ 
     }
 }
 
-__global__ void psnr_ssim_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int nblk_per_chan,
-                                        int C, int H, int W) {
-    if (threadIdx.x || blockIdx.x) return;
-    double se = 0.0, ssim = 0.0;
+// one workgroup: deterministic tree sums of the per-tile partials (a single thread walking 12 k partials took 1 ms)
+__global__ void __launch_bounds__(256)
+psnr_ssim_finish_kernel(const double* __restrict__ partial, float* __restrict__ out, int nblk_per_chan, int C, int H, int W) {
+    __shared__ double r1[256], r2[256];
+    __shared__ double se_tot, ssim_tot;
+    if (threadIdx.x == 0) { se_tot = 0.0; ssim_tot = 0.0; }
     const double valid = (double)(H - 6) * (W - 6);
     for (int c = 0; c < C; ++c) {
-        double s = 0.0;
-        for (int k = 0; k < nblk_per_chan; ++k) { se += partial[2 * ((int64_t)c * nblk_per_chan + k)]; s += partial[2 * ((int64_t)c * nblk_per_chan + k) + 1]; }
-        ssim += s / valid;                                   // per-channel mean SSIM ...
+        double se = 0.0, s = 0.0;
+        for (int k = threadIdx.x; k < nblk_per_chan; k += 256) {
+            se += partial[2 * ((int64_t)c * nblk_per_chan + k)]; s += partial[2 * ((int64_t)c * nblk_per_chan + k) + 1];
+        }
+        r1[threadIdx.x] = se; r2[threadIdx.x] = s;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if (threadIdx.x < k) { r1[threadIdx.x] += r1[threadIdx.x + k]; r2[threadIdx.x] += r2[threadIdx.x + k]; }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) { se_tot += r1[0]; ssim_tot += r2[0] / valid; }       // per-channel mean SSIM ...
+        __syncthreads();
     }
-    const double mse = se / ((double)C * H * W);
-    out[0] = (float)(10.0 * log10(255.0 * 255.0 / mse));     // peak_signal_noise_ratio(data_range=255)
-    out[1] = (float)(ssim / C);                              // ... averaged over channels
+    if (threadIdx.x == 0) {
+        const double mse = se_tot / ((double)C * H * W);
+        out[0] = (float)(10.0 * log10(255.0 * 255.0 / mse));     // peak_signal_noise_ratio(data_range=255)
+        out[1] = (float)(ssim_tot / C);                          // ... averaged over channels
+    }
 }
 
 }  // namespace
@@ -130,7 +154,7 @@ int pnnp_psnr_ssim_f32(const float* a, const float* b, float* out, int C, int H,
     const dim3 grid((W + 31) / 32, (H + 31) / 32, C);
     const float c1 = (0.01f * 255.f) * (0.01f * 255.f), c2 = (0.03f * 255.f) * (0.03f * 255.f);
     hipLaunchKernelGGL(psnr_ssim_partial_kernel, grid, dim3(256), 0, as_stream(stream), a, b, workspace, H, W, c1, c2);
-    hipLaunchKernelGGL(psnr_ssim_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, out, (int)(grid.x * grid.y), C, H, W);
+    hipLaunchKernelGGL(psnr_ssim_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, out, (int)(grid.x * grid.y), C, H, W);
     return pnnp_launch_status();
 }
 

@@ -98,3 +98,26 @@ def test_pack_raw_bayer_pattern(golden_dir):
         for clip in (True, False):
             got = P.pack_raw_bayer(raw, wp=16383, clip=clip)
             assert np.array_equal(got.view(np.uint32), g[f'prb_{name}_c{int(clip)}'].view(np.uint32)), (name, clip)
+
+
+def test_every_uint16_code_is_bit_exact():
+    """The kernel divides by the per-plane constant (wp - black) with a 3-operation correctly-rounded sequence instead of the
+    hardware's fp64 division: exhaustive check over all 65536 input codes in every Bayer position, against numpy's float64
+    division (the oracle), for the two cameras' levels, fractional biases and both clip settings; float32 inputs as well."""
+    from oracle import isp_np as O
+    from pnnp_amd import isp_ops as I
+    codes = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    raw = np.empty((512, 512), np.uint16)
+    raw[0::2, 0::2] = codes; raw[0::2, 1::2] = codes[::-1]; raw[1::2, 0::2] = codes.T; raw[1::2, 1::2] = codes[:, ::-1]
+    rng = np.random.default_rng(5)
+    for (wp, bl) in ((16383, 512), (1023, 64), (4095, 240)):
+        for bias in (np.zeros(4), rng.normal(0, 3, 4), np.array([0.1, -0.7, 1e-3, 2.5])):
+            for clip in (False, True):
+                ref = O.raw2bayer(raw, wp, bl, True, clip, bias)
+                got = I.raw2bayer(raw, wp, bl, True, clip, bias)
+                assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), (wp, bl, bias, clip)
+    f = (rng.random((256, 256)) * 20000 - 1000).astype(np.float32)
+    for bias in (np.zeros(4), np.array([0.3, -1.2, 7.7, 0.01])):
+        ref = O.raw2bayer(f, 16383, 512, True, False, bias)
+        got = I.raw2bayer(f, 16383, 512, True, False, bias)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
