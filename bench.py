@@ -66,6 +66,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=16, help='crops per GPU per step')
+    ap.add_argument('--strong', action='store_true', help='SURVEY 8(d) C4 strong scaling: --batch is the GLOBAL batch, split over the ranks')
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--arch', default='unet', choices=['unet', 'resunet'], help='resunet + --noise noiseflow = BASELINE config 5')
     ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
@@ -117,6 +118,10 @@ def main():
     ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
                       rank=rank, world=world)
     B, S = args.batch, args.size
+    if args.strong:
+        if B % world:
+            raise SystemExit(f'--strong: global batch {B} is not divisible by {world} ranks')
+        B //= world
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     hr = torch.rand(B, 4, S, S, device=dev, generator=g)          # synthetic clean crops, resident in HBM
     hr_nf = hr * 0.01                                             # dark crops for the NoiseFlow proxy (clean/gain scale)
@@ -156,7 +161,7 @@ def main():
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else "NoiseFlow.sample proxy (iso 6400, ratio in {1,2,4,8,16})") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
