@@ -46,18 +46,33 @@ def cpu_baseline(batch, H, W, seconds_hint=20.0):
     p = dict(K=1.5, sigGs=6.0, sigR=1.0, q=1 / 2 ** 14, ratio=150.0, wp=16383, bl=512, bias=0)
     pt = {k: torch.tensor(float(val)) for k, val in p.items()}
 
+    split = {}
+
     def one(b, h, w, step):
         hr = torch.rand(b, 4, h, w)
+        t0 = time.perf_counter()
         lr = torch.stack([N.generate_noisy_torch(hr[i], noise_code='pr', param=pt, ori=False, clip=2) for i in range(b)])
         lr = lr.clamp(max=1.0)
-        return O.train_step(sd, m, v, step, lr, hr, lr=1e-4)
+        split['preprocess_s'] = time.perf_counter() - t0           # the 'preprocess' bucket of trainer_SID.py:81-123
+        t0 = time.perf_counter()
+        out = O.train_step(sd, m, v, step, lr, hr, lr=1e-4)
+        split['net_bp_s'] = time.perf_counter() - t0               # its 'net' + 'bp' buckets (forward, loss, backward, Adam)
+        return out
 
     one(1, 64, 64, 1)
     t0 = time.perf_counter()
     one(batch, H, W, 2)
     dt = time.perf_counter() - t0
+    # the dataloader-side sampler (generate_noisy_obs: numpy, one core, as a DataLoader worker runs it), one crop
+    y = np.random.rand(4, H, W).astype(np.float32)
+    pn = dict(K=1.5, sigGs=6.0, sigTL=6.0, lam=0.0, sigR=1.0, q=1 / 2 ** 14, ratio=150.0, wp=16383, bl=512, bias=np.zeros(4))
+    N.generate_noisy_obs(y[:, :8, :8], param=pn, noise_code='pr', ori=False, clip=False)       # un-timed: first-call imports
+    t0 = time.perf_counter()
+    N.generate_noisy_obs(y, param=pn, noise_code='pr', ori=False, clip=False)
+    split['generate_noisy_obs_1crop_1core_s'] = time.perf_counter() - t0
     return {"value": batch / dt, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (sampler 'pr' + UNet nf=32 fwd/L1/bwd/Adam) on {batch} crops of 4x{H}x{W}, torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s"}
+            "sample": f"1 train step (sampler 'pr' + UNet nf=32 fwd/L1/bwd/Adam) on {batch} crops of 4x{H}x{W}, torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s",
+            "split": {k: round(val, 3) for k, val in split.items()}}
 
 
 def main():
