@@ -211,3 +211,43 @@ def test_fit_steps_follow_oracle_trajectory(golden_dir):
         nll.backward(); opt.step(); got.append(float(nll))
     assert got[-1] < got[0]
     np.testing.assert_allclose(got, ref, rtol=5e-4)
+
+
+def test_train_mode_edge_shapes_and_input_gradient(golden_dir):
+    """One crop, odd non-square sizes (33x47: partial tiles in both directions), and the gradient w.r.t. the noise input
+    (the backward's last dx), against autograd on the oracle.  (Non-square: both sides keep the reference's W*W log-det quirk.)"""
+    from oracle import noiseflow_torch as O
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    sd = {k: torch.from_numpy(g['sd:' + k]) for k in [str(x) for x in g['keys']]}
+    gen = torch.Generator().manual_seed(21)
+    for (B, H, W) in ((1, 33, 47), (2, 16, 16)):
+        noise = torch.randn(B, 4, H, W, generator=gen) * 0.03
+        clean = torch.rand(B, 4, H, W, generator=gen) * 0.02
+        cur = {k: v.clone() for k, v in sd.items()}
+        xin = noise.clone().requires_grad_(True)
+        rn, _ = O.loss(cur, xin, clean, torch.tensor(1000.0), training=True)
+        (rgx,) = torch.autograd.grad(rn, xin)
+        net = _net(g).train()
+        xg = noise.cuda().requires_grad_(True)
+        nll, _ = net.loss(noise=xg, clean=clean.cuda(), iso=1000.0)
+        assert abs(float(nll.detach()) - float(rn)) < 2e-5 * abs(float(rn))
+        nll.backward()
+        err = (xg.grad.cpu() - rgx).abs().max()
+        assert float(err) <= 2e-4 * float(rgx.abs().max()), (float(err), float(rgx.abs().max()))
+
+
+def test_train_pair_c_abi_rejects_bad_arguments():
+    import ctypes as C
+    from pnnp_amd import _lib
+    L = _lib.lib()
+    t = torch.zeros(4 * 32 * 32, device='cuda')
+    p = _lib.ptr(t)
+    nul = C.c_void_p(0)
+    bad = L.pnnp_nf_train_fwd_pair_f32(p, nul, nul, p, p, p, p, p, p, p, p, p, 0, 32, 32, _lib.stream())      # B = 0
+    assert bad != 0
+    bad = L.pnnp_nf_train_fwd_pair_f32(p, p, nul, p, p, p, p, p, p, p, p, p, 1, 32, 32, _lib.stream())        # clean without ab
+    assert bad != 0
+    z = torch.zeros_like(t)
+    bad = L.pnnp_nf_train_fwd_pair_f32(p, nul, nul, p, p, p, p, p, p, p, _lib.ptr(z), p, 1, 32, 32, _lib.stream())   # z aliases x
+    assert bad != 0
+    assert L.pnnp_nf_train_tiles(3, 33, 64) == 3 * 2 * 2 and L.pnnp_nf_train_pblocks(1, 32, 33) == 2
