@@ -1,0 +1,41 @@
+"""The eval loop of trainer_SID.py:208-246 end to end on the device against the same steps on the CPU oracle, same weights and
+same noisy input: net -> clamp -> IlluminanceCorrect -> tensor2im -> raw-domain PSNR / SSIM.  north_star asks for eval PSNR
+within +-0.02 dB; with identical weights the two paths agree to < 1e-3 dB, SSIM to 2e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('arch', ['unet', 'resunet'])
+def test_eval_psnr_ssim_gpu_equals_cpu_path(arch):
+    from oracle import metrics_np as M, net_torch as O
+    from pnnp_amd import process
+    from pnnp_amd.archs import ResUnet, UNetSeeInDark
+    from pnnp_amd.metrics import IlluminanceCorrect, quality_assess
+    torch.manual_seed(3); np.random.seed(3)
+    nthr = torch.get_num_threads(); torch.set_num_threads(min(nthr, 8))      # the CPU leg is small convs: more threads only add overhead
+    shapes = O.unet_param_shapes(nf=32) if arch == 'unet' else O.resunet_param_shapes(nf=32)
+    sd = O.init_state(shapes, seed=5, std=0.02)
+    sd = {k: v * 6.0 for k, v in sd.items()}                     # N(0, 0.02) weights give a dead network: make every layer matter
+    net = (UNetSeeInDark if arch == 'unet' else ResUnet)(dict(nframes=1, res=True, nf=32, in_nc=4, out_nc=4))
+    net.load_state_dict(sd); net = net.cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    hr = (torch.rand(1, 4, 192, 192, generator=g) ** 2.2) * 0.1 * 100.0 / 100.0          # dark-ish linear raw
+    hr = (hr * 8).clamp(0, 1)
+    p = process.sample_params_max('SonyA7S2', ratio=100, iso=1600)
+    lr = process.generate_noisy_torch(hr[0].cuda(), param=p, noise_code='pr', ori=False, clip=False).unsqueeze(0).clamp(0, 1)
+    with torch.no_grad():
+        dn_gpu = net(lr).clamp(0, 1)
+        dn_gpu = IlluminanceCorrect()(dn_gpu, hr.cuda())
+        res = quality_assess(dn_gpu, hr.cuda()).cpu().numpy()
+        fwd = O.unet_forward if arch == 'unet' else O.resunet_forward
+        dn_cpu = fwd(sd, lr.cpu(), res=True).clamp(0, 1)
+        dn_cpu = O.illuminance_correct(dn_cpu, hr)
+    psnr_cpu = M.psnr(M.tensor2im(hr.numpy()), M.tensor2im(dn_cpu.numpy()))
+    ssim_cpu = M.ssim(M.tensor2im(hr.numpy()), M.tensor2im(dn_cpu.numpy()))
+    assert np.isfinite(res).all() and 5.0 < psnr_cpu < 60.0
+    assert abs(float(res[0]) - psnr_cpu) < 1e-3, (float(res[0]), psnr_cpu)            # dB
+    assert abs(float(res[1]) - ssim_cpu) < 2e-5, (float(res[1]), ssim_cpu)
+    torch.set_num_threads(nthr)
