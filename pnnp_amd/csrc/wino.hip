@@ -26,6 +26,9 @@ namespace {
 #ifndef WINO_FENCED
 #define WINO_FENCED 1
 #endif
+#ifndef WINO_STEPTIME
+#define WINO_STEPTIME 0     // profiling build: clock64() at every step of chunk 2 (tools/wino_phases.py --steps)
+#endif
 constexpr int KC = 8, BN = 64, TT = 64, PATCH = 18;
 constexpr int VPLANE = TT * 4 + 32;                    // 288: the +32 keeps the two k-quads of a b128 store on disjoint banks
 constexpr int VS_STAGE = 16 * 2 * VPLANE;              // floats
@@ -176,6 +179,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     // chunk c+1, the LDS stores of U(c+1)/patch(c+2) and the global loads of U(c+2)/patch(c+3).  Past the last
     // chunk the same instructions run on clamped (valid) addresses and write LDS buffers nobody reads.
     const long long t_loop = a.dbg ? clock64() : 0;
+    long long stp[17] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int c = 0; c < nchunks; ++c) {
         const int stage = c & 1;
         const float* vb = Vs + stage * VS_STAGE + voff;
@@ -196,6 +200,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
 #define WINO_STEP(XI)                                                                                                  \
         {                                                                                                              \
             constexpr int xi = XI;                                                                                     \
+            if constexpr (WINO_STEPTIME) { if (c == 2) stp[xi] = clock64(); }                                            \
             constexpr int ur_ = (xi < 4) ? xi : ((xi >= 6 && xi < 10) ? xi - 2 : -1);    /* unit whose LDS reads go here */ \
             constexpr int uf_ = (xi >= 1 && xi < 5) ? xi - 1 : ((xi >= 7 && xi < 11) ? xi - 3 : -1);   /* unit whose fma goes here */ \
             constexpr bool out_ = (xi == 5 || xi == 11), ust_ = xi < 8, pst_ = (xi >= 12 && xi < 15);                  \
@@ -254,6 +259,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         WINO_STEP(0) WINO_STEP(1) WINO_STEP(2) WINO_STEP(3) WINO_STEP(4) WINO_STEP(5) WINO_STEP(6) WINO_STEP(7)
         WINO_STEP(8) WINO_STEP(9) WINO_STEP(10) WINO_STEP(11) WINO_STEP(12) WINO_STEP(13) WINO_STEP(14) WINO_STEP(15)
 #undef WINO_STEP
+        if constexpr (WINO_STEPTIME) { if (c == 2) stp[16] = clock64(); }
         __syncthreads();
     }
     const long long t_epi = a.dbg ? clock64() : 0;
@@ -330,6 +336,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     if (a.dbg && tid == 0) {
         long long* d = a.dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
         d[0] = t_start; d[1] = t_loop; d[2] = t_epi; d[3] = clock64();
+        if constexpr (WINO_STEPTIME) {        // second region of the buffer: 17 stamps per workgroup
+            long long* e = a.dbg + (int64_t)gridDim.x * gridDim.y * 4 + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 17;
+#pragma unroll
+            for (int i = 0; i < 17; ++i) e[i] = stp[i];
+        }
     }
 }
 
