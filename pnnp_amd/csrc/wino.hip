@@ -21,6 +21,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -81,6 +82,21 @@ __device__ __forceinline__ void input_transform(const float* __restrict__ raws, 
         *reinterpret_cast<float4*>(o + 6 * VPLANE) = f4_sub(t[1], t[3]);
     }
 }
+
+// Packed fp32 VALU (two floats of an even-aligned register pair per issue slot).  hipcc expands <4 x float> / <2 x float> fma
+// and fadd into scalar v_fma_f32 / v_add_f32 in this kernel, so the three forms the input transform needs are written out.
+// Their operands come from LDS reads or from results at least one fenced step old, and their results go to LDS stores or to a
+// later step: no back-to-back VALU dependency the hazard recogniser would have to pad.
+__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r;
+}
+__device__ __forceinline__ f32x2 pk_add2(f32x2 a, f32x2 b) { f32x2 r; asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ f32x2 pk_sub2(f32x2 a, f32x2 b) {
+    f32x2 r; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ f32x4 pk_fma(f32x4 a, f32x2 s, f32x4 b) { f32x4 r; r.lo = pk_fma2(a.lo, s, b.lo); r.hi = pk_fma2(a.hi, s, b.hi); return r; }
+__device__ __forceinline__ f32x4 pk_add(f32x4 a, f32x4 b) { f32x4 r; r.lo = pk_add2(a.lo, b.lo); r.hi = pk_add2(a.hi, b.hi); return r; }
+__device__ __forceinline__ f32x4 pk_sub(f32x4 a, f32x4 b) { f32x4 r; r.lo = pk_sub2(a.lo, b.lo); r.hi = pk_sub2(a.hi, b.hi); return r; }
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == 1) return v > 0.f ? v : 0.2f * v;
@@ -181,6 +197,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     const int it_ra = (it_i == 0) ? 0 : (it_i == 2 ? 2 : 1);
     const int it_rb = (it_i == 0) ? 2 : (it_i == 1 ? 2 : (it_i == 2 ? 1 : 3));
     const float it_sg = (it_i == 1) ? 1.f : -1.f;
+    const f32x2 it_sg2 = {it_sg, it_sg};
     const int it_a = (2 * it_ty + it_ra) * RAW_ROW + it_tx * KC + it_cg * 4;      // + item*8*RAW_ROW + column offset
     const int it_b = (2 * it_ty + it_rb) * RAW_ROW + it_tx * KC + it_cg * 4;
     const int it_o = (it_i * 8 + it_cg) * VPLANE + (it_ty * 8 + it_tx) * 4;        // + item*32*4 + j*2*VPLANE
@@ -235,17 +252,17 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, Bv.y, acc[xi], 0, 0, 0);                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, Bv.z, acc[xi], 0, 0, 0);                               \
             acc[xi] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, Bv.w, acc[xi], 0, 0, 0);                               \
-            if constexpr (uf_ >= 0) tt[uf_ & 3] = db[uf_ & 1] * it_sg + da[uf_ & 1];                                   \
+            if constexpr (uf_ >= 0) tt[uf_ & 3] = pk_fma(db[uf_ & 1], it_sg2, da[uf_ & 1]);                            \
             if constexpr (ust_) {                                           /* U(c+1) -> LDS, U(c+2) -> registers */   \
                 *reinterpret_cast<f32x4*>(usdst + (xi & 7) * 1024) = ur[xi & 7];                                       \
                 ur[xi & 7] = bload(rsu, utid, unext + (xi & 7) * 4096);                                                \
             }                                                                                                          \
             if constexpr (out_) {                                           /* outputs of item 0 / item 1 */           \
                 float* o = vdst + (xi == 11 ? 32 * 4 : 0);                                                             \
-                *reinterpret_cast<f32x4*>(o) = tt[0] - tt[2];                                                   \
-                *reinterpret_cast<f32x4*>(o + 2 * VPLANE) = tt[1] + tt[2];                                      \
-                *reinterpret_cast<f32x4*>(o + 4 * VPLANE) = tt[2] - tt[1];                                      \
-                *reinterpret_cast<f32x4*>(o + 6 * VPLANE) = tt[1] - tt[3];                                      \
+                *reinterpret_cast<f32x4*>(o) = pk_sub(tt[0], tt[2]);                                            \
+                *reinterpret_cast<f32x4*>(o + 2 * VPLANE) = pk_add(tt[1], tt[2]);                               \
+                *reinterpret_cast<f32x4*>(o + 4 * VPLANE) = pk_sub(tt[2], tt[1]);                               \
+                *reinterpret_cast<f32x4*>(o + 6 * VPLANE) = pk_sub(tt[1], tt[3]);                               \
             }                                                                                                          \
             if constexpr (pst_) {                                           /* patch(c+2) -> LDS, patch(c+3) -> registers */ \
                 constexpr int j = pst_ ? xi - 12 : 0;                                                                  \

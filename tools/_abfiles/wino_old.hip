@@ -20,6 +20,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -103,42 +104,52 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     const int y0 = tyi * 16, x0 = txi * 16;
 
     // halo patch staging slots: 18*18 pixels x 2 channel quads = 648 float4, three per thread.
-    // Out-of-image pixels load a clamped (valid) address and are zeroed by a select: no divergent branches.
-    unsigned roff0[3], roff1[3]; bool rok[3]; int rdst[3];     // unsigned: uniform base + zero-extended lane offset = saddr loads
+    // Global loads go through buffer resources (one per source image, one for this channel block's U): the lane offset is a
+    // loop-invariant 32-bit VGPR, the chunk offset an SGPR, and an out-of-image halo pixel gets an offset beyond num_records, for
+    // which the hardware returns zeros -- no per-chunk address arithmetic and no selects on the VALU (instruction count is the
+    // currency here: every non-MFMA instruction in the main loop costs ~7 cycles of matrix-pipe time).
+    constexpr unsigned OOB = 0x80000000u;              // host guarantees every image is < 2 GB
+    unsigned roff0[3], roff1[3]; int rdst[3];          // byte offsets inside image b of source 0 / 1
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         const int q = tid + 256 * s, pl = min(q >> 1, PATCH * PATCH - 1);
         const int py = pl / PATCH, px = pl % PATCH;
         const int y = y0 - 1 + py, x = x0 - 1 + px;
-        rok[s] = y >= 0 && y < a.H && x >= 0 && x < a.W;
-        const int pix = (b * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1);
-        roff0[s] = pix * a.src_cs[0] + (tid & 1) * 4;
-        roff1[s] = pix * a.src_cs[1] + (tid & 1) * 4;
+        const bool ok = y >= 0 && y < a.H && x >= 0 && x < a.W;
+        const unsigned pix = (unsigned)(y * a.W + x);
+        roff0[s] = ok ? (pix * (unsigned)a.src_cs[0] + (tid & 1) * 4) * 4u : OOB;
+        roff1[s] = ok ? (pix * (unsigned)a.src_cs[1] + (tid & 1) * 4) * 4u : OOB;
         rdst[s] = py * RAW_ROW + ((px & 1) * 9 + (px >> 1)) * KC + (tid & 1) * 4;
     }
+    const int64_t img0 = (int64_t)b * a.H * a.W;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.src[0] + img0 * a.src_cs[0]), 0, a.H * a.W * a.src_cs[0] * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)((a.src[1] ? a.src[1] : a.src[0]) + img0 * a.src_cs[1]), 0,
+                                                                         a.src[1] ? a.H * a.W * a.src_cs[1] * 4 : 0, 0x00020000);
     const int nchunks = a.K / KC;
-    const float* ug = a.u + (int64_t)nb * nchunks * US_STAGE;          // uniform; the lane offset utid is added per load
-    const unsigned utid = tid * 4;
+    const __amdgpu_buffer_rsrc_t rsu = __builtin_amdgcn_make_buffer_rsrc((void*)(a.u + (int64_t)nb * nchunks * US_STAGE), 0,
+                                                                         nchunks * US_STAGE * 4, 0x00020000);
+    const unsigned utid = tid * 16;                    // bytes
 
     f32x4 rr[3], ur[8];
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
     auto gload_raw = [&](int c) {
         const int k0 = c * KC;
-        const int s = k0 >= a.C1;
-        const float* p = (s ? a.src[1] : a.src[0]) + (k0 - (s ? a.C1 : 0));
+        const bool s = k0 >= a.C1;
+        const int so = (k0 - (s ? a.C1 : 0)) * 4;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p + (s ? roff1[j] : roff0[j]));
+        for (int j = 0; j < 3; ++j) rr[j] = bload(s ? rs1 : rs0, s ? roff1[j] : roff0[j], so);
     };
     auto gload_u = [&](int c) {
-        const float* up = ug + (int64_t)c * US_STAGE;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) ur[j] = *reinterpret_cast<const f32x4*>(up + j * 1024 + utid);
+        for (int j = 0; j < 8; ++j) ur[j] = bload(rsu, utid, (c * US_STAGE + j * 1024) * 4);
     };
     auto store_raw = [&](int buf) {
         float* r = raws + buf * RAW_FLOATS;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(r + rdst[0]) = rok[0] ? rr[0] : z;
-        *reinterpret_cast<f32x4*>(r + rdst[1]) = rok[1] ? rr[1] : z;
-        *reinterpret_cast<f32x4*>(r + rdst[2]) = rok[2] ? rr[2] : z;     // slots past the 648th duplicate the last one
+        *reinterpret_cast<f32x4*>(r + rdst[0]) = rr[0];
+        *reinterpret_cast<f32x4*>(r + rdst[1]) = rr[1];
+        *reinterpret_cast<f32x4*>(r + rdst[2]) = rr[2];                      // slots past the 648th duplicate the last one
     };
     auto store_u = [&](int stage) {
         float* us = Us + stage * US_STAGE + tid * 4;
@@ -188,10 +199,11 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
         float* vdst = Vs + (stage ^ 1) * VS_STAGE + it_o;
         float* usdst = Us + (stage ^ 1) * US_STAGE + us_w;
         float* rdstb = raws + stage * RAW_FLOATS;                    // receives patch(c+2)
-        const float* unext = ug + (int64_t)min(c + 2, nchunks - 1) * US_STAGE;
+        const int unext = min(c + 2, nchunks - 1) * (US_STAGE * 4);      // byte offset of U(c+2)
         const int k3 = min(c + 3, nchunks - 1) * KC;
-        const int s3 = k3 >= a.C1;
-        const float* rnext = (s3 ? a.src[1] : a.src[0]) + (k3 - (s3 ? a.C1 : 0));
+        const bool s3 = k3 >= a.C1;
+        const int rnext = (k3 - (s3 ? a.C1 : 0)) * 4;                   // byte offset of the channels of patch(c+3)
+        const __amdgpu_buffer_rsrc_t rs3 = s3 ? rs1 : rs0;
         f32x4 av[2], bv[2];
         f32x4 da[2], db[2], tt[4];
         av[0] = *reinterpret_cast<const f32x4*>(vb);
@@ -205,7 +217,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             constexpr int uf_ = (xi >= 1 && xi < 5) ? xi - 1 : ((xi >= 7 && xi < 11) ? xi - 3 : -1);   /* unit whose fma goes here */ \
             constexpr bool out_ = (xi == 5 || xi == 11), ust_ = xi < 8, pst_ = (xi >= 12 && xi < 15);                  \
             constexpr int n_read = (xi + 1 < 16 ? 2 : 0) + (ur_ >= 0 ? 2 : 0);                                         \
-            constexpr int n_valu = (uf_ >= 0 ? 4 : 0) + (ust_ ? 2 : 0) + (out_ ? 16 : 0) + (pst_ ? 8 : 0);             \
+            constexpr int n_valu = (uf_ >= 0 ? 4 : 0) + (ust_ ? 2 : 0) + (out_ ? 16 : 0) + (pst_ ? 1 : 0);             \
             constexpr int n_write = (ust_ ? 1 : 0) + (out_ ? 4 : 0) + (pst_ ? 1 : 0);                                  \
             constexpr int n_vmem = (ust_ ? 1 : 0) + (pst_ ? 1 : 0);                                                    \
             if constexpr (xi + 1 < 16) {                                                                               \
@@ -226,7 +238,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             if constexpr (uf_ >= 0) tt[uf_ & 3] = db[uf_ & 1] * it_sg + da[uf_ & 1];                                   \
             if constexpr (ust_) {                                           /* U(c+1) -> LDS, U(c+2) -> registers */   \
                 *reinterpret_cast<f32x4*>(usdst + (xi & 7) * 1024) = ur[xi & 7];                                       \
-                ur[xi & 7] = *reinterpret_cast<const f32x4*>(unext + (xi & 7) * 1024 + utid);                          \
+                ur[xi & 7] = bload(rsu, utid, unext + (xi & 7) * 4096);                                                \
             }                                                                                                          \
             if constexpr (out_) {                                           /* outputs of item 0 / item 1 */           \
                 float* o = vdst + (xi == 11 ? 32 * 4 : 0);                                                             \
@@ -237,9 +249,8 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
             }                                                                                                          \
             if constexpr (pst_) {                                           /* patch(c+2) -> LDS, patch(c+3) -> registers */ \
                 constexpr int j = pst_ ? xi - 12 : 0;                                                                  \
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                                  \
-                *reinterpret_cast<f32x4*>(rdstb + rdst[j]) = rok[j] ? rr[j] : z;                                       \
-                rr[j] = *reinterpret_cast<const f32x4*>(rnext + (s3 ? roff1[j] : roff0[j]));                           \
+                *reinterpret_cast<f32x4*>(rdstb + rdst[j]) = rr[j];                                                    \
+                rr[j] = bload(rs3, s3 ? roff1[j] : roff0[j], rnext);                                                   \
             }                                                                                                          \
             if constexpr (WINO_FENCED) {                                                                               \
                 __builtin_amdgcn_sched_barrier(0);      /* nothing crosses a step boundary */                          \
@@ -384,6 +395,9 @@ int wino_launch(WinoArgs& a, hipStream_t st) {
     a.dbg = g_wino_dbg;
     if (a.K % KC || a.N % BN || a.C1 % KC || (a.n_split % 32)) return PNNP_E_UNSUPPORTED;
     if ((int64_t)a.B * a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    // buffer-resource addressing: byte offsets inside one image (and inside one channel block of U) are 32-bit, 2^31 marks out-of-range
+    if ((int64_t)a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    if ((int64_t)a.K * 16 * BN * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     a.tiles_x = (a.W + 15) / 16; a.tiles_y = (a.H + 15) / 16;
     // 16-byte epilogue accesses
     if ((a.dst_cs[0] & 3) || (a.dst_cs[1] & 3) ||
