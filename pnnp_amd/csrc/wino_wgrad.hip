@@ -83,43 +83,61 @@ __global__ void __launch_bounds__(256, 1) wino_wgrad_kernel(WwArgs a) {
     // ---- staging slots: the chunk's x patch (6x10 px) and g patch (4x8 px), 64 channels each, as float4 per
     // (pixel, channel quad): 960 + 512 float4 = 4 + 2 per thread, global -> registers -> LDS.  Out-of-image x
     // pixels load a clamped address and are zeroed at the LDS store; slots past the 960th duplicate the last one.
-    int xprow[4], xpcol[4], xdst[4], gprow[2], gpcol[2], gdst[2];
+    // Loads go through buffer resources (base = the image, shifted one row + one pixel up-left for x so that chunk offsets are
+    // non-negative): lane offset = loop-invariant VGPR, chunk offset = SGPR.  A chunk's patch leaves the image only through its
+    // first/last row or column, so out-of-image lanes are four loop-invariant lane masks per slot, combined per chunk on the
+    // scalar unit; such lanes get an offset beyond num_records and the hardware returns zeros.  (Was: clamped 64-bit addresses,
+    // 16 min/max, 16 selects and ~30 address VALU per chunk -- every VALU instruction costs matrix-pipe time here.)
+    unsigned OOB = 0x80000000u;
+    asm("" : "+v"(OOB));                     // pinned in one VGPR (else re-materialised with a v_mov per use)
+    int xdst[4], gdst[2];
+    unsigned xvoff[4], gvoff[2];
+    unsigned long long m_top[4], m_bot[4], m_left[4], m_right[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const int q = min(tid + 256 * s, 959), px = q >> 4;
-        xprow[s] = px / 10; xpcol[s] = px % 10; xdst[s] = px * 64 + (q & 15) * 4;
+        const int prow = px / 10, pcol = px % 10;
+        xdst[s] = px * 64 + (q & 15) * 4;
+        xvoff[s] = (unsigned)(((prow * a.W + pcol) * xcs + (q & 15) * 4) * 4);
+        m_top[s] = __ballot(prow == 0); m_bot[s] = __ballot(prow == 5);
+        m_left[s] = __ballot(pcol == 0); m_right[s] = __ballot(pcol == 9);
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         const int q = tid + 256 * s, px = q >> 4;
-        gprow[s] = px >> 3; gpcol[s] = px & 7; gdst[s] = px * 64 + (q & 15) * 4;
+        gdst[s] = px * 64 + (q & 15) * 4;
+        gvoff[s] = (unsigned)((((px >> 3) * a.W + (px & 7)) * gcs + (q & 15) * 4) * 4);
     }
     f32x4 xr[4], gr[2];
-    bool xok[4];
     auto chunk_pos = [&](int c, int& b, int& y0, int& x0) {
         const int cx = c % a.chunks_x; c /= a.chunks_x;
         const int cy = c % a.chunks_y;
         b = c / a.chunks_y; y0 = cy * 4; x0 = cx * 8;
     };
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
     auto gload = [&](int c) {
         int b, y0, x0; chunk_pos(c, b, y0, x0);
+        const int64_t img = (int64_t)b * a.H * a.W;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(xsrc + (img - a.W - 1) * xcs), 0,
+                                                                            (a.H * a.W + a.W + 1) * xcs * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(gsrc + img * gcs), 0, a.H * a.W * gcs * 4, 0x00020000);
+        const int sx = (y0 * a.W + x0) * xcs * 4, sgo = (y0 * a.W + x0) * gcs * 4;
+        const bool top = y0 == 0, bot = y0 + 4 == a.H, left = x0 == 0, right = x0 + 8 == a.W;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int y = y0 - 1 + xprow[s], x = x0 - 1 + xpcol[s];
-            xok[s] = y >= 0 && y < a.H && x >= 0 && x < a.W;
-            const int off = ((b * a.H + min(max(y, 0), a.H - 1)) * a.W + min(max(x, 0), a.W - 1)) * xcs + (tid & 15) * 4;
-            xr[s] = *reinterpret_cast<const f32x4*>(xsrc + off);
+            const unsigned long long bad = (top ? m_top[s] : 0ull) | (bot ? m_bot[s] : 0ull) | (left ? m_left[s] : 0ull) | (right ? m_right[s] : 0ull);
+            unsigned vo;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(vo) : "v"(xvoff[s]), "v"(OOB), "s"(bad));
+            xr[s] = bload(rx, vo, sx);
         }
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int off = ((b * a.H + y0 + gprow[s]) * a.W + x0 + gpcol[s]) * gcs + (tid & 15) * 4;
-            gr[s] = *reinterpret_cast<const f32x4*>(gsrc + off);
-        }
+        for (int s = 0; s < 2; ++s) gr[s] = bload(rg, gvoff[s], sgo);
     };
     auto lstore = [&]() {
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(xraw + xdst[s]) = xok[s] ? xr[s] : z4;
+        for (int s = 0; s < 4; ++s) *reinterpret_cast<f32x4*>(xraw + xdst[s]) = xr[s];
 #pragma unroll
         for (int s = 0; s < 2; ++s) *reinterpret_cast<f32x4*>(graw + gdst[s]) = gr[s];
     };
