@@ -12,12 +12,13 @@ _i64 = C.c_int64
 # Optional per-launch timing with HIP events on the launching stream (bench.py turns it on):
 # PROFILE = [] collects (kind, algorithmic_flops, algorithmic_bytes, start_event, end_event).
 PROFILE = None
+PROFILE_KINDS = None        # None: every launch class; a set: only those (bench.py times just the dominant kernel in its timed region)
 
 
 class _Timed:
     def __init__(self, kind, flops=0.0, nbytes=0.0):
         self.rec = None
-        if PROFILE is not None:
+        if PROFILE is not None and (PROFILE_KINDS is None or kind in PROFILE_KINDS):
             self.rec = (kind, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
 
     def __enter__(self):
