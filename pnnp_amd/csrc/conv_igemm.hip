@@ -57,28 +57,41 @@ igemm_kernel(const IgemmArgs a) {
     const int G = gridDim.x;
     const int nchunks = a.nseg * a.chunks_per_seg;
     const int K4 = nchunks * KQ;                       // Ktot / 4
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(a.w);
 
     f32x4 ra[NA], rb[NB];                             // staging registers of the NEXT work item
 
-    // Per-thread constants of the staging pattern (which halo pixel / channel quad / weight slot each
-    // of this thread's float4s is): computed once, so the per-item address arithmetic is a few
-    // 32-bit multiply-adds (the host guarantees every tensor has < 2^31 elements).
-    int pa[NA], pb[NB];
+    // Per-thread constants of the staging pattern (which halo pixel / channel quad / weight slot each of this thread's
+    // float4s is), computed once.  The loads go through buffer resources: lane offset = a loop-invariant pixel index times
+    // the segment's channel stride, tile / segment / chunk offset = one SGPR, and a halo pixel outside the image (four
+    // compares against per-item scalar bounds) or an unused slot gets an offset beyond num_records, for which the hardware
+    // returns zeros.  (Was: per-load 64-bit addresses behind divergent bounds branches -- ~180 VALU instructions per chunk,
+    // which on this chip come straight out of the matrix pipe's time; now ~45.)
+    constexpr unsigned OOB = 0x80000000u;              // host guarantees image and weight offsets < 2^31 bytes
+    int rk[NA], qk[NA]; unsigned pixk[NA], cq16[NA];
 #pragma unroll
     for (int k = 0; k < NA; ++k) {
         const int i = tid + 256 * k;
         const int cq = i % KQ, pix = i / KQ;
-        const int r = pix / HC, q = pix - r * HC;
-        pa[k] = (i < Cfg::XS_F4) ? (((r - P) & 0xff) << 16) | (((q - P) & 0xff) << 8) | cq : -1;
+        const int r = pix / HC, q = pix - r * HC;       // halo-tile coordinates, 0-based
+        const bool used = i < Cfg::XS_F4;
+        rk[k] = used ? r - P : (1 << 20);               // an unused slot fails every row test
+        qk[k] = q - P;
+        pixk[k] = (unsigned)((r * a.IW + q) * a.in_mul);
+        cq16[k] = cq * 16;
     }
+    unsigned wvoff[NB]; int nk[NB];
 #pragma unroll
     for (int k = 0; k < NB; ++k) {
         const int i = tid + 256 * k;
         const int n = i % BN, rest = i / BN;
         const int cq = rest % KQ, tt = rest / KQ;
-        pb[k] = (i < Cfg::WS_F4) ? (tt * K4 + cq) * a.Ntot + n : -1;      // float4 index at chunk 0, n0 = 0
+        nk[k] = n;
+        wvoff[k] = (i < Cfg::WS_F4) ? (unsigned)(((tt * K4 + cq) * a.Ntot + n) * 16) : OOB;     // byte offset at chunk 0, n0 = 0
     }
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
 
     struct Tile { int b, y0, x0, n0; };
     auto decode = [&](int t) {                          // scalar divisions: once per tile, not per chunk
@@ -94,23 +107,25 @@ igemm_kernel(const IgemmArgs a) {
     auto prefetch = [&](const Tile& tl, int si, int cc, int g) {
         const IgemmSeg sg = a.seg[si];
         const int c0 = sg.coff + cc * KC;
-        const int rowbase = tl.b * a.IH;
+        const int mul = a.in_mul, sh = mul - 1;         // in_mul is 1 or 2: ceil(n / mul) == (n + sh) >> sh
+        // input pixel of halo coordinate (r, q) (relative to the tile, -P based) is ((y0 + r) * mul + yoff, (x0 + q) * mul + xoff)
+        const int rlo = ((-sg.yoff + sh) >> sh) - tl.y0, rhi = ((a.IH - sg.yoff + sh) >> sh) - tl.y0;
+        const int qlo = ((-sg.xoff + sh) >> sh) - tl.x0, qhi = ((a.IW - sg.xoff + sh) >> sh) - tl.x0;
+        // the resource starts `shift` elements before the image so that the scalar offset below is never negative
+        const int shift = ((P * mul + 1) * a.IW + P * mul + 1) * sg.cstride;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(sg.ptr + ((int64_t)tl.b * a.IH * a.IW * sg.cstride - shift)), 0, 0x7fffffff, 0x00020000);
+        const int soff = ((((tl.y0 - P) * mul + sg.yoff) * a.IW + (tl.x0 - P) * mul + sg.xoff) * sg.cstride + c0 + shift) * 4;
+        const unsigned cs4 = (unsigned)sg.cstride * 4u;
 #pragma unroll
         for (int k = 0; k < NA; ++k) {
-            const int r = (int)(signed char)(pa[k] >> 16), q = (int)(signed char)(pa[k] >> 8), cq = pa[k] & 0xff;
-            const int gy = (tl.y0 + r) * a.in_mul + sg.yoff, gx = (tl.x0 + q) * a.in_mul + sg.xoff;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pa[k] >= 0 && gy >= 0 && gy < a.IH && gx >= 0 && gx < a.IW)
-                v = *reinterpret_cast<const f32x4*>(sg.ptr + (((rowbase + gy) * a.IW + gx) * sg.cstride + c0 + 4 * cq));
-            ra[k] = v;
+            const bool ok = rk[k] >= rlo && rk[k] < rhi && qk[k] >= qlo && qk[k] < qhi;
+            ra[k] = bload(rs, ok ? __umul24(pixk[k], cs4) + cq16[k] : OOB, soff);
         }
-        const int wb = g * KQ * a.Ntot + tl.n0;
+        const int wso = (g * KQ * a.Ntot + tl.n0) * 16;
+        const int nlim = a.Ntot - tl.n0;
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (pb[k] >= 0 && tl.n0 + (tid + 256 * k) % BN < a.Ntot) v = w4[wb + pb[k]];
-            rb[k] = v;
-        }
+        for (int k = 0; k < NB; ++k) rb[k] = bload(rsw, nk[k] < nlim ? wvoff[k] : OOB, wso);
     };
 
     f32x16 acc[MT][NT];
@@ -389,8 +404,12 @@ int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_
     if ((a.Ntot & 3) || (a.dst_cs[0] & 3) || (a.dst[1] && ((a.dst_cs[1] & 3) || (a.n_split & 3)))) return PNNP_E_UNSUPPORTED;
     if ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) |
          ((uintptr_t)a.addsrc)) & 15) return PNNP_E_INVALID;
-    for (int i = 0; i < a.nseg; ++i)                         // 32-bit element offsets when staging
+    for (int i = 0; i < a.nseg; ++i) {                       // 32-bit element offsets when staging
         if ((int64_t)a.B * a.IH * a.IW * a.seg[i].cstride >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+        // buffer-resource addressing: byte offsets inside one image (+ a (P*mul+1)-row shift) must stay below 2^31
+        if (((int64_t)a.IH + 4) * a.IW * a.seg[i].cstride * 4 >= (1ll << 31) || a.in_mul < 1 || a.in_mul > 2) return PNNP_E_UNSUPPORTED;
+        if (a.seg[i].yoff < -1 || a.seg[i].xoff < -1) return PNNP_E_UNSUPPORTED;
+    }
     for (int d = 0; d < 2; ++d)                              // 32-bit element offsets in the epilogue
         if (a.dst[d] && (int64_t)a.B * a.OH * a.OW * a.dst_cs[d] >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     IgemmArgs b = a;
