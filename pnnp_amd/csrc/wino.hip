@@ -317,7 +317,8 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     }
     const int cq = lane & 7;                                           // channel quad of this lane (fixed over the 16 rows it handles)
     const int n4 = nb * BN + wn * 32 + cq * 4;
-    const int d = (a.n_split > 0 && n4 >= a.n_split) ? 1 : 0;         // wave-uniform: n_split is a multiple of 32
+    // wave-uniform (n_split is a multiple of 32): readfirstlane tells the compiler so, else the buffer resources below are 'divergent'
+    const int d = __builtin_amdgcn_readfirstlane((a.n_split > 0 && n4 >= a.n_split) ? 1 : 0);
     const int nc = n4 - (d ? a.n_split : 0);
     float* dst = d ? a.dst[1] : a.dst[0];
     const int dcs = d ? a.dst_cs[1] : a.dst_cs[0];
@@ -325,41 +326,46 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     const int mmode = d ? a.mask_mode[1] : a.mask_mode[0], accum = d ? a.accum[1] : a.accum[0];
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + n4);
-    const int64_t img = (int64_t)b * a.H * a.W;
-    int64_t off[16]; bool ok[16];
+    // Epilogue traffic through buffer resources on image b of the destination geometry: a lane whose pixel is outside the image
+    // gets an out-of-range offset (loads return zeros, stores are dropped), so there is no per-store branch and no 64-bit address
+    // arithmetic; the activation is branch-free (max(v, slope*v) covers none / LeakyReLU / ReLU with slope 1 / 0.2 / 0).
+    const int64_t img = (int64_t)b * a.H * a.W * dcs;
+    const int ibytes = a.H * a.W * dcs * 4;
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(dst + img), 0, ibytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)((mmode ? mask : dst) + img), 0, ibytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)((a.addsrc ? a.addsrc : dst) + img), 0, ibytes, 0x00020000);
+    unsigned off[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int q = (k * 64 + lane) >> 3;                            // patch row = tile * 4 + sub-pixel
         const int m = wm * 32 + (q >> 2), p = q & 3;
         const int y = y0 + 2 * (m >> 3) + (p >> 1), x = x0 + 2 * (m & 7) + (p & 1);
-        ok[k] = y < a.H && x < a.W;
-        off[k] = (img + (int64_t)min(y, a.H - 1) * a.W + min(x, a.W - 1)) * dcs + nc;
+        off[k] = (y < a.H && x < a.W) ? (unsigned)(((y * a.W + x) * dcs + nc) * 4) : 0x80000000u;
     }
     f32x4 mk[16], ad[16];                                              // batched: one HBM latency for all 16
     if (mmode) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) mk[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(mask + off[k]));
+        for (int k = 0; k < 16; ++k) mk[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, off[k], 0, 0));
     }
     if (a.addsrc) {
 #pragma unroll
-        for (int k = 0; k < 16; ++k) ad[k] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.addsrc + off[k]));
+        for (int k = 0; k < 16; ++k) ad[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, off[k], 0, 0));
     }
     const float slope = mmode == 1 ? 0.2f : 0.f;
+    const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int q = (k * 64 + lane) >> 3;
         f32x4 v = *reinterpret_cast<const f32x4*>(T + q * TSTR + cq * 4) + bias4;
         if (a.addsrc) v += ad[k];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) v[c] = act_fn(v[c], a.act);
+        for (int c = 0; c < 4; ++c) v[c] = fmaxf(v[c], aslope * v[c]);
         if (mmode) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) v[c] *= (mk[k][c] > 0.f) ? 1.f : slope;
         }
-        if (ok[k]) {
-            if (accum) v += *reinterpret_cast<const f32x4*>(dst + off[k]);
-            *reinterpret_cast<f32x4*>(dst + off[k]) = v;
-        }
+        if (accum) v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, off[k], 0, 0));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rd, off[k], 0, 0);
     }
     if (a.dbg && tid == 0) {
         long long* d = a.dbg + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * 4;
