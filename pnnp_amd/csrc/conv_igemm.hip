@@ -223,6 +223,7 @@ igemm_kernel(const IgemmArgs a) {
             const float* mask_any = a.mask_mode[0] ? a.mask[0] : a.mask[1];
             const float* accum_any = a.accum[0] ? a.dst[0] : a.dst[1];
             const int q4 = (lane & 7) * 4, pr = lane >> 3;
+            const bool uni = (a.n_split & 31) == 0 && (a.n_sub & 31) == 0;      // kernel-uniform
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int n = n0 + (wn * NT + k) * 32 + q4;             // first of this lane's 4 channels
@@ -250,7 +251,64 @@ igemm_kernel(const IgemmArgs a) {
                         eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][r];
                         acc[i][k][r] = 0.f;
                     }
-                    if (py < a.DH && oy >= 0 && oy < a.OH) {
+                    if (uni) {
+                        // Fast path (n_split / n_sub multiples of 32: destination, sub-pixel and channel base are the same for the
+                        // whole wave): buffer-resource loads and stores on image b of the destination -- a lane outside the tile
+                        // domain / image gets an out-of-range offset (loads return zeros, stores are dropped), so there are no
+                        // per-store branches and no 64-bit addresses -- and a branch-free activation.
+                        const int nwv = __builtin_amdgcn_readfirstlane(n0 + (wn * NT + k) * 32);
+                        const int du = nwv >= a.n_split ? 1 : 0;
+                        const int subu = a.n_sub ? nwv / a.n_sub : 0;
+                        const int chw = nwv - subu * a.n_sub - (du ? a.n_split : 0);
+                        const int yo2 = a.out_yoff + (subu >> 1), xo2 = a.out_xoff + (subu & 1);
+                        const int cs2 = a.dst_cs[du], mm2 = a.mask_mode[du], acc2 = a.accum[du];
+                        const int oy2 = py * a.out_mul + yo2;
+                        const bool rowok = py < a.DH && oy2 >= 0 && oy2 < a.OH;
+                        const int64_t imgo = (int64_t)b * a.OH * a.OW * cs2;
+                        const int ibytes = a.OH * a.OW * cs2 * 4;
+                        float* dstb = a.dst[du] + imgo;
+                        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dstb, 0, ibytes, 0x00020000);
+                        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(mm2 ? a.mask[du] + imgo : dstb), 0, ibytes, 0x00020000);
+                        const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)((a.addsrc && du == 0) ? a.addsrc + imgo : dstb), 0, ibytes, 0x00020000);
+                        const bool use_add2 = a.addsrc && du == 0;
+                        unsigned vo[4];
+                        f32x4 v2[4], m2[4], ad2[4];
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            const int p = pr + 8 * it, px = x0 + p;
+                            const int oxp = px * a.out_mul + xo2;
+                            const bool ok2 = rowok && px < a.DW && n_ok && oxp >= 0 && oxp < a.OW;
+                            vo[it] = ok2 ? (unsigned)(((oy2 * a.OW + oxp) * cs2 + chw + q4) * 4) : 0x80000000u;
+                            v2[it] = *reinterpret_cast<const f32x4*>(eb + p * 32 + q4);
+                        }
+                        if (mm2) {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) m2[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, vo[it], 0, 0));
+                        }
+                        if (use_add2) {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) ad2[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, vo[it], 0, 0));
+                        }
+                        if (acc2) {
+#pragma unroll
+                            for (int it = 0; it < 4; ++it) ad2[it] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vo[it], 0, 0));
+                        }
+                        const f32x4 bias4 = {bias.x, bias.y, bias.z, bias.w};
+                        const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f), mslope = mm2 == 1 ? 0.2f : 0.f;
+#pragma unroll
+                        for (int it = 0; it < 4; ++it) {
+                            f32x4 o = v2[it] + bias4;
+                            if (use_add2) o += ad2[it];
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+                            if (mm2) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[c] *= (m2[it][c] > 0.f) ? 1.f : mslope;
+                            }
+                            if (acc2) o += ad2[it];
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[it], 0, 0);
+                        }
+                    } else if (py < a.DH && oy >= 0 && oy < a.OH) {
                         // Epilogue loads are issued under WAVE-UNIFORM conditions (kernel arguments) and from
                         // always-valid addresses (offset 0 for lanes that do not take part), never under a
                         // per-lane branch: a per-element "load or not" makes hipcc branch around every load and

@@ -22,6 +22,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct IgemmSeg {
     const float* ptr;   // NHWC tensor [B][IH][IW][cstride]
