@@ -144,6 +144,26 @@ int pnnp_conv3x3_wino_bwd_data_f32(const float* g, int Cout, const float* u_dgra
                                    int B, int H, int W, void* stream);
 /* Winograd backward-weight (dg = G^T [sum_tiles (A dY A^T) (.) (B^T d B)] G): same contract as
  * pnnp_conv_bwd_weight_f32 with taps = 9; needs H % 4 == 0, W % 8 == 0 and Cout, C1, C2 multiples of 64. */
+/* ---------------------------------------------------------------- weight re-packing, batched (csrc/pack_jobs.hip)
+ * The optimiser moves every weight every step (trainer_SID.py:101), so every layer's packed images are rebuilt every step.  A job
+ * is one such rebuild; pnnp_pack_jobs_f32 runs a HOST array of jobs in ceil(n / 32) launches.  The builders append the jobs of one
+ * layer (the same ones pnnp_pack_conv_weight_f32 / pnnp_pack_convt_weight_f32 / pnnp_pack_conv_weight_wino_f32 run): build the
+ * table once, run it once per step.  kind 0 = strided gather, kind 1 = Winograd filter transform (K = Cout, N = Cin, T = dgrad). */
+typedef struct PnnpPackJob {
+    const float* src; float* dst;
+    int kind, T, K, N;
+    int64_t sk, sn, st, off;
+    int flip, Kvalid, Ndst, n_off;
+} PnnpPackJob;
+int pnnp_pack_jobs_f32(const PnnpPackJob* jobs /*[host]*/, int n, void* stream);
+int pnnp_pack_jobs_add_conv(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
+                            int Cout, int Cin, int taps, int Cin_pad, int Cout_pad);
+int pnnp_pack_jobs_add_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
+                             int Cin, int Cout);
+int pnnp_pack_jobs_add_wino(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
+                            int Cout, int Cin);
+int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const float* w, float* dst, int Cout, int Cin);
+
 /* Profiling hook of the Winograd forward / backward-data kernel (no reference counterpart): every later launch writes per-workgroup
  * clock64() stamps at entry, main-loop entry, epilogue entry and exit to buf[4*workgroup .. +3]; null switches it off. */
 int pnnp_wino_set_debug(long long* buf);

@@ -67,8 +67,17 @@ class ResUnetEngine:
         return self.packed[k]
 
     def pack_weights(self, train):
+        """Re-pack every layer's weights for the kernels; the job table is built once per device / mode / parameter storage
+        and runs in a few launches per step (ops.PackJobs)."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
+        key = (dev, train, os.environ.get('PNNP_WINO', '1'), os.environ.get('PNNP_WINO_MINK', '32'), tuple(p.data_ptr() for p in P.values()))
+        if getattr(self, '_jobs_key', None) != key:
+            self._jobs, self._jobs_key = self._build_pack_jobs(train, dev, P), key
+        self._jobs.run()
+
+    def _build_pack_jobs(self, train, dev, P):
+        jobs = ops.PackJobs(cap=512)
         W = {}
         self.WU = {}
         def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True):
@@ -80,11 +89,11 @@ class ResUnetEngine:
             wf, wd = self._wino(co, ci, t)
             wd = wd and train and dgrad
             if not wf or (d is not None and not wd):
-                ops.pack_conv_weight(w, None if wf else f, d if not wd else None, cin_pad=cin_pad, cout_pad=cout_pad)
+                jobs.add_conv(w, None if wf else f, d if not wd else None, cin_pad=cin_pad, cout_pad=cout_pad)
             uf = self._buf(name + ':uf', 16 * co * ci, dev) if wf else None
             ud = self._buf(name + ':ud', 16 * co * ci, dev) if wd else None
             if wf or wd:
-                ops.pack_conv_weight_wino(w, uf, ud)
+                jobs.add_wino(w, uf, ud)
             W[name] = (f, d)
             self.WU[name] = (uf, ud)
         conv('conv_in', 'conv_in.weight', cin_pad=self.cin_pad, dgrad=False)
@@ -96,20 +105,21 @@ class ResUnetEngine:
         for l in range(1, 5):
             w = P[f'pool{l}.conv.weight']
             f = self._buf(f'pool{l}:f', w.numel(), dev)
-            ops.pack_conv_weight(w, f, None)
+            jobs.add_conv(w, f, None)
             d = None
             if train:
                 d = self._buf(f'pool{l}:d', w.numel(), dev)
-                ops.pack_conv_s2_dgrad(w, d)
+                jobs.add_s2_dgrad(w, d)
             W[f'pool{l}'] = (f, d)
         for i in range(6, 10):
             w = P[f'upv{i}.weight']
             f = self._buf(f'upv{i}:f', w.numel(), dev)
             d = self._buf(f'upv{i}:d', w.numel(), dev) if train else None
-            ops.pack_convt_weight(w, f, d)
+            jobs.add_convt(w, f, d)
             W[f'upv{i}'] = (f, d)
         conv('conv10', 'conv10.weight', cout_pad=self.cout_pad)
         self.W = W
+        return jobs
 
     @staticmethod
     def _wino(co, ci, taps=9):

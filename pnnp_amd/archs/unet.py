@@ -93,10 +93,19 @@ class UNetEngine:
         return ['conv%d_%d' % (i, j) for i in range(1, 10) for j in (1, 2)] + ['conv10_1']
 
     def pack_weights(self, need_dgrad):
-        """Re-pack every layer's weights into the kernels' K-major order (device side,
-        a few tiny launches); called once per forward because the optimiser has moved them."""
+        """Re-pack every layer's weights into the kernels' K-major order; called once per forward because the optimiser has
+        moved them.  The table of pack jobs is built once (per device / mode / parameter storage) and runs in two or three
+        launches (ops.PackJobs) instead of ~70."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
+        key = (dev, need_dgrad, os.environ.get('PNNP_WINO', '1'), os.environ.get('PNNP_WINO_MINK', '32'),
+               tuple(p.data_ptr() for p in P.values()))
+        if getattr(self, '_jobs_key', None) != key:
+            self._jobs, self._jobs_key = self._build_pack_jobs(need_dgrad, dev, P), key
+        self._jobs.run()
+
+    def _build_pack_jobs(self, need_dgrad, dev, P):
+        jobs = ops.PackJobs()
         for name in self._conv_names():
             w = P[name + '.weight']
             co, ci, kh, kw = w.shape
@@ -110,14 +119,14 @@ class UNetEngine:
             f, d = self.packed[key]
             wf, wd = self._wino(name, co, ci, taps)
             if not (wf and (wd or not need_dgrad)):
-                ops.pack_conv_weight(w, None if wf else f, d if (need_dgrad and not wd) else None, cin_pad=cip, cout_pad=cop)
+                jobs.add_conv(w, None if wf else f, d if (need_dgrad and not wd) else None, cin_pad=cip, cout_pad=cop)
             if wf or (wd and need_dgrad):
                 wkey = (name, dev, 'wino')
                 if wkey not in self.packed:
                     self.packed[wkey] = (torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wf else None,
                                          torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wd else None)
                 uf, ud = self.packed[wkey]
-                ops.pack_conv_weight_wino(w, uf, ud if need_dgrad else None)
+                jobs.add_wino(w, uf, ud if need_dgrad else None)
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
             key = (name, dev)
@@ -125,7 +134,8 @@ class UNetEngine:
                 self.packed[key] = (torch.empty(w.numel(), dtype=torch.float32, device=dev),
                                     torch.empty(w.numel(), dtype=torch.float32, device=dev))
             f, d = self.packed[key]
-            ops.pack_convt_weight(w, f, d if need_dgrad else None)
+            jobs.add_convt(w, f, d if need_dgrad else None)
+        return jobs
 
     def _w(self, name):
         return self.packed[(name, self.params.flat.device)]

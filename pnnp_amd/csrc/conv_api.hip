@@ -8,30 +8,13 @@ namespace {
 
 // dst[((t*K/4 + k/4)*N + n)*4 + k%4] = src[off + k*sk + n*sn + tap(t)*st],  tap(t) = flip ? T-1-t : t
 // rows k >= Kvalid are zero (channel padding of the 4-channel network input / output).
-__global__ void __launch_bounds__(256)
-pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int T, int K, int N,
-                    int64_t sk, int64_t sn, int64_t st, int64_t off, int flip, int Kvalid, int Ndst, int n_off) {
-    const int64_t total = (int64_t)T * K * N;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int kr = (int)(i & 3);
-        int64_t r = i >> 2;
-        const int n = (int)(r % N); r /= N;
-        const int kq = (int)(r % (K >> 2));
-        const int t = (int)(r / (K >> 2));
-        const int k = kq * 4 + kr;
-        const int ts = flip ? T - 1 - t : t;
-        dst[(((int64_t)t * (K >> 2) + kq) * Ndst + n_off + n) * 4 + kr] = k < Kvalid ? src[off + k * sk + n * sn + ts * st] : 0.f;
-    }
-}
-
 int pack_launch(const float* src, float* dst, int T, int K, int N, int64_t sk, int64_t sn, int64_t st, int64_t off,
                 int flip, void* stream, int Kvalid = 1 << 30, int Ndst = 0, int n_off = 0) {
     if (!src || !dst || T <= 0 || K <= 0 || N <= 0 || (K & 3)) return PNNP_E_INVALID;
-    const int64_t total = (int64_t)T * K * N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, dst, T, K, N, sk, sn, st, off, flip, Kvalid, Ndst ? Ndst : N, n_off);
-    return pnnp_launch_status();
+    PnnpPackJob j{};
+    j.src = src; j.dst = dst; j.kind = 0; j.T = T; j.K = K; j.N = N; j.sk = sk; j.sn = sn; j.st = st; j.off = off;
+    j.flip = flip; j.Kvalid = Kvalid; j.Ndst = Ndst ? Ndst : N; j.n_off = n_off;
+    return pnnp_pack_jobs_f32(&j, 1, stream);           // one job through the batched kernel (csrc/pack_jobs.hip)
 }
 
 void base_args(IgemmArgs& a) {

@@ -1,0 +1,169 @@
+// Weight re-packing as ONE launch per optimiser step.  The optimiser moves every weight every step, so every layer's packed
+// images (direct forward / backward-data order, Winograd U = G g G^T forward / backward-data) are rebuilt each step: ~70
+// launches of 4-8 us each when done layer by layer (0.38 ms of a 30 ms step).  Here a launch takes a table of jobs (a kernel
+// argument, <= 32 per launch) and every workgroup finds its job from a prefix of block counts.
+//   job kind 0: strided gather  dst[((t*(K/4)+kq)*Ndst + n_off + n)*4 + kr] = src[off + k*sk + n*sn + ts*st]  (k < Kvalid else 0)
+//   job kind 1: Winograd filter transform into the kernel's chunked order (csrc/wino.hip)
+// The builders below produce exactly the jobs the per-layer entry points used to launch (same formulas, same layouts).
+#include "common.h"
+
+namespace {
+
+constexpr int W_KC = 8, W_BN = 64, W_UPLANE = W_BN * 4, W_US_STAGE = 16 * 2 * W_UPLANE;   // csrc/wino.hip (static_assert there)
+constexpr int MAXJ = 32;
+
+struct JobTable { int n; int blk_end[MAXJ]; PnnpPackJob job[MAXJ]; };
+
+__device__ __forceinline__ void gather_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ src = j.src; float* __restrict__ dst = j.dst;
+    const int T = j.T, K = j.K, N = j.N;
+    const int64_t total = (int64_t)T * K * N;
+    for (int64_t i = blk * 256 + threadIdx.x; i < total; i += (int64_t)nblk * 256) {
+        const int kr = (int)(i & 3);
+        int64_t r = i >> 2;
+        const int n = (int)(r % N); r /= N;
+        const int kq = (int)(r % (K >> 2));
+        const int t = (int)(r / (K >> 2));
+        const int k = kq * 4 + kr;
+        const int ts = j.flip ? T - 1 - t : t;
+        dst[(((int64_t)t * (K >> 2) + kq) * j.Ndst + j.n_off + n) * 4 + kr] = k < j.Kvalid ? src[j.off + k * j.sk + n * j.sn + ts * j.st] : 0.f;
+    }
+}
+
+// U = G g G^T of every (k, n) filter, written in the Winograd kernel's chunked order [N/64][K/8][16][2][64][4].
+//   forward:  g[a][b] = w[n][k][a][b]        (w [Cout][Cin][3][3], K = Cin, N = Cout)
+//   dgrad:    g[a][b] = w[k][n][2-a][2-b]    (K = Cout, N = Cin)
+__device__ __forceinline__ void wino_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ w = j.src; float* __restrict__ u = j.dst;
+    const int Cout = j.K, Cin = j.N, dgrad = j.T;
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int64_t total = (int64_t)K * N;
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
+        const int n = (int)(t % N), k = (int)(t / N);
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                g[r][c] = dgrad ? w[((int64_t)k * Cin + n) * 9 + (2 - r) * 3 + (2 - c)] : w[((int64_t)n * Cin + k) * 9 + r * 3 + c];
+        float gg[4][3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            gg[0][c] = g[0][c];
+            gg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
+            gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
+            gg[3][c] = g[2][c];
+        }
+        const int nb = n / W_BN, nn = n % W_BN, kc = k / W_KC, kg = (k % W_KC) / 4, e = k % 4;
+        float* o = u + ((int64_t)nb * (K / W_KC) + kc) * W_US_STAGE + (kg * W_BN + nn) * 4 + e;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float uu[4] = {gg[i][0], 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]), 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]), gg[i][2]};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[(i * 4 + q) * 2 * W_UPLANE] = uu[q];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
+    int j = 0;
+    while (j + 1 < tb.n && (int)blockIdx.x >= tb.blk_end[j]) ++j;          // uniform: <= 32 scalar compares
+    const int b0 = j ? tb.blk_end[j - 1] : 0;
+    const int nblk = tb.blk_end[j] - b0;
+    const PnnpPackJob& job = tb.job[j];
+    if (job.kind == 1) wino_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else gather_job(job, (int64_t)blockIdx.x - b0, nblk);
+}
+
+int job_blocks(const PnnpPackJob& j) {
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (int64_t)j.T * j.K * j.N;
+    int64_t b = (total + 255) / 256;
+    const int64_t cap = j.kind == 1 ? 4096 : 2048;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+bool push(PnnpPackJob* jobs, int* n, int cap, const PnnpPackJob& j) {
+    if (*n >= cap) return false;
+    jobs[(*n)++] = j;
+    return true;
+}
+
+PnnpPackJob gather(const float* src, float* dst, int T, int K, int N, int64_t sk, int64_t sn, int64_t st, int64_t off, int flip,
+                   int Kvalid = 1 << 30, int Ndst = 0, int n_off = 0) {
+    PnnpPackJob j{};
+    j.src = src; j.dst = dst; j.kind = 0; j.T = T; j.K = K; j.N = N; j.sk = sk; j.sn = sn; j.st = st; j.off = off;
+    j.flip = flip; j.Kvalid = Kvalid; j.Ndst = Ndst ? Ndst : N; j.n_off = n_off;
+    return j;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Run `n` pack jobs (HOST array) in ceil(n / 32) launches on `stream`.
+int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
+    if (n < 0 || (n && !jobs)) return PNNP_E_INVALID;
+    for (int i0 = 0; i0 < n; i0 += MAXJ) {
+        JobTable tb{};
+        tb.n = n - i0 < MAXJ ? n - i0 : MAXJ;
+        int blocks = 0;
+        for (int i = 0; i < tb.n; ++i) {
+            const PnnpPackJob& j = jobs[i0 + i];
+            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3)))) return PNNP_E_INVALID;
+            tb.job[i] = j;
+            blocks += job_blocks(j);
+            tb.blk_end[i] = blocks;
+        }
+        hipLaunchKernelGGL(pack_jobs_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), tb);
+    }
+    return pnnp_launch_status();
+}
+
+// Builders: append the jobs of one layer to jobs[0..cap) (HOST array), *n is advanced.  Null destinations are skipped.
+// Conv2d weight [Cout][Cin][kh][kw] -> direct forward / backward-data packs (see pnnp_pack_conv_weight_f32).
+int pnnp_pack_jobs_add_conv(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd, float* dgrad, int Cout, int Cin, int taps,
+                            int Cin_pad, int Cout_pad) {
+    if (!jobs || !n || !w || Cin_pad < Cin || Cout_pad < Cout) return PNNP_E_INVALID;
+    bool ok = true;
+    if (fwd) ok = ok && push(jobs, n, cap, gather(w, fwd, taps, Cin_pad, Cout, taps, (int64_t)Cin * taps, 1, 0, 0, Cin));
+    if (dgrad) ok = ok && push(jobs, n, cap, gather(w, dgrad, taps, Cout_pad, Cin, (int64_t)Cin * taps, taps, 1, 0, 1, Cout));
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+// ConvTranspose2d weight [Cin][Cout][2][2] (see pnnp_pack_convt_weight_f32).
+int pnnp_pack_jobs_add_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd, float* dgrad, int Cin, int Cout) {
+    if (!jobs || !n || !w) return PNNP_E_INVALID;
+    bool ok = true;
+    for (int s = 0; s < 4; ++s) {
+        if (fwd) ok = ok && push(jobs, n, cap, gather(w, fwd, 1, Cin, Cout, (int64_t)Cout * 4, 4, 0, s, 0, 1 << 30, 4 * Cout, s * Cout));
+        if (dgrad) ok = ok && push(jobs, n, cap, gather(w, dgrad + (int64_t)s * Cout * Cin, 1, Cout, Cin, 4, (int64_t)Cout * 4, 0, s, 0));
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+// Winograd filter transforms of a 3x3 Conv2d weight (see pnnp_pack_conv_weight_wino_f32).
+int pnnp_pack_jobs_add_wino(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd, float* dgrad, int Cout, int Cin) {
+    if (!jobs || !n || !w || Cout <= 0 || Cin <= 0) return PNNP_E_INVALID;
+    if ((fwd && (Cin % W_KC || Cout % W_BN)) || (dgrad && (Cout % W_KC || Cin % W_BN))) return PNNP_E_UNSUPPORTED;
+    bool ok = true;
+    for (int d = 0; d < 2; ++d) {
+        float* dst = d ? dgrad : fwd;
+        if (!dst) continue;
+        PnnpPackJob j{};
+        j.src = w; j.dst = dst; j.kind = 1; j.T = d; j.K = Cout; j.N = Cin;
+        ok = ok && push(jobs, n, cap, j);
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+// Backward-data weights of the stride-2 3x3 conv (see pnnp_pack_conv3x3s2_dgrad_f32): 9 slices ordered by input-pixel parity class.
+int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const float* w, float* dst, int Cout, int Cin) {
+    if (!jobs || !n || !w || !dst) return PNNP_E_INVALID;
+    static const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};          // S2_TAP_ORDER of csrc/conv_api.hip
+    bool ok = true;
+    for (int i = 0; i < 9; ++i)
+        ok = ok && push(jobs, n, cap, gather(w, dst + (int64_t)i * Cout * Cin, 1, Cout, Cin, (int64_t)Cin * 9, 9, 0, order[i], 0));
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+}  // extern "C"

@@ -378,39 +378,7 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
     }
 }
 
-// U = G g G^T of every (k, n) filter, written in the kernel's chunked order [N/64][K/8][16][2][64][4].
-//   forward:  g[a][b] = w[n][k][a][b]        (w [Cout][Cin][3][3], K = Cin, N = Cout)
-//   dgrad:    g[a][b] = w[k][n][2-a][2-b]    (K = Cout, N = Cin)
-__global__ void __launch_bounds__(256)
-wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int Cout, int Cin, int dgrad) {
-    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const int64_t total = (int64_t)K * N;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int n = (int)(t % N), k = (int)(t / N);
-        float g[3][3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r)
-#pragma unroll
-            for (int c = 0; c < 3; ++c)
-                g[r][c] = dgrad ? w[((int64_t)k * Cin + n) * 9 + (2 - r) * 3 + (2 - c)] : w[((int64_t)n * Cin + k) * 9 + r * 3 + c];
-        float gg[4][3];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            gg[0][c] = g[0][c];
-            gg[1][c] = 0.5f * (g[0][c] + g[1][c] + g[2][c]);
-            gg[2][c] = 0.5f * (g[0][c] - g[1][c] + g[2][c]);
-            gg[3][c] = g[2][c];
-        }
-        const int nb = n / BN, nn = n % BN, kc = k / KC, kg = (k % KC) / 4, e = k % 4;
-        float* o = u + ((int64_t)nb * (K / KC) + kc) * US_STAGE + (kg * BN + nn) * 4 + e;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float uu[4] = {gg[i][0], 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]), 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]), gg[i][2]};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[(i * 4 + j) * 2 * UPLANE] = uu[j];
-        }
-    }
-}
+static_assert(KC == 8 && BN == 64 && UPLANE == 256 && US_STAGE == 8192, "csrc/pack_jobs.hip restates the U layout");
 
 long long* g_wino_dbg = nullptr;       // set by pnnp_wino_set_debug; profiling only
 
@@ -448,18 +416,9 @@ int64_t pnnp_wino_weight_floats(int Cout, int Cin) { return (int64_t)16 * Cout *
 int pnnp_wino_supported(int K, int N) { return (K % KC == 0 && N % BN == 0) ? 1 : 0; }
 
 int pnnp_pack_conv_weight_wino_f32(const float* w, float* fwd, float* dgrad, int Cout, int Cin, void* stream) {
-    if (!w || Cout <= 0 || Cin <= 0) return PNNP_E_INVALID;
-    const int64_t total = (int64_t)Cout * Cin;
-    const unsigned blocks = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
-    if (fwd) {
-        if (Cin % KC || Cout % BN) return PNNP_E_UNSUPPORTED;
-        hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, fwd, Cout, Cin, 0);
-    }
-    if (dgrad) {
-        if (Cout % KC || Cin % BN) return PNNP_E_UNSUPPORTED;
-        hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), w, dgrad, Cout, Cin, 1);
-    }
-    return pnnp_launch_status();
+    PnnpPackJob jobs[2]; int n = 0;
+    const int rc = pnnp_pack_jobs_add_wino(jobs, &n, 2, w, fwd, dgrad, Cout, Cin);      // the filter transform lives in csrc/pack_jobs.hip
+    return rc != PNNP_OK ? rc : pnnp_pack_jobs_f32(jobs, n, stream);
 }
 
 // y = act(conv3x3(cat[x1,x2]) + bias), same contract as pnnp_conv_fwd_f32 with taps = 9.

@@ -47,6 +47,48 @@ def pack_conv_weight(w, fwd, dgrad, cin_pad=None, cout_pad=None):
                                             cin_pad or ci, cout_pad or co, stream()), 'pack_conv_weight')
 
 
+class PackJob(C.Structure):                      # PnnpPackJob of include/pnnp_hip.h
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int), ('T', C.c_int), ('K', C.c_int), ('N', C.c_int),
+                ('sk', C.c_int64), ('sn', C.c_int64), ('st', C.c_int64), ('off', C.c_int64),
+                ('flip', C.c_int), ('Kvalid', C.c_int), ('Ndst', C.c_int), ('n_off', C.c_int)]
+
+
+class PackJobs:
+    """A table of weight re-pack jobs (csrc/pack_jobs.hip): filled once per model / device with the add_* builders, run once
+    per optimiser step in ceil(n / 32) launches instead of one or two launches per layer.  The tensors whose pointers are
+    recorded must stay alive and in place (parameters as views of the flat buffer, the persistent packed buffers)."""
+
+    def __init__(self, cap=256):
+        self.cap = cap
+        self.jobs = (PackJob * cap)()
+        self.n = C.c_int(0)
+        self.keep = []                           # the tensors behind the recorded pointers
+
+    def add_conv(self, w, fwd, dgrad, cin_pad=None, cout_pad=None):
+        co, ci, kh, kw = w.shape
+        check(_prep().pnnp_pack_jobs_add_conv(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci, kh * kw,
+                                              cin_pad or ci, cout_pad or co), 'pack_jobs_add_conv')
+        self.keep += [w, fwd, dgrad]
+
+    def add_convt(self, w, fwd, dgrad):
+        ci, co = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_convt(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), ci, co), 'pack_jobs_add_convt')
+        self.keep += [w, fwd, dgrad]
+
+    def add_wino(self, w, fwd, dgrad):
+        co, ci = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_wino(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci), 'pack_jobs_add_wino')
+        self.keep += [w, fwd, dgrad]
+
+    def add_s2_dgrad(self, w, dst):
+        co, ci = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_conv3x3s2_dgrad(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(dst), co, ci), 'pack_jobs_add_s2_dgrad')
+        self.keep += [w, dst]
+
+    def run(self):
+        check(_prep().pnnp_pack_jobs_f32(self.jobs, self.n.value, stream()), 'pack_jobs')
+
+
 def pack_convt_weight(w, fwd, dgrad):
     ci, co = w.shape[:2]
     check(_prep().pnnp_pack_convt_weight_f32(ptr(w), ptr(fwd), ptr(dgrad), ci, co, stream()), 'pack_convt_weight')
