@@ -193,7 +193,7 @@ int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const 
 int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, float* dx, int Cin,
                                const float* mask, int mode, int B, int H, int W, void* stream);
 int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Cout, float* dW,
-                                 float* dbias_unused, int B, int H, int W, int accumulate,
+                                 float* dbias /*[Cout] = channel sums of g, or null*/, int B, int H, int W, int accumulate,
                                  float* workspace, int64_t workspace_floats, void* stream);
 /* Conv2d 3x3 stride 2 pad 1 (ResUnet down-sampling `conv3x3`, archs/modules.py:130-138,
  * archs/ResUnet.py:18-27): x [B][H][W][Cin] <-> y [B][H/2][W/2][Cout].  forward takes the ordinary

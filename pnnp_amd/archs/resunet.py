@@ -239,8 +239,7 @@ class ResUnetEngine:
             self._dg(f'b{i}_0', g_t, g_u, dx2=g_skip)
             ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
-            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc)
-            ops.channel_sum(g_u, G(f'upv{i}.bias'), wsf, accumulate=acc)
+            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
             ops.convt_bwd_data(g_u, W[f'upv{i}'][1], g)

@@ -271,8 +271,8 @@ class UNetEngine:
             g_skip = gb(f'c{lvl + 1}', skip.shape)
             dgrad(f'conv{i}_1', g_a, g_u, dx2=g_skip, mask2=skip, mode2=LRELU)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
-            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc)
-            ops.channel_sum(g_u, G(f'upv{i}.bias', (ch[lvl],)), wsf, accumulate=acc)
+            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc,
+                                 dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
             ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)

@@ -28,7 +28,8 @@ struct WgradArgs {
     int B, DH, DW;
     int M, N;
     float* slab;                        // [Z][M][N][TAPS]
-    float* bias_slab;                   // [Z][M] or null
+    float* bias_slab;                   // [Z][M] or null: sum of U over the pixels (bias gradient of a Conv2d)
+    float* bias_slab_n;                 // [Z][N] or null: sum of S over the pixels (TAPS == 4: bias gradient of a ConvTranspose2d)
     int Z;
 };
 
@@ -75,7 +76,9 @@ wgrad_kernel(const WgradArgs a) {
     for (int t = 0; t < TAPS; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    float bsum = 0.f;
+    float bsum = 0.f, bsn = 0.f;
+    // every S pixel is visited exactly once per (pixel pair, tap) when TAPS == 4; only one M block / M wave adds it up
+    const float bsn_w = (TAPS == 4 && a.bias_slab_n && mi == 0 && wmo == 0) ? 1.f : 0.f;
 
     // staging registers of the NEXT pixel tile (its loads fly while this tile's MFMAs run)
     constexpr int NU = (Cfg::US_F / 4 + 255) / 256, NS = (Cfg::SS_F / 4 + 255) / 256;
@@ -143,6 +146,7 @@ wgrad_kernel(const WgradArgs a) {
                     else if (TAPS == 4) sp = (2 * r + (t >> 1)) * SC + 2 * p + (t & 1);
                     else sp = r * SC + p;
                     const float bv = ss[sp * BNO + wno * 32 + l31];
+                    if (TAPS == 4) bsn = fmaf(bsn_w, bv, bsn);
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                 }
             }
@@ -192,6 +196,20 @@ wgrad_kernel(const WgradArgs a) {
         }
         const int m = m0 + wmo * 32 + l31;
         if (wno == 0 && wk == 0 && half == 0 && m < a.M) a.bias_slab[(int64_t)z * a.M + m] = bsum;
+    }
+    if (TAPS == 4 && a.bias_slab_n && mi == 0) {         // block-uniform
+        bsn += __shfl_xor(bsn, 32);
+        if (WK > 1) {
+            __syncthreads();
+            if (half == 0) red[wave * 32 + l31] = bsn;
+            __syncthreads();
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < WK; ++k) s += red[((wave - wk) + k) * 32 + l31];
+            bsn = s;
+        }
+        const int n = n0 + wno * 32 + l31;
+        if (wmo == 0 && wk == 0 && half == 0 && n < a.N) a.bias_slab_n[(int64_t)z * a.N + n] = bsn;
     }
 }
 
@@ -304,7 +322,7 @@ int pnnp_wgrad_splits(int B, int H, int W, int M, int N, int taps) {
 
 int64_t pnnp_wgrad_workspace_floats(int B, int H, int W, int M, int N, int taps) {
     const int64_t z = pnnp_wgrad_splits(B, H, W, M, N, taps);
-    return z * ((int64_t)M * N * (taps == 18 ? 9 : taps) + M);
+    return z * ((int64_t)M * N * (taps == 18 ? 9 : taps) + (M > N ? M : N));
 }
 
 // dW (+ optional dbias) of Conv2d 3x3 / 1x1 (taps = 9 / 1):
@@ -354,12 +372,15 @@ int pnnp_convt2x2_bwd_weight_f32(const float* x, int Cin, const float* g, int Co
     a.s_mul = 2; a.SH = 2 * H; a.SW = 2 * W; a.B = B; a.DH = H; a.DW = W; a.M = Cin; a.N = Cout;
     a.Z = pnnp_wgrad_splits(B, H, W, Cin, Cout, 4);
     a.slab = workspace; a.bias_slab = nullptr;
+    a.bias_slab_n = dbias ? workspace + (int64_t)a.Z * Cin * Cout * 4 : nullptr;      // dbias = sum of g, gathered while g is staged anyway
     int rc = launch_shape<4>(a, pick_shape(Cin, Cout), as_stream(stream));
     if (rc != PNNP_OK) return rc;
     const int64_t n = (int64_t)Cin * Cout * 4;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0,
                        as_stream(stream), a.slab, dW, n, a.Z, accumulate, (int64_t)a.M * a.N, (int)(n / ((int64_t)a.M * a.N)));
-    (void)dbias;   // the bias gradient of a ConvTranspose2d is a plain channel sum: pnnp_channel_sum_f32
+    if (dbias)
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, as_stream(stream), a.bias_slab_n, dbias,
+                           (int64_t)Cout, a.Z, accumulate, (int64_t)Cout, 1);
     return pnnp_launch_status();
 }
 

@@ -213,11 +213,12 @@ def convt_bwd_data(g, w_dgrad, dx, mask=None, mode=0):
                                                  stream()), 'convt_bwd_data')
 
 
-def convt_bwd_weight(x, g, dW, ws, accumulate=0):
-    require_cuda(x, g, dW, ws)
+def convt_bwd_weight(x, g, dW, ws, accumulate=0, dbias=None):
+    """dW (and dbias = the channel sums of g, gathered by the same kernel while g is staged) of ConvTranspose2d(k2, s2)."""
+    require_cuda(x, g, dW, ws, dbias)
     B, H, W, Cin = x.shape
     with _Timed('convt_wgrad', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
-        check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), None, B, H, W, accumulate,
+        check(_prep().pnnp_convt2x2_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), ptr(dbias), B, H, W, accumulate,
                                                    ptr(ws), _i64(ws.numel()), stream()), 'convt_bwd_weight')
 
 

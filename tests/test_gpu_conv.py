@@ -183,6 +183,13 @@ def test_convt(case):
     ops.channel_sum(nhwc(g).cuda(), db, ws)
     close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'convT wgrad {case}')
     close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'convT bgrad {case}')
+    # the bias gradient fused into the weight-gradient kernel (what the engines use), with and without accumulation
+    dW2 = torch.full(w.shape, float('nan'), device='cuda'); db2 = torch.full((Co,), float('nan'), device='cuda')
+    ops.convt_bwd_weight(nhwc(x.detach()).cuda(), nhwc(g).cuda(), dW2, ws, dbias=db2)
+    close(dW2, w.grad, rtol=2e-4, atol=2e-5, what=f'convT wgrad+bias {case}')
+    close(db2, b.grad, rtol=2e-4, atol=2e-5, what=f'convT fused bgrad {case}')
+    ops.convt_bwd_weight(nhwc(x.detach()).cuda(), nhwc(g).cuda(), dW2, ws, accumulate=1, dbias=db2)
+    close(db2, 2 * b.grad, rtol=2e-4, atol=4e-5, what=f'convT fused bgrad accumulate {case}')
 
 
 @pytest.mark.parametrize('case', [(1, 8, 32, 8, 16), (2, 16, 64, 32, 64), (1, 12, 40, 64, 128), (1, 6, 70, 128, 256),
