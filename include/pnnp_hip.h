@@ -212,6 +212,11 @@ int pnnp_conv3x3s2_bwd_weight_f32(const float* g, int Cout, const float* x, int 
 int pnnp_maxpool2_fwd_f32(const float* x, float* y, int B, int H, int W, int C, void* stream);
 int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int H, int W, int C,
                           int act_mode, int accumulate, void* stream);
+/* The same pair with a one-byte code per pooled element (bits 0-1: first maximum of the window, bits 2-5: sign of its four
+ * elements) written by the forward pass, so that the backward pass needs gy and the codes only (no second read of x). */
+int pnnp_maxpool2_fwd_codes_f32(const float* x, float* y, unsigned char* codes /*[B][H/2][W/2][C]*/, int B, int H, int W, int C, void* stream);
+int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                                int accumulate, void* stream);
 /* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);
  * the NCHW result can add a residual (arch 'res' flag, archs/Unet.py:95-98). */
 int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);

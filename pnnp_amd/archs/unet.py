@@ -200,7 +200,14 @@ class UNetEngine:
             a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             if lvl < 4:
-                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])))
+                codes = None
+                if train:                          # argmax + sign codes: the backward pass then does not re-read the full-resolution map
+                    codes = bufs.t.get(f'pc{i}')
+                    shp = (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])
+                    if codes is None or tuple(codes.shape) != shp or codes.device != dev:
+                        codes = bufs.t[f'pc{i}'] = torch.empty(shp, dtype=torch.uint8, device=dev)
+                    a[f'pc{i}'] = codes
+                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])), codes=codes)
                 cur = a[f'p{i}']
         cur = a['c5']
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
@@ -288,7 +295,7 @@ class UNetEngine:
                 g_p = gb(f'p{i - 1}', src.shape)
                 dgrad(f'conv{i}_1', g_a, g_p)
                 g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
-                ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1)
+                ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1, codes=a.get(f'pc{i - 1}'))
             else:
                 wgrad('conv1_1', g_a, ch[0], a['x8'], self.cin)
                 if need_dx:

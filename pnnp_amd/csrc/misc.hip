@@ -116,6 +116,82 @@ maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, fl
     }
 }
 
+// The same pair with a one-byte code per pooled element written by the forward pass -- bits 0-1: position of the window's
+// first maximum, bits 2-5: sign (> 0) of the four window elements -- so that the backward pass does not have to read the
+// full-resolution activation again (it is 1/3 of that kernel's HBM traffic): gx is fully determined by gy and the code.
+__global__ void __launch_bounds__(256)
+maxpool_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ codes, int B, int H, int W, int C) {
+    const int h = H / 2, w = W / 2, cq = C / 4;
+    const int64_t total = (int64_t)B * h * w * cq;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        int64_t p = i / cq;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int64_t b = p / h;
+        const float* s = x + ((b * H + 2 * oy) * W + 2 * ox) * C + c;
+        const int64_t off[4] = {0, (int64_t)C, (int64_t)W * C, (int64_t)W * C + C};
+        float xv[4][4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(s + off[k]);
+            xv[k][0] = t.x; xv[k][1] = t.y; xv[k][2] = t.z; xv[k][3] = t.w;
+        }
+        float m[4]; unsigned code = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int arg = 0; float best = xv[0][j];
+#pragma unroll
+            for (int k = 1; k < 4; ++k) if (xv[k][j] > best) { best = xv[k][j]; arg = k; }   // first max wins (as in the backward kernel above)
+            unsigned cj = (unsigned)arg;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cj |= (xv[k][j] > 0.f ? 1u : 0u) << (2 + k);
+            m[j] = fmaxf(fmaxf(xv[0][j], xv[1][j]), fmaxf(xv[2][j], xv[3][j]));
+            code |= cj << (8 * j);
+        }
+        const int64_t o = ((b * h + oy) * w + ox) * C + c;
+        *reinterpret_cast<float4*>(y + o) = make_float4(m[0], m[1], m[2], m[3]);
+        *reinterpret_cast<unsigned*>(codes + o) = code;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+maxpool_bwd_codes_kernel(const unsigned char* __restrict__ codes, const float* __restrict__ gy, float* __restrict__ gx,
+                         int B, int H, int W, int C, int act_mode, int accumulate) {
+    const int h = H / 2, w = W / 2, cq = C / 4;
+    const int64_t total = (int64_t)B * h * w * cq;
+    const float slope = act_mode == 1 ? 0.2f : (act_mode == 2 ? 0.f : 1.f);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        int64_t p = i / cq;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int64_t b = p / h;
+        const int64_t base = ((b * H + 2 * oy) * W + 2 * ox) * C + c, po = ((b * h + oy) * w + ox) * C + c;
+        const int64_t off[4] = {0, (int64_t)C, (int64_t)W * C, (int64_t)W * C + C};
+        const unsigned code = *reinterpret_cast<const unsigned*>(codes + po);
+        const float4 g4 = *reinterpret_cast<const float4*>(gy + po);
+        const float g[4] = {g4.x, g4.y, g4.z, g4.w};
+        float o[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned cj = (code >> (8 * j)) & 0xffu, arg = cj & 3u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = ((cj >> (2 + k)) & 1u) ? 1.f : slope;
+                o[k][j] = ((unsigned)k == arg) ? g[j] * d : 0.f;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float4* d = reinterpret_cast<float4*>(gx + base + off[k]);
+            float4 v = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
+            if (accumulate) { const float4 t = *d; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            *d = v;
+        }
+    }
+}
+
 // per-channel sum over pixels of an NHWC tensor: partial[blockIdx][C] then a fixed-order finish
 __global__ void __launch_bounds__(256)
 channel_sum_partial_kernel(const float* __restrict__ x, float* __restrict__ partial, int64_t npix, int C) {
@@ -275,6 +351,24 @@ int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int
     if (B == 0) return PNNP_OK;
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream),
                        x, gy, gx, B, H, W, C, act_mode, accumulate);
+    return pnnp_launch_status();
+}
+
+// MaxPool2d(2) forward that also writes the one-byte codes [B][H/2][W/2][C] for pnnp_maxpool2_bwd_codes_f32.
+int pnnp_maxpool2_fwd_codes_f32(const float* x, float* y, unsigned char* codes, int B, int H, int W, int C, void* stream) {
+    if (!x || !y || !codes || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 3)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(maxpool_fwd_codes_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream), x, y, codes, B, H, W, C);
+    return pnnp_launch_status();
+}
+
+// Backward of the pool (+ the activation in front of it) from the codes: same result as pnnp_maxpool2_bwd_f32 without reading x.
+int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                                int accumulate, void* stream) {
+    if (!codes || !gy || !gx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 3)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    hipLaunchKernelGGL(maxpool_bwd_codes_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream),
+                       codes, gy, gx, B, H, W, C, act_mode, accumulate);
     return pnnp_launch_status();
 }
 

@@ -253,17 +253,25 @@ def conv_s2_bwd_weight(g, x, dW, dbias, ws, accumulate=0):
                                                     ptr(ws), _i64(ws.numel()), stream()), 'conv3x3s2_bwd_weight')
 
 
-def maxpool_fwd(x, y):
-    require_cuda(x, y)
+def maxpool_fwd(x, y, codes=None):
+    """MaxPool2d(2); with ``codes`` (uint8 [B,H/2,W/2,C]) it also records argmax + signs for maxpool_bwd(codes=...)."""
+    require_cuda(x, y, codes)
     B, H, W, Cc = x.shape
-    check(_prep().pnnp_maxpool2_fwd_f32(ptr(x), ptr(y), B, H, W, Cc, stream()), 'maxpool_fwd')
+    if codes is not None:
+        check(_prep().pnnp_maxpool2_fwd_codes_f32(ptr(x), ptr(y), ptr(codes), B, H, W, Cc, stream()), 'maxpool_fwd_codes')
+    else:
+        check(_prep().pnnp_maxpool2_fwd_f32(ptr(x), ptr(y), B, H, W, Cc, stream()), 'maxpool_fwd')
     return y
 
 
-def maxpool_bwd(x, gy, gx, act_mode, accumulate):
-    require_cuda(x, gy, gx)
+def maxpool_bwd(x, gy, gx, act_mode, accumulate, codes=None):
+    """gx (+)= routed(gy) * act'(x); with the forward pass's ``codes`` the full-resolution x is not read again."""
+    require_cuda(x, gy, gx, codes)
     B, H, W, Cc = x.shape
-    check(_prep().pnnp_maxpool2_bwd_f32(ptr(x), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd')
+    if codes is not None:
+        check(_prep().pnnp_maxpool2_bwd_codes_f32(ptr(codes), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd_codes')
+    else:
+        check(_prep().pnnp_maxpool2_bwd_f32(ptr(x), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd')
 
 
 def nchw_to_nhwc(src, dst, cp):

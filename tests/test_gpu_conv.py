@@ -241,6 +241,15 @@ def test_maxpool_loss_adam():
     gx = nhwc(base).cuda().clone()
     ops.maxpool_bwd(actd, nhwc(gy).cuda(), gx, 1, 1)
     close(nchw(gx), base + xr.grad, what='maxpool bwd (+lrelu derivative, accumulate)')
+    # the same through the one-byte argmax / sign codes written by the forward pass (no second read of the activation)
+    codes = torch.empty((B, H // 2, W // 2, Cc), dtype=torch.uint8, device='cuda')
+    yo2 = torch.empty_like(yo); ops.maxpool_fwd(actd, yo2, codes=codes)
+    assert torch.equal(yo2, yo)
+    for mode, accum in ((1, 1), (1, 0), (2, 1), (0, 0)):
+        ga = nhwc(base).cuda().clone(); gb_ = nhwc(base).cuda().clone()
+        ops.maxpool_bwd(actd, nhwc(gy).cuda(), ga, mode, accum)
+        ops.maxpool_bwd(actd, nhwc(gy).cuda(), gb_, mode, accum, codes=codes)
+        assert torch.equal(ga, gb_), (mode, accum)
     # L1(clamp) loss + gradient + per-crop SSE
     pred = (_rand(3, 4, 16, 24, seed=4) * 0.8 + 0.5).requires_grad_(True); hr = _rand(3, 4, 16, 24, seed=5) * 0.5 + 0.5
     loss = F.l1_loss(pred.clamp(0, 1), hr); loss.backward()
