@@ -164,9 +164,9 @@ int pnnp_pack_jobs_add_wino(PnnpPackJob* jobs, int* n, int cap, const float* w, 
                             int Cout, int Cin);
 int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const float* w, float* dst, int Cout, int Cin);
 
-/* Profiling hook of the Winograd forward / backward-data kernel (no reference counterpart): every later launch writes per-workgroup
- * clock64() stamps at entry, main-loop entry, epilogue entry and exit to buf[4*workgroup .. +3]; null switches it off. */
-int pnnp_wino_set_debug(long long* buf);
+/* (The Winograd kernel's cycle-stamp hook `pnnp_wino_set_debug` exists only in profiling builds, -DPNNP_WINO_DEBUG=1: the shipped
+ * library exports no debug hook, reads no environment variable and keeps no state between calls besides idempotent per-device
+ * caches of device facts.) */
 int pnnp_wino_wgrad_supported(int H, int W, int Cout, int C1, int C2);
 int64_t pnnp_wino_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
 int pnnp_conv3x3_wino_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
@@ -231,6 +231,10 @@ int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int ac
  * workspace >= 128*B floats. */
 int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc, float* loss_out,
                            int B, int C, int H, int W, int Cp, float* workspace, void* stream);
+/* the same with the `ori` branch of the train loop (trainer_SID.py:97-99: pred = pred * ratio before the loss):
+ * scale [B] (device, or null = 1) multiplies crop b's prediction first; loss, SSE and dL/dpred (x scale[b]) follow. */
+int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale /*[B] or null*/, float* grad_nhwc,
+                                  float* loss_out, int B, int C, int H, int W, int Cp, float* workspace, void* stream);
 /* torch.optim.Adam step (trainer_SID.py:44,101) over a flat parameter buffer; step is 1-based;
  * grad_scale is applied to g first (1/world_size after a sum all-reduce). */
 int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -81,6 +81,26 @@ def init_state(shapes, seed=0, std=0.02):
     return {k: torch.randn(v, generator=g) * std for k, v in shapes.items()}
 
 
+def init_state_he(shapes, seed=0, bias_std=0.02, res_scale=1.0):
+    """Variance-preserving weights (std = sqrt(1.92 / fan_in), the LeakyReLU(0.2) gain) so that a 10-level nf=32 network
+    keeps O(1) activations and live gradients in every layer -- N(0, 0.02) gives a nearly dead net at full depth.  Used by
+    the 512x512 backward golden (ResUnet: res_scale = 0.25) (tests/golden/make_golden.py `nets512`) and the test that replays it."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in shapes.items():
+        if k.endswith('.weight'):
+            if k.startswith('upv'):                 # ConvTranspose2d [Cin][Cout][2][2] k2 s2: one tap per output pixel
+                fan_in = v[0]
+            else:
+                fan_in = v[1] * v[2] * v[3]
+            out[k] = torch.randn(v, generator=g) * (1.92 / fan_in) ** 0.5
+            if '.block.1.' in k:                    # second conv of a ResidualBlock: keep the residual sum from growing
+                out[k] = out[k] * res_scale
+        else:
+            out[k] = torch.randn(v, generator=g) * bias_std
+    return out
+
+
 # --------------------------------------------------------------------------- UNet
 def _lrelu(x):
     return F.leaky_relu(x, 0.2)

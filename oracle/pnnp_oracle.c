@@ -93,7 +93,9 @@ static float poisson(float lam, uint32_t elem, const ctx_t* c, uint32_t r0, uint
     if (lam < 10.f) {                       /* sequential inversion on one uniform */
         const float u = unit(r0);
         float p = expf(-lam), s = p, k = 0.f;
-        while (u > s && k < 200.f) { k += 1.f; p *= lam / k; s += p; }
+        /* the float32 CDF can saturate below the largest uniform (1 - 2^-24); without the s2 == s exit the loop would
+           run on to a cap and return a far-out hot pixel about once per 1e7 dark pixels */
+        while (u > s) { k += 1.f; p *= lam / k; const float s2 = s + p; if (s2 == s) break; s = s2; }
         return k;
     }
     /* Hoermann PTRS */

@@ -12,14 +12,12 @@ Reference quirks kept: ``conv3x3`` attaches its ReLU as a child of nn.Conv2d, wh
 """
 from collections import OrderedDict
 
-import os
-
 import torch
 import torch.nn as nn
 
 from .. import ops
 from .._lib import PnnpError
-from .unet import FlatParams, _Bufs, RELU
+from .unet import FlatParams, _Bufs, _EngineBase, RELU
 
 
 class _ConvHolder(nn.Module):      # modules.py:140-153 convWithBN(is_bn=False): .conv = Sequential(conv=Conv2d(bias=False))
@@ -41,15 +39,13 @@ class _DownHolder(nn.Module):      # modules.py:130-138 conv3x3(stride=2)
         self.conv = nn.Conv2d(ci, co, kernel_size=3, padding=1, stride=2)
 
 
-class ResUnetEngine:
+class ResUnetEngine(_EngineBase):
     def __init__(self, module):
+        self._init_base()
         self.m = module
         self.params = FlatParams(module)
         self.bufs = {}
         self.packed = {}
-        self.saved = None
-        self._pack_key = None
-        self._dirty_epoch = 0
         nf = module.nf
         if nf % 8:
             raise PnnpError('ResUnet on HIP needs nf % 8 == 0')
@@ -71,8 +67,8 @@ class ResUnetEngine:
         and runs in a few launches per step (ops.PackJobs)."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
-        key = (dev, train, os.environ.get('PNNP_WINO', '1'), os.environ.get('PNNP_WINO_MINK', '32'), tuple(p.data_ptr() for p in P.values()))
-        if getattr(self, '_jobs_key', None) != key:
+        key = (dev, train, self.policy.key(), tuple(p.data_ptr() for p in P.values()))
+        if self._jobs_key != key:
             self._jobs, self._jobs_key = self._build_pack_jobs(train, dev, P), key
         self._jobs.run()
 
@@ -121,13 +117,9 @@ class ResUnetEngine:
         self.W = W
         return jobs
 
-    @staticmethod
-    def _wino(co, ci, taps=9):
-        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  Same rule as the UNet engine."""
-        if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
-            return False, False
-        mink = int(os.environ.get('PNNP_WINO_MINK', '32'))
-        return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
+    def _wino(self, co, ci, taps=9):
+        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  Same rule as the UNet engine (self.policy)."""
+        return self.policy.use_wino(co, ci, taps)
 
     def _cf(self, name, src, src2, bias, out, cout, act, residual=None):
         """3x3 forward: Winograd kernel where packed for it, else the direct implicit GEMM."""
@@ -141,10 +133,6 @@ class ResUnetEngine:
         if u is not None:
             return ops.conv_wino_bwd_data(gsrc, u, dx1, **kw)
         return ops.conv_bwd_data(gsrc, self.W[name][1], dx1, **kw)
-
-    def mark_dirty(self):
-        """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
-        self._dirty_epoch += 1
 
     # ---------------------------------------------------------------- forward
     def forward(self, x, train):
@@ -162,6 +150,7 @@ class ResUnetEngine:
         if key != self._pack_key:
             self.pack_weights(train)
             self._pack_key = key
+        gen = self._begin_forward((B, H, Wd, dev), train)
         bufs = self.bufs.setdefault((B, H, Wd, dev), _Bufs())
         P = dict(self.m.named_parameters())
         ch, W = self.ch, self.W
@@ -195,12 +184,12 @@ class ResUnetEngine:
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
-            self.saved = (a, (B, H, Wd, dev))
+            self.saved = (a, (B, H, Wd, dev), gen)
         return out
 
     # ---------------------------------------------------------------- backward
     def backward(self, g_out8, need_dx=False, accumulate=False, on_ready=None):
-        a, (B, H, Wd, dev) = self.saved
+        a, (B, H, Wd, dev), _ = self.saved
         bufs = self.bufs[(B, H, Wd, dev)]
         ch, W = self.ch, self.W
         gb = lambda n, like: bufs.get('g_' + n, like.shape, dev)
@@ -215,8 +204,7 @@ class ResUnetEngine:
 
         def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
             c2 = x2.shape[3] if x2 is not None else 0
-            if (taps == 9 and os.environ.get('PNNP_WINO', '1') != '0' and os.environ.get('PNNP_WINO_WGRAD', '1') != '0'
-                    and gpre.shape[3] == cout and x1.shape[3] == c1 and ops.wino_wgrad_supported(gpre.shape[1], gpre.shape[2], cout, c1, c2)):
+            if taps == 9 and self.policy.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             else:
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
@@ -291,13 +279,14 @@ class _ResUnetFn(torch.autograd.Function):
     def forward(ctx, x, engine, train, *params):
         ctx.engine = engine
         ctx.x_needs = x.requires_grad
-        return engine.forward(x, train)
+        out = engine.forward(x, train)
+        ctx.gen = engine.gen
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         e = ctx.engine
-        if e.saved is None:
-            raise PnnpError('backward without a training-mode forward')
+        e.check_saved(ctx.gen)
         B, _, H, W = grad_out.shape
         bufs = e.bufs[(B, H, W, grad_out.device)]
         g8 = ops.nchw_to_nhwc(grad_out.contiguous().float(), bufs.get('g_out8', (B, H, W, e.cout_pad), grad_out.device), e.cout_pad)

@@ -19,6 +19,69 @@ from .._lib import PnnpError
 LRELU, RELU = 1, 2
 
 
+class ConvPolicy:
+    """Which kernel family a 3x3 layer runs on.  ``wino``: Winograd F(2x2,3x3) forward / backward-data where the layer
+    qualifies (channels written % 64 == 0, reduction >= ``wino_mink`` channels), ``wino_wgrad``: the Winograd
+    backward-weight kernel likewise; everything else (and everything when both are off) uses the direct implicit-GEMM
+    kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
+    families against each other at full size)."""
+
+    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32):
+        self.wino, self.wino_wgrad, self.wino_mink = bool(wino), bool(wino_wgrad), int(wino_mink)
+
+    def key(self):
+        return (self.wino, self.wino_wgrad, self.wino_mink)
+
+    def use_wino(self, co, ci, taps=9):
+        """(forward, backward-data) of a Conv2d(ci -> co, taps) on the Winograd kernel?"""
+        if taps != 9 or not self.wino:
+            return False, False
+        return (ops.wino_supported(ci, co) and ci >= self.wino_mink, ops.wino_supported(co, ci) and co >= self.wino_mink)
+
+    def use_wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
+        return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
+
+
+DEFAULT_POLICY = ConvPolicy(wino=os.environ.get('PNNP_WINO', '1') != '0')      # host-side default only; the library reads no environment
+
+
+class _EngineBase:
+    """What the two network engines share: the kernel-family policy and the bookkeeping that ties an autograd backward to
+    the training forward whose activations it needs."""
+
+    def _init_base(self):
+        self.policy = ConvPolicy(*DEFAULT_POLICY.key())
+        self.saved = None
+        self.gen = 0                 # bumped by every forward that (re)writes an activation buffer set
+        self._pack_key = None
+        self._jobs_key = None
+        self._dirty_epoch = 0
+
+    def set_policy(self, policy=None, **kw):
+        self.policy = policy if policy is not None else ConvPolicy(**kw)
+        self._pack_key = None        # re-pack for the other kernel family
+        self._jobs_key = None
+
+    def mark_dirty(self):
+        """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
+        self._dirty_epoch += 1
+
+    def _begin_forward(self, key, train):
+        """Activation buffers are per input shape and reused: a later forward on the same shape overwrites what an earlier
+        training forward saved for its backward.  Every forward gets a generation number; `saved` remembers the one it
+        belongs to and is dropped when its buffers are about to be overwritten by a forward that does not replace it."""
+        self.gen += 1
+        if self.saved is not None and self.saved[1] == key and not train:
+            self.saved = None
+        return self.gen
+
+    def check_saved(self, gen):
+        if self.saved is None or self.saved[2] != gen:
+            raise PnnpError('backward: the activations of this forward were overwritten by a later forward on the same input shape '
+                            '(the HIP engine keeps ONE saved forward per shape: run backward before the next forward, '
+                            'or accumulate gradients step by step)')
+
+
 class FlatParams:
     """All parameters (and their gradients) of a module as views of two flat fp32 buffers,
     16-byte aligned per tensor: one fused Adam launch and one (bucketed) all-reduce."""
@@ -68,17 +131,15 @@ class _Bufs:
         return b
 
 
-class UNetEngine:
+class UNetEngine(_EngineBase):
     """Forward / backward schedule of UNetSeeInDark over the C-ABI layer kernels."""
 
     def __init__(self, module):
+        self._init_base()
         self.m = module
         self.params = FlatParams(module)
         self.bufs = {}
         self.packed = {}
-        self.saved = None
-        self._pack_key = None
-        self._dirty_epoch = 0
         nf = module.nf
         self.ch = [nf, nf * 2, nf * 4, nf * 8, nf * 16]
         if nf % 8:
@@ -98,9 +159,8 @@ class UNetEngine:
         launches (ops.PackJobs) instead of ~70."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
-        key = (dev, need_dgrad, os.environ.get('PNNP_WINO', '1'), os.environ.get('PNNP_WINO_MINK', '32'),
-               tuple(p.data_ptr() for p in P.values()))
-        if getattr(self, '_jobs_key', None) != key:
+        key = (dev, need_dgrad, self.policy.key(), tuple(p.data_ptr() for p in P.values()))
+        if self._jobs_key != key:
             self._jobs, self._jobs_key = self._build_pack_jobs(need_dgrad, dev, P), key
         self._jobs.run()
 
@@ -141,26 +201,15 @@ class UNetEngine:
         return self.packed[(name, self.params.flat.device)]
 
     def _wino(self, name, co, ci, taps=9):
-        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  3x3 layers whose written channels are a
-        multiple of 64 and whose reduction is deep enough to amortise the tile prologue/epilogue.
-        PNNP_WINO=0 forces the direct implicit-GEMM kernels, PNNP_WINO_MINK sets the minimum reduction depth."""
-        if taps != 9 or os.environ.get('PNNP_WINO', '1') == '0':
-            return False, False
-        mink = int(os.environ.get('PNNP_WINO_MINK', '32'))
-        return (ops.wino_supported(ci, co) and ci >= mink, ops.wino_supported(co, ci) and co >= mink)
+        """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  (self.policy)"""
+        return self.policy.use_wino(co, ci, taps)
 
     def _wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
-        """Backward-weight through the Winograd kernel?  (PNNP_WINO=0 / PNNP_WINO_WGRAD=0 force the direct kernel.)"""
-        if os.environ.get('PNNP_WINO', '1') == '0' or os.environ.get('PNNP_WINO_WGRAD', '1') == '0':
-            return False
-        return g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
+        """Backward-weight through the Winograd kernel?  (self.policy)"""
+        return self.policy.use_wino_wgrad(h, w, cout, c1, c2, g_cs, x_cs)
 
     def _wu(self, name):
         return self.packed[(name, self.params.flat.device, 'wino')]
-
-    def mark_dirty(self):
-        """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
-        self._dirty_epoch += 1
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train):
@@ -178,6 +227,7 @@ class UNetEngine:
         if key != self._pack_key:
             self.pack_weights(need_dgrad=train)
             self._pack_key = key
+        gen = self._begin_forward((B, H, W, dev), train)
         bufs = self.bufs.setdefault((B, H, W, dev), _Bufs())
         P = dict(self.m.named_parameters())
         ch = self.ch
@@ -221,7 +271,7 @@ class UNetEngine:
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=dev)
         ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
-            self.saved = (a, (B, H, W, dev))
+            self.saved = (a, (B, H, W, dev), gen)
         return out
 
     # ------------------------------------------------------------------ backward
@@ -230,7 +280,7 @@ class UNetEngine:
         buffer.  ``on_ready(offset)`` is called as soon as flat_grad[offset:] is final (layers
         finish in exactly the reverse of the flat parameter order) so a data-parallel reducer
         can start all-reducing the tail while the rest of the backward pass still runs."""
-        a, (B, H, W, dev) = self.saved
+        a, (B, H, W, dev), _ = self.saved
         bufs = self.bufs[(B, H, W, dev)]
         ch = self.ch
         gb = lambda n, s: bufs.get('g_' + n, s, dev)
@@ -324,13 +374,14 @@ class _UNetFn(torch.autograd.Function):
         # autograd.Function.forward runs with grad mode off: `train` is decided by the caller
         ctx.engine = engine
         ctx.x_needs = x.requires_grad
-        return engine.forward(x, train)
+        out = engine.forward(x, train)
+        ctx.gen = engine.gen
+        return out
 
     @staticmethod
     def backward(ctx, grad_out):
         e = ctx.engine
-        if e.saved is None:
-            raise PnnpError('backward without a training-mode forward')
+        e.check_saved(ctx.gen)
         B, _, H, W = grad_out.shape
         bufs = e.bufs[(B, H, W, grad_out.device)]
         g8 = ops.nchw_to_nhwc(grad_out.contiguous().float(), bufs.get('g_out8', (B, H, W, e.cout_pad), grad_out.device), e.cout_pad)

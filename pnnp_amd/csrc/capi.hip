@@ -16,12 +16,14 @@ const char* pnnp_error_string(int code) {
     }
 }
 
-int pnnp_device_cus(void) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    hipDeviceProp_t p;
-    if (hipGetDeviceProperties(&p, dev) != hipSuccess) return 0;
-    return p.multiProcessorCount;
+int pnnp_device_cus(void) {            // compute units of the CURRENT device (cached per device)
+    static PnnpPerDevice cache;
+    return cache.get([] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return n;
+    });
 }
 
 }  // extern "C"

@@ -15,3 +15,36 @@ static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream
 
 template <typename T>
 static inline T ceil_div(T a, T b) { return (a + b - 1) / b; }
+
+// The library keeps no mutable state that changes results.  What it does cache are device facts (CU count, occupancy of a
+// kernel) and the per-device "raise the dynamic-LDS limit of this kernel" call: idempotent, keyed by the CURRENT device
+// (hipFuncSetAttribute and occupancy are per device), lock-free, safe to race (two threads may both do the one-time call).
+#include <atomic>
+constexpr int PNNP_MAX_DEVICES = 64;
+static inline int pnnp_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PNNP_MAX_DEVICES) return -1;
+    return dev;
+}
+struct PnnpPerDevice {                    // one int per device, 0 = not yet computed
+    std::atomic<int> v[PNNP_MAX_DEVICES];
+    template <class F>
+    int get(F&& compute) {                // compute() returns the value (> 0) or <= 0 on failure (not cached)
+        const int dev = pnnp_current_device();
+        if (dev < 0) return compute();
+        int x = v[dev].load(std::memory_order_relaxed);
+        if (x > 0) return x;
+        x = compute();
+        if (x > 0) v[dev].store(x, std::memory_order_relaxed);
+        return x;
+    }
+};
+// raise a kernel's dynamic shared-memory limit once per device; returns PNNP_OK / PNNP_E_LAUNCH
+template <class K>
+static inline int pnnp_allow_lds(PnnpPerDevice& once, K kern, int bytes) {
+    if (bytes <= 64 * 1024) return PNNP_OK;
+    const int ok = once.get([&] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 0;
+    });
+    return ok > 0 ? PNNP_OK : PNNP_E_LAUNCH;
+}

@@ -9,7 +9,6 @@
 // and are written to LDS after the barrier that retires item i (issue-early / write-late); the
 // epilogue stores of a finished tile overlap the next tile's loads the same way.
 #include "igemm.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -140,14 +139,6 @@ igemm_kernel(const IgemmArgs a) {
     int g = 0, si = 0, cc = 0;                          // global chunk, segment, chunk within segment
     Tile cur = decode(t < total ? t : 0), nxt = cur;
     if (t < total) prefetch(cur, 0, 0, 0);
-    // Co-resident workgroups run the same program: started together they stay in lockstep (both stage,
-    // then both share the matrix pipe).  Delaying half of them by part of a chunk's MFMA time puts one
-    // workgroup's staging / address arithmetic under the other's MFMAs.
-    if (a.stagger_mode) {
-        const bool late = a.stagger_mode == 1 ? (int)blockIdx.x >= (G >> 1) : (blockIdx.x & 1);
-        if (late)
-            for (int i = 0; i < a.stagger_n; ++i) __builtin_amdgcn_s_sleep(32);      // 32 x 64 cycles each
-    }
     bool first = true;
     while (t < total) {
         if (!first) __syncthreads();                   // every wave is done reading the previous item
@@ -364,57 +355,32 @@ igemm_kernel(const IgemmArgs a) {
     }
 }
 
-int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-
-int grid_cap() {   // experiments: PNNP_IGEMM_WGS_PER_CU overrides the resident-workgroup count
-    static int v = -2;
-    if (v == -2) { const char* e = getenv("PNNP_IGEMM_WGS_PER_CU"); v = e ? atoi(e) : -1; }
-    return v;
-}
-
 template <int TAPS, int KC, int BN, int MT, int NT, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
     using Cfg = IgemmCfg<TAPS, KC, BN, MT, NT, WM, WN>;
     auto kern = igemm_kernel<TAPS, KC, BN, MT, NT, WM, WN>;
-    static int per_cu = 0, cus = 0;
-    if (!per_cu) {
-        if (Cfg::LDS_BYTES > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::LDS_BYTES) != hipSuccess)
-            return PNNP_E_LAUNCH;
+    static PnnpPerDevice lds_once, occ;       // per-device: LDS limit raised, resident workgroups per CU
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int per_cu = occ.get([&] {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, Cfg::LDS_BYTES) != hipSuccess || n < 1)
-            n = 1;
-        cus = pnnp_device_cus();
-        if (cus < 1) cus = 256;
-        per_cu = n;
-    }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        return n;
+    });
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
     const int tiles = ((a.DW + 31) / 32) * ((a.DH + Cfg::TH - 1) / Cfg::TH) * a.B * ((a.Ntot + BN - 1) / BN);
     if (tiles <= 0) return PNNP_OK;
-    int wgs = (grid_cap() > 0 ? grid_cap() : per_cu) * cus;
+    int wgs = per_cu * cus;
     if (wgs > tiles) wgs = tiles;
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();
-}
-
-// tuning knob (experiments): PNNP_KC_CAP caps the channel chunk
-int kc_cap() {
-    static int cap = -1;
-    if (cap < 0) { const char* e = getenv("PNNP_KC_CAP"); cap = e ? atoi(e) : 32; if (cap < 8) cap = 8; }
-    return cap;
-}
-
-int kc1() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("PNNP_KC1"); v = e ? atoi(e) : 16; if (v != 8 && v != 16 && v != 32) v = 16; }
-    return v;
 }
 
 int pick_bn(int ntot) { return ntot >= 128 ? 128 : (ntot >= 64 ? 64 : 32); }
 
 int pick_kc(int bn, int chan, int taps = 9) {
     if (taps == 1) {                 // 1x1: the weight tile is 9x smaller, so a chunk can carry 4x the channels
-        int kc = kc1();              // (16 MFMAs per chunk and wave at KC = 8 drown in barriers and staging)
+        int kc = 16;                 // (16 MFMAs per chunk and wave at KC = 8 drown in barriers and staging)
         while (kc > 8 && (chan % kc)) kc >>= 1;
         return kc;
     }
@@ -422,7 +388,6 @@ int pick_kc(int bn, int chan, int taps = 9) {
     // 3-4 workgroups resident per CU
     int kc = 1024 / bn;
     if (kc > 16) kc = 16;
-    if (kc > kc_cap()) kc = kc_cap();
     while (kc > 8 && (chan % kc)) kc >>= 1;
     return kc;
 }
@@ -471,8 +436,6 @@ int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_
     for (int d = 0; d < 2; ++d)                              // 32-bit element offsets in the epilogue
         if (a.dst[d] && (int64_t)a.B * a.OH * a.OW * a.dst_cs[d] >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     IgemmArgs b = a;
-    static const int stagger_mode = env_int("PNNP_STAGGER", 0), stagger_n = env_int("PNNP_STAGGER_N", 2);
-    b.stagger_mode = stagger_mode; b.stagger_n = stagger_n;
     const int kc = pick_kc(pick_bn(a.Ntot), chan_per_seg, taps);
     b.chunks_per_seg = chan_per_seg / kc;
     if (taps == 9) return launch_taps<9>(b, chan_per_seg, s);

@@ -48,6 +48,5 @@ struct IgemmArgs {
     const float* mask[2];          // saved activation at the dst position (or null)
     int mask_mode[2];              // 0 none, 1 x lrelu'(mask), 2 x relu'(mask)
     int accum[2];                  // dst += result
-    int stagger_mode, stagger_n;   // tuning: delay half of the co-resident workgroups at start (0 = off)
     const float* addsrc;           // optional residual tensor with dst[0] geometry, added before act (or null)
 };

@@ -240,9 +240,11 @@ rows_sum_kernel(const float* __restrict__ partial, float* __restrict__ out, int 
 // partial[block] = {sum |d|, then per-crop SSE is accumulated in sse_partial[block]} ; a block
 // never straddles two crops (grid = B x blocks_per_crop).
 __global__ void __launch_bounds__(256)
-l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, float* __restrict__ grad_nhwc,
-                float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop) {
+l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, const float* __restrict__ scale,
+                float* __restrict__ grad_nhwc, float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop) {
     const int b = blockIdx.x / blocks_per_crop, blk = blockIdx.x % blocks_per_crop;
+    const float sc = scale ? scale[b] : 1.f;            // `ori`: pred * ratio before the loss (trainer_SID.py:97-98)
+    const float gsc = inv_n * sc;
     float l1 = 0.f, sse = 0.f;
     for (int64_t s = (int64_t)blk * 256 + threadIdx.x; s < hw; s += (int64_t)blocks_per_crop * 256) {
         float g[8];
@@ -250,14 +252,14 @@ l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, fl
         for (int k = 0; k < 8; ++k) g[k] = 0.f;
         for (int c = 0; c < C; ++c) {
             const int64_t i = ((int64_t)b * C + c) * hw + s;
-            const float p = pred[i], t = hr[i];
+            const float p = pred[i] * sc, t = hr[i];
             const float pc = fminf(fmaxf(p, 0.f), 1.f);
             const float d = pc - t;
             l1 += fabsf(d);
             const float tc = fminf(fmaxf(t, 0.f), 1.f);          // PSNR uses clamped hr (trainer_SID.py:112-114)
             sse += (pc - tc) * (pc - tc);
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
-            if (c < 8) g[c] = (p >= 0.f && p <= 1.f) ? sgn * inv_n : 0.f;   // clamp passes grad on [0,1]
+            if (c < 8) g[c] = (p >= 0.f && p <= 1.f) ? sgn * gsc : 0.f;     // clamp passes grad on [0,1]
         }
         if (grad_nhwc) {
             float* d = grad_nhwc + ((int64_t)b * hw + s) * Cp;
@@ -384,15 +386,20 @@ int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int ac
 // loss_out[0] = mean |clamp(pred,0,1) - hr| (trainer_SID.py:99); loss_out[1+b] = sum_b (clamp(pred)-clamp(hr))^2
 // (PSNR_b = -10 log10(SSE_b / (C*H*W)), losses/__init__.py:4-15).  grad_nhwc (optional): dL/dpred laid out
 // [B][H][W][Cp] for the backward pass.  workspace >= 2 * B * 64 floats.
-int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc, float* loss_out, int B, int C, int H, int W,
-                           int Cp, float* workspace, void* stream) {
+int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
+                                  int B, int C, int H, int W, int Cp, float* workspace, void* stream) {
     if (!pred || !hr || !loss_out || !workspace || B <= 0 || C <= 0 || C > 8 || (grad_nhwc && (Cp < C || (Cp != 4 && Cp != 8)))) return PNNP_E_INVALID;
     const int bpc = 64;
     const float inv_n = 1.0f / ((float)B * C * H * W);
-    hipLaunchKernelGGL(l1_clamp_kernel, dim3(B * bpc), dim3(256), 0, as_stream(stream), pred, hr, grad_nhwc, workspace, C,
+    hipLaunchKernelGGL(l1_clamp_kernel, dim3(B * bpc), dim3(256), 0, as_stream(stream), pred, hr, scale, grad_nhwc, workspace, C,
                        (int64_t)H * W, Cp, inv_n, bpc);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, loss_out, B, bpc, inv_n);
     return pnnp_launch_status();
+}
+
+int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc, float* loss_out, int B, int C, int H, int W,
+                           int Cp, float* workspace, void* stream) {
+    return pnnp_l1_clamp_loss_scaled_f32(pred, hr, nullptr, grad_nhwc, loss_out, B, C, H, W, Cp, workspace, stream);
 }
 
 int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

@@ -57,7 +57,8 @@ __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0
     if (lam < 10.f) {
         const float u = u01(r0);
         float p = expf(-lam), s = p, k = 0.f;
-        while (u > s && k < 200.f) { k += 1.f; p *= lam / k; s += p; }
+        // the rounded CDF can saturate below the largest uniform (1 - 2^-24): stop when a term no longer moves the sum
+        while (u > s) { k += 1.f; p *= lam / k; const float s2 = s + p; if (s2 == s) break; s = s2; }
         return k;
     }
     const float slam = sqrtf(lam), loglam = logf(lam);

@@ -251,14 +251,8 @@ template <int TAPS, int WMO, int WNO, int WK, int TH, int SMUL = (TAPS == 4 ? 2 
 int launch_wg(const WgradArgs& a, hipStream_t s) {
     using Cfg = WgCfg<TAPS, WMO, WNO, WK, TH, SMUL>;
     auto kern = wgrad_kernel<TAPS, WMO, WNO, WK, TH, SMUL>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (Cfg::LDS_BYTES > 64 * 1024 &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                Cfg::LDS_BYTES) != hipSuccess)
-            return PNNP_E_LAUNCH;
-        attr_set = true;
-    }
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
     const int blocks = ((a.M + Cfg::BMO - 1) / Cfg::BMO) * ((a.N + Cfg::BNO - 1) / Cfg::BNO) * a.Z;
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();

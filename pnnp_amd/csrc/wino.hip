@@ -31,6 +31,9 @@ namespace {
 #ifndef WINO_STEPTIME
 #define WINO_STEPTIME 0     // profiling build: clock64() at every step of chunk 2 (tools/wino_phases.py --steps)
 #endif
+#ifndef PNNP_WINO_DEBUG
+#define PNNP_WINO_DEBUG WINO_STEPTIME   // profiling builds only (tools/ab_build.sh -DPNNP_WINO_DEBUG=1): exports pnnp_wino_set_debug;
+#endif                                  // the shipped library has no debug hook and no mutable global
 constexpr int KC = 8, BN = 64, TT = 64, PATCH = 18;
 constexpr int VPLANE = TT * 4 + 32;                    // 288: the +32 keeps the two k-quads of a b128 store on disjoint banks
 constexpr int VS_STAGE = 16 * 2 * VPLANE;              // floats
@@ -380,10 +383,16 @@ __global__ void __launch_bounds__(256, 1) wino_kernel(WinoArgs a) {
 
 static_assert(KC == 8 && BN == 64 && UPLANE == 256 && US_STAGE == 8192, "csrc/pack_jobs.hip restates the U layout");
 
-long long* g_wino_dbg = nullptr;       // set by pnnp_wino_set_debug; profiling only
+#if PNNP_WINO_DEBUG
+long long* g_wino_dbg = nullptr;       // set by pnnp_wino_set_debug; profiling builds only
+#endif
 
 int wino_launch(WinoArgs& a, hipStream_t st) {
+#if PNNP_WINO_DEBUG
     a.dbg = g_wino_dbg;
+#else
+    a.dbg = nullptr;
+#endif
     if (a.K % KC || a.N % BN || a.C1 % KC || (a.n_split % 32)) return PNNP_E_UNSUPPORTED;
     if ((int64_t)a.B * a.H * a.W * (a.src_cs[0] > a.src_cs[1] ? a.src_cs[0] : a.src_cs[1]) >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     // buffer-resource addressing: byte offsets inside one image (and inside one channel block of U) are 32-bit, 2^31 marks out-of-range
@@ -394,12 +403,8 @@ int wino_launch(WinoArgs& a, hipStream_t st) {
     if ((a.dst_cs[0] & 3) || (a.dst_cs[1] & 3) ||
         ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) | ((uintptr_t)a.addsrc)) & 15))
         return PNNP_E_INVALID;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM_FLOATS * 4) != hipSuccess) return PNNP_E_LAUNCH;
-        attr_set = true;
-    }
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, wino_kernel, SMEM_FLOATS * 4) != PNNP_OK) return PNNP_E_LAUNCH;
     const dim3 grid((unsigned)(a.tiles_x * a.tiles_y * a.B), (unsigned)(a.N / BN));
     hipLaunchKernelGGL(wino_kernel, grid, dim3(256), SMEM_FLOATS * 4, st, a);
     return pnnp_launch_status();
@@ -466,8 +471,10 @@ int pnnp_conv3x3_wino_bwd_data_res_f32(const float* g, int Cout, const float* u_
     return wino_launch(a, as_stream(stream));
 }
 
-// Profiling hook: when buf is non-null every later Winograd launch writes, per workgroup w (= blockIdx.y*gridDim.x+blockIdx.x),
+#if PNNP_WINO_DEBUG
+// Profiling builds only: when buf is non-null every later Winograd launch writes, per workgroup w (= blockIdx.y*gridDim.x+blockIdx.x),
 // buf[4w..4w+3] = clock64() at kernel entry, main-loop entry, epilogue entry and exit.  buf must hold 4 * workgroups entries.
 int pnnp_wino_set_debug(long long* buf) { g_wino_dbg = buf; return PNNP_OK; }
+#endif
 
 }  // extern "C"

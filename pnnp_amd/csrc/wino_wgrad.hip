@@ -309,8 +309,8 @@ ww_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_
 int ww_splits(int B, int H, int W, int M, int N) {
     const int chunks = B * (H / 4) * (W / 8);
     const int blocks = (M / BM) * (N / BN);
-    static int cus = 0;
-    if (cus <= 0) { cus = pnnp_device_cus(); if (cus <= 0) cus = 256; }
+    int cus = pnnp_device_cus();
+    if (cus <= 0) cus = 256;
     int z = (cus + blocks - 1) / blocks;
     if (z > chunks) z = chunks;
     if (z < 1) z = 1;
@@ -345,12 +345,8 @@ int pnnp_conv3x3_wino_bwd_weight_f32(const float* g, int g_cs, int Cout, const f
     if (g_cs < Cout || x1_cs < C1 || (x2 && x2_cs < C2) || (g_cs & 3) || (x1_cs & 3) || (x2 && (x2_cs & 3))) return PNNP_E_INVALID;
     if ((int64_t)B * H * W * (g_cs > x1_cs ? g_cs : x1_cs) >= (1ll << 31) || (x2 && (int64_t)B * H * W * x2_cs >= (1ll << 31))) return PNNP_E_UNSUPPORTED;
     if (workspace_floats < pnnp_wino_wgrad_workspace_floats(B, H, W, Cout, N)) return PNNP_E_WORKSPACE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(wino_wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SMEM_FLOATS * 4) != hipSuccess) return PNNP_E_LAUNCH;
-        attr_set = true;
-    }
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, wino_wgrad_kernel, SMEM_FLOATS * 4) != PNNP_OK) return PNNP_E_LAUNCH;
     hipStream_t st = as_stream(stream);
     WwArgs a{};
     a.g = g; a.g_cs = g_cs;

@@ -56,6 +56,8 @@ class BucketedAllReduce:
         self.works = []
         self.cuda = flat.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        # one event per bucket, allocated once: "the backward stream has finished this bucket's gradients"
+        self.events = [torch.cuda.Event() for _ in self.buckets] if (self.cuda and self.active) else []
 
     def reset(self):
         self.pending = len(self.buckets) - 1
@@ -70,7 +72,7 @@ class BucketedAllReduce:
             s, e = self.buckets[self.pending]
             view = self.flat[s:e]
             if self.cuda:
-                ev = torch.cuda.Event()
+                ev = self.events[self.pending]
                 ev.record(torch.cuda.current_stream())
                 self.comm_stream.wait_event(ev)
                 with torch.cuda.stream(self.comm_stream):
@@ -99,7 +101,15 @@ class HipTrainStep:
     """One optimiser step on a batch of clean crops ``hr`` [B,4,H,W] (CUDA):
     noise sampler ('camera_type', 'noise_code', 'ori', 'clip' as in the dst section of the
     YAMLs) -> denoiser -> L1 -> backward -> (all-reduce) -> Adam.  Returns the device tensor
-    ``[loss, sse_0 .. sse_{B-1}]`` without synchronising."""
+    ``[loss, sse_0 .. sse_{B-1}]`` without synchronising.
+
+    ``ori=True`` (dst.ori in the YAMLs): the sampler leaves the noisy crop un-brightened and the prediction is multiplied
+    by the per-crop ratio before the loss (trainer_SID.py:97-99), so loss, PSNR and the gradient carry the ratio.
+
+    Data parallel (world > 1): replicas must start identical.  The reference's ``nn.DataParallel`` re-broadcasts the
+    parameters from device 0 on every forward (base_trainer.py:115-118); here rank 0's flat parameter buffer is broadcast
+    ONCE, at the first step (``sync_replicas``), after which identical gradients (all-reduce) and the deterministic fused
+    Adam keep the replicas bit-identical; ``replica_checksum`` lets a caller verify that at any time."""
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
                  seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False):
@@ -116,6 +126,30 @@ class HipTrainStep:
         self.m = self.v = None
         self.reducer = None
         self._loss = None
+        self._synced = False
+
+    def sync_replicas(self):
+        """Broadcast rank 0's parameters (and Adam moments) to every rank of the group: the start-up counterpart of
+        DataParallel's per-step replicate() (base_trainer.py:115-118)."""
+        import torch.distributed as dist
+        if self.world > 1 and dist.is_initialized():
+            for t in (self.engine.params.flat, self.m, self.v):
+                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            self.engine.mark_dirty()
+        self._synced = True
+
+    def replica_checksum(self):
+        """(max - min) over ranks of a parameter checksum: 0.0 when all replicas hold bit-identical weights."""
+        import torch.distributed as dist
+        flat = self.engine.params.flat
+        w = (torch.arange(flat.numel(), device=flat.device) % 977 + 1).double()          # position-dependent weights: catches permutations
+        cs = torch.stack([flat.double().sum(), (flat.double() * w).sum()])
+        if self.world > 1 and dist.is_initialized():
+            hi, lo = cs.clone(), cs.clone()
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+            return float((hi - lo).abs().max())
+        return 0.0
 
     def _state(self, device):
         self.engine.params.ensure(device)
@@ -125,6 +159,8 @@ class HipTrainStep:
             self.v = torch.zeros_like(flat)
         if (self.world > 1 or self.force_reducer) and (self.reducer is None or self.reducer.flat is not self.engine.params.grad):
             self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group, force=self.force_reducer)
+        if not self._synced:
+            self.sync_replicas()
 
     def sample_noise_params(self, batch):
         """trainer_SID.py:451-459: one host-side parameter draw per crop."""
@@ -171,7 +207,9 @@ class HipTrainStep:
             noisy = noisy.clamp_(max=1.0) if self.clip == process.HALF_CLIP else noisy.clamp_(0.0, 1.0)
         return noisy, ratio, iso
 
-    def step(self, hr, plist=None, rows=None, noisy=None, lr=None):
+    def step(self, hr, plist=None, rows=None, noisy=None, lr=None, ratio=None):
+        """``ratio`` [B] (or [B,1,1,1]): the per-crop ratio for ``ori=True`` when ``noisy`` comes from outside (with the
+        built-in sampler it is the ratio column of the parameter rows)."""
         if not hr.is_cuda:
             raise PnnpError('HipTrainStep needs CUDA tensors (no CPU path)')
         dev = hr.device
@@ -179,14 +217,23 @@ class HipTrainStep:
         e = self.engine
         B, C, H, W = hr.shape
         if noisy is None:
-            noisy, _ = self.make_noisy(hr, plist, rows)
+            noisy, rows = self.make_noisy(hr, plist, rows)
+        scale = None
+        if self.ori:                                         # trainer_SID.py:97-98: pred = pred * ratio
+            if ratio is None and rows is not None:
+                ratio = rows[:, 6]                           # column order of process.pack_params
+            if ratio is None:
+                raise PnnpError('ori=True needs the per-crop ratio: pass rows= / plist= or ratio=')
+            scale = ratio.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
+            if scale.numel() == 1 and B > 1:
+                scale = scale.expand(B).contiguous()
         target = hr.clamp(0, 1) if self.clip else hr        # trainer_SID.py:485 (plumbing)
         pred = e.forward(noisy, True)
         bufs = e.bufs[(B, H, W, dev)]
         g8 = bufs.get('g_out8', (B, H, W, e.cout_pad), dev)
         loss = bufs.get('loss_out', (1 + B,), dev)
         lws = bufs.get('loss_ws', (128 * B,), dev)
-        ops.l1_clamp_loss(pred, target, g8, loss, lws)
+        ops.l1_clamp_loss(pred, target, g8, loss, lws, scale=scale)
         if self.reducer is not None:
             self.reducer.reset()
         e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)
@@ -213,21 +260,28 @@ class NoiseFlowFitStep:
         noise = (lr - hr) / ratio;  clean = hr / ratio;  nll, sd_z = net.loss(noise=, clean=, iso=);  nll.backward();  Adam
 
     with ``net`` in training mode (BatchNorm batch statistics, :102).  ``step`` returns the device scalars
-    ``(nll + mean log ratio, sd_z * mean ratio)`` that the reference logs (:129-133)."""
+    ``(nll + mean log ratio, sd_z * mean ratio)`` that the reference logs (:129-133).
+
+    As in the reference's preprocess: the ratio is ALWAYS the sampled parameter's ratio (:435, also with ``ori``); the
+    parameters come from ``sample_params_max(camera_type, ratio=None)`` -- the regression table (:429) -- unless
+    ``iso_table=True`` asks for the per-ISO table of the step's ISO; with ``clip`` set (run files: ``clip: 2``) the noisy
+    crop is clamped to (-inf or 0, 1] and the clean crop to [0, 1] after the sampler (:438-442)."""
 
     def __init__(self, net, lr=2e-3, camera_type='SonyA7S2', noise_code='pgrq', ori=False, clip=False, seed=1997,
-                 rank=0, world=1, group=None, tukey=True):
+                 rank=0, world=1, group=None, tukey=True, iso_table=False):
         self.net = net
         self.lr = lr
         self.camera_type, self.noise_code, self.ori, self.clip = camera_type, noise_code, ori, clip
         self.seed, self.rank, self.world, self.group = seed, rank, world, group
         self.tukey = tukey                       # 'g' in the run files' noise_code: drawn on the device (row f3)
+        self.iso_table = iso_table
         self.step_count = 0
+        self._flat_grad = None
         self.optimizer = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=lr)      # trainer_NF_SID.py:34
 
     def make_pair(self, hr, iso):
         B = hr.shape[0]
-        plist = [process.sample_params_max(camera_type=self.camera_type, ratio=None, iso=iso) for _ in range(B)]
+        plist = [process.sample_params_max(camera_type=self.camera_type, ratio=None, iso=iso if self.iso_table else None) for _ in range(B)]
         rows = process.pack_params(plist, hr.device)
         code = self.noise_code.lower()
         if 'g' in code and 'b' not in code and not self.tukey:
@@ -235,8 +289,10 @@ class NoiseFlowFitStep:
         flags = process.noise_flags(code if self.tukey else code.replace('g', ''), ori=self.ori, clip=bool(self.clip), torch_mode=True)
         if self.tukey and 'g' in code:
             flags |= process.F_TORCH_TUKEY
+        if self.clip:                            # trainer_NF_SID.py:438-441, fused into the sampler's store
+            flags |= process.F_POST_MAX1 | (0 if self.clip == process.HALF_CLIP else process.F_POST_MIN0)
         lr_img = process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count, crop_base=self.rank * B)
-        ratio = torch.ones(B, 1, 1, 1, device=hr.device) if self.ori else rows[:, 6].reshape(B, 1, 1, 1)    # column order of process.pack_params: K sigGs sigTL lam sigR q ratio wp bl
+        ratio = rows[:, 6].reshape(B, 1, 1, 1)   # :435 (column order of process.pack_params: K sigGs sigTL lam sigR q ratio wp bl)
         return lr_img, ratio
 
     def step(self, hr, iso=1600, lr=None):
@@ -247,14 +303,20 @@ class NoiseFlowFitStep:
                 g['lr'] = lr
         self.net.train()
         imgs_lr, ratio = self.make_pair(hr, iso)
+        if self.clip:
+            hr = hr.clamp(0, 1)                  # :442
         self.optimizer.zero_grad(set_to_none=True)
         nll, sd_z = self.net.loss(noise=(imgs_lr - hr) / ratio, clean=hr / ratio, iso=float(iso))
         nll.backward()
         if self.world > 1:                       # replicas average their gradients (BatchNorm statistics stay per replica,
-            import torch.distributed as dist     # as under the reference's nn.DataParallel)
-            for p in self.net.parameters():
-                if p.grad is not None:
-                    dist.all_reduce(p.grad, group=self.group); p.grad.div_(self.world)
+            import torch.distributed as dist     # as under the reference's nn.DataParallel): ONE all-reduce of the few
+            ps = [p for p in self.net.parameters() if p.grad is not None]           # hundred parameters, flattened
+            flat = torch.cat([p.grad.reshape(-1) for p in ps])
+            dist.all_reduce(flat, group=self.group)
+            flat.div_(self.world)
+            o = 0
+            for p in ps:
+                p.grad.copy_(flat[o:o + p.numel()].view_as(p.grad)); o += p.numel()
         self.optimizer.step()
         self.step_count += 1
         return nll.detach() + torch.log(ratio).mean(), sd_z * ratio.mean()

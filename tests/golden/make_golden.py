@@ -306,6 +306,39 @@ def gen_nets(archs, losses):
                             x_sha=np.array(sha(x.numpy())), w_sha=np.array(wsha))
 
 
+def gen_nets512(archs, losses):
+    """G4b: loss.backward() of the reference modules at the benchmark's full crop size (1 x 4 x 512 x 512, nf = 32) on
+    variance-preserving weights (oracle.net_torch.init_state_he: live gradients in all layers): loss, output probes and,
+    per parameter tensor, 64 probe elements + sum + L2 of its gradient."""
+    import torch
+    sys.path.insert(0, REPO)
+    from oracle import net_torch as O
+    torch.set_num_threads(8)
+    for arch, cls, shapes_fn in (('unet', archs.UNetSeeInDark, O.unet_param_shapes),
+                                 ('resunet', archs.ResUnet, O.resunet_param_shapes)):
+        net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
+        sd = O.init_state_he(shapes_fn(nf=32), seed=11, res_scale=0.25)
+        net.load_state_dict(sd)
+        g = torch.Generator().manual_seed(2)
+        x = torch.rand(1, 4, 512, 512, generator=g)
+        t = torch.rand(1, 4, 512, 512, generator=g)
+        y = net(x)
+        loss = losses.Unet_Loss()(y.clamp(0, 1), t)
+        loss.backward()
+        pr = probes(y.detach().numpy(), 1024)
+        out = {'loss': np.float64(loss.item()), 'y:idx': pr['idx'], 'y:val': pr['val'], 'y:sum': np.array([pr['sum'], pr['l2']]),
+               'x_sha': np.array(sha(x.numpy())), 't_sha': np.array(sha(t.numpy())),
+               'w_sha': np.array(sha(np.concatenate([v.numpy().reshape(-1) for v in sd.values()]))),
+               'inside': np.float64(((y > 0) & (y < 1)).float().mean().item())}
+        for k, p in net.named_parameters():
+            pg = probes(p.grad.numpy(), 64)
+            out['g:' + k + ':idx'] = pg['idx']; out['g:' + k + ':val'] = pg['val']
+            out['g:' + k + ':sum'] = np.array([pg['sum'], pg['l2']])
+        np.savez_compressed(os.path.join(HERE, f'{arch}_nf32_512_bwd.npz'), **out)
+        print(arch, 'loss', loss.item(), 'fraction of outputs inside (0,1):', float(out['inside']),
+              'min grad l2', min(float(out[k][1]) for k in out if k.endswith(':sum') and k.startswith('g:')))
+
+
 # ------------------------------------------------------------------ G6/G7 misc
 def gen_misc(base_trainer, losses, data_process):
     import torch
@@ -527,11 +560,12 @@ def gen_augment(data_process, isp):
 
 def main():
     archs, proc, isp, losses, data_process, base_trainer = import_reference()
-    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'misc', 'noiseflow', 'augment', 'sna', 'hbr']
+    which = sys.argv[1:] or ['pack', 'params', 'noise', 'nets', 'nets512', 'misc', 'noiseflow', 'augment', 'sna', 'hbr']
     if 'pack' in which: gen_pack(isp)
     if 'params' in which: gen_params(proc)
     if 'noise' in which: gen_noise(proc)
     if 'nets' in which: gen_nets(archs, losses)
+    if 'nets512' in which: gen_nets512(archs, losses)
     if 'misc' in which: gen_misc(base_trainer, losses, data_process)
     if 'noiseflow' in which: gen_noiseflow()
     if 'augment' in which: gen_augment(data_process, isp)

@@ -39,9 +39,13 @@ def _worker(rank, world, port, n, bucket_bytes, offsets, out):
                 before = red.pending
                 red.ready(off)
                 launched.append(before - red.pending)
-                # nothing below `off` may have been touched yet
+                # a bucket is launched only once it lies entirely inside the finished range [off, n): what is still
+                # pending starts below `off` and has not been touched by any collective yet
                 for s, e in red.buckets[:red.pending + 1]:
-                    assert s < off or e <= off or True
+                    assert s < off
+                    assert torch.equal(flat[s:e], mine[s:e])
+                for s, e in red.buckets[red.pending + 1:]:
+                    assert s >= off
             red.finish()
             assert red.pending == -1
             other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))

@@ -186,3 +186,41 @@ def test_tukey_extension_in_torch_mode():
     q = np.quantile(n, [0.05, 0.25, 0.5, 0.75, 0.95])
     want = stats.tukeylambda.ppf([0.05, 0.25, 0.5, 0.75, 0.95], -0.2) * SONY['sigTL']
     assert np.abs(q - want).max() < 0.08 * SONY['sigTL']
+
+
+@pytest.mark.parametrize('clip', [1, 2])
+@pytest.mark.parametrize('ori', [False, True])
+def test_trainer_preprocess_clamp_is_the_oracle_sampler_plus_the_trainers_clamp(clip, ori):
+    """HipTrainStep.make_noisy -- the path every bench step runs -- fuses the clamp of Trainer.preprocess
+    (trainer_SID.py:481-485: lr.clamp(lb, 1) with lb = -inf for clip == HALF_CLIP (2), else 0) into the sampler's store
+    (F_POST_MAX1 / F_POST_MIN0).  Checked against the C oracle's sampler WITHOUT the post flags followed by that clamp in
+    numpy, on crops bright and dark enough for both bounds to bite; tier-A bar (99.9 % of pixels to 1e-5)."""
+    from oracle import cbind
+    from pnnp_amd import process as P
+    from pnnp_amd.trainer import HipTrainStep
+
+    class _Net:                                    # make_noisy never touches the network
+        engine = None
+    rng = np.random.default_rng(7)
+    B, C, H, W = 3, 4, 48, 72
+    y = rng.random((B, C, H, W), dtype=np.float32)
+    y[0] *= 1.2                                    # values above 1: the upper clamp bites after x ratio
+    y[1] *= 0.002                                  # dark: read/row noise drives pixels below 0
+    plist = [SONY, dict(SONY, ratio=250.0), dict(SONY, ratio=100.0, K=0.3)]
+    ts = HipTrainStep(_Net(), camera_type='SonyA7S2', noise_code='pr', ori=ori, clip=clip, seed=11, rank=2)
+    ts.step_count = 5
+    got, rows = ts.make_noisy(torch.from_numpy(y).cuda(), plist)
+    got = got.cpu().numpy()
+    flags = cbind.noise_flags('pr', ori=ori, clip=True, torch_mode=True)          # clip: 1 and 2 are both truthy (process.py:668)
+    ref = cbind.noise_sample(y, cbind.param_rows(plist), flags, seed=11, offset=5, crop_base=2 * B)
+    ref = np.clip(ref, -np.inf if clip == 2 else 0.0, 1.0)
+    assert got.max() <= 1.0 and got.min() >= 0.0  # (the sampler's own clip already floors at 0 before x ratio, process.py:668)
+    assert (ref == 1.0).mean() > 0.01 and (ref == 0.0).mean() > 0.01          # both bounds really are exercised
+    for b, p in enumerate(plist):
+        scale = (1.0 if ori else p['ratio']) / (p['wp'] - p['bl'])
+        tol = 1e-5 * np.maximum(np.abs(ref[b]), scale)
+        assert float((np.abs(got[b] - ref[b]) <= tol).mean()) >= 0.999, (clip, ori, b)
+    # the same flags through the oracle's own post-clamp bits agree with the numpy clamp exactly
+    pf = flags | P.F_POST_MAX1 | (0 if clip == 2 else P.F_POST_MIN0)
+    ref2 = cbind.noise_sample(y, cbind.param_rows(plist), pf, seed=11, offset=5, crop_base=2 * B)
+    assert np.array_equal(ref2, ref)

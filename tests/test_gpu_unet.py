@@ -170,3 +170,59 @@ def test_rccl_bucketed_reducer_on_one_gpu():
         assert torch.equal(outs[0][1], outs[1][1])
     finally:
         dist.destroy_process_group()
+
+
+def test_ori_multiplies_prediction_by_ratio_before_the_loss():
+    """dst.ori = True (trainer_SID.py:97-99): pred = pred * ratio; loss(pred.clamp(0,1), hr).  Loss and every parameter
+    gradient vs autograd on the oracle with per-crop ratios; bars as in the nf=32 oracle test."""
+    from oracle import net_torch as O
+    from pnnp_amd.archs import UNetSeeInDark
+    from pnnp_amd.trainer import HipTrainStep
+    from pnnp_amd._lib import PnnpError
+    sd = O.init_state_he(O.unet_param_shapes(nf=8), seed=5)
+    net = _load(UNetSeeInDark(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4)), sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(3, 4, 64, 80, generator=g) * 0.02; t = torch.rand(3, 4, 64, 80, generator=g)
+    ratio = torch.tensor([120.0, 1.0, 37.5])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_ref = O.l1_clamp_loss(O.unet_forward(leaves, x) * ratio.view(-1, 1, 1, 1), t)
+    loss_ref.backward()
+    ts = HipTrainStep(net, lr=0.0, clip=0, ori=True)
+    with pytest.raises(PnnpError):
+        ts.step(t.cuda(), noisy=x.cuda())                       # ori without a ratio must not silently drop the scaling
+    lo = ts.step(t.cuda(), noisy=x.cuda(), ratio=ratio.cuda())
+    assert abs(float(lo[0]) - loss_ref.item()) < 2e-6
+    for k, p in net.named_parameters():
+        got = net.engine.params.grad_view(k, p.shape).cpu()
+        ref = leaves[k].grad
+        assert float((got - ref).norm() / (ref.norm() + 1e-12)) < 2e-3, k
+    # and it is not the un-scaled objective
+    lo1 = HipTrainStep(net, lr=0.0, clip=0, ori=False).step(t.cuda(), noisy=x.cuda())
+    assert abs(float(lo1[0]) - float(lo[0])) > 1e-3
+
+
+def test_autograd_path_refuses_overwritten_activations():
+    """The engine keeps ONE saved training forward per input shape (activation buffers are reused): a backward whose
+    activations were overwritten -- second training forward, or a same-shape no_grad forward in between -- must raise
+    instead of returning gradients of the wrong input; gradient accumulation step by step works."""
+    from oracle import net_torch as O
+    from pnnp_amd.archs import UNetSeeInDark
+    from pnnp_amd._lib import PnnpError
+    sd = O.init_state(O.unet_param_shapes(nf=8), seed=1)
+    net = _load(UNetSeeInDark(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4)), sd)
+    a = torch.rand(1, 4, 32, 32).cuda(); b = torch.rand(1, 4, 32, 32).cuda()
+    la = net(a).abs().mean(); lb = net(b).abs().mean()
+    with pytest.raises(PnnpError):
+        (la + lb).backward()
+    la = net(a).abs().mean()
+    with torch.no_grad():
+        net(b)
+    with pytest.raises(PnnpError):
+        la.backward()
+    # sequential accumulation is fine and equals the oracle's sum of gradients
+    net.zero_grad()
+    net(a).abs().mean().backward(); net(b).abs().mean().backward()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    (O.unet_forward(leaves, a.cpu()).abs().mean() + O.unet_forward(leaves, b.cpu()).abs().mean()).backward()
+    for k, p in net.named_parameters():
+        assert float((p.grad.cpu() - leaves[k].grad).norm() / (leaves[k].grad.norm() + 1e-12)) < 2e-3, k

@@ -19,7 +19,9 @@ def test_load_and_schedule():
     period = (60 - 20) // 2
     for epoch in (21, 22, 30, 41, 45, 59):
         assert lr(epoch) == get_cos_lr(epoch - 20, period=period, peak=2, lr=1e-3)
-    assert lr(41) < lr(30) or True
+    # restart at epoch 41 (T = 1): warm-up from s/peak of a halved peak rate (base_trainer.py:140-149)
+    assert lr(41) == pytest.approx(1e-3 * 0.5 / 2) and lr(41) < lr(30) < lr(22)
+    assert lr(59) == pytest.approx(0.2 * 1e-3 / 2, rel=0.05)          # the cosine floor `ratio` of the second period
 
 
 def test_unknown_arch_raises_keyerror(tmp_path):

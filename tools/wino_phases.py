@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Where a Winograd workgroup spends its cycles (prologue / main loop / epilogue), from the kernel's own clock64() stamps
-(pnnp_wino_set_debug).  Also cycles per K-chunk iteration against the 64 x 64 = 4096 MFMA cycles it contains."""
+(pnnp_wino_set_debug, present only in a profiling build:  PNNP_HIPCC_EXTRA=-DPNNP_WINO_DEBUG=1 python tools/build.py --force).
+Also cycles per K-chunk iteration against the 64 x 64 = 4096 MFMA cycles it contains."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

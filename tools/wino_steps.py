@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Cycles per step inside one K-chunk of the Winograd kernel (needs a build with -DWINO_STEPTIME=1):
-    PNNP_HIPCC_EXTRA=-DWINO_STEPTIME=1 python tools/build.py && python tools/wino_steps.py"""
+    PNNP_HIPCC_EXTRA="-DWINO_STEPTIME=1 -DPNNP_WINO_DEBUG=1" python tools/build.py && python tools/wino_steps.py"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
