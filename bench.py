@@ -31,48 +31,90 @@ GFLOP_PER_CROP_TRAIN = {'unet': 289.70, 'resunet': 375.07}   # f
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 
 
-def cpu_baseline(batch, H, W, seconds_hint=20.0):
-    """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py +
-    oracle/noise_np.py), timed on this box's host cores.  Bounded: one step on `batch`
-    crops after a short un-timed warm-up on a 64x64 patch."""
+def cpu_baseline(H, W):
+    """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py + oracle/noise_np.py), timed on this
+    box's host cores as BASELINE.md section 3 plans it, bounded to ~30 s: per crop `sample_params_max('SonyA7S2')` ->
+    `generate_noisy_torch('pr', clip=2)` -> clamp -> UNetSeeInDark nf=32 forward -> L1(clamp) -> backward -> Adam,
+    `np.random.seed(1997 + step)`, one warm-up step + two timed steps per leg:
+      * all cores (torch.set_num_threads(min(cpu_count, 32))) on B = 4 crops of 4 x H x W   -> `value`
+      * one thread (the reference exports OMP_NUM_THREADS=1, utils/utils.py:2) on B = 1 crop -> `one_thread`
+    with the four buckets the reference's tqdm line shows (trainer_SID.py:81-123): dataloader (here: synthetic clean crops),
+    preprocess (parameters + sampler + clamp), net (forward), bp (loss + backward + Adam)."""
     import numpy as np
     import torch
     from oracle import net_torch as O, noise_np as N
-    cores = min(os.cpu_count() or 1, 32)       # more threads than this slow torch-CPU convs down on big hosts
-    torch.set_num_threads(cores)
-    sd = O.init_state(O.unet_param_shapes(nf=32), seed=0)
-    m = {k: torch.zeros_like(v) for k, v in sd.items()}
-    v = {k: torch.zeros_like(vv) for k, vv in sd.items()}
-    p = dict(K=1.5, sigGs=6.0, sigR=1.0, q=1 / 2 ** 14, ratio=150.0, wp=16383, bl=512, bias=0)
-    pt = {k: torch.tensor(float(val)) for k, val in p.items()}
+    from pnnp_amd import process as P                      # host-side parameter tables / draws (no device code)
+    ncpu = os.cpu_count() or 1
+    all_cores = min(ncpu, 32)                              # more threads than this slow torch-CPU convs down on big hosts
 
-    split = {}
+    def leg(threads, batch, warm, timed):
+        torch.set_num_threads(threads)
+        torch.manual_seed(1997)
+        sd = O.init_state(O.unet_param_shapes(nf=32), seed=0)
+        m = {k: torch.zeros_like(v) for k, v in sd.items()}
+        v = {k: torch.zeros_like(vv) for k, vv in sd.items()}
+        buckets = dict(dataloader=0.0, preprocess=0.0, net=0.0, bp=0.0)
+        total = 0.0
+        for step in range(1, warm + timed + 1):
+            np.random.seed(1997 + step)
+            t = [time.perf_counter()]
+            hr = torch.rand(batch, 4, H, W)
+            t.append(time.perf_counter())
+            noisy = []
+            for i in range(batch):                          # trainer_SID.py:451-462, per crop
+                p = P.sample_params_max(camera_type='SonyA7S2', ratio=None)
+                pt = {k: torch.from_numpy(np.array(val, np.float32)) for k, val in p.items()}
+                noisy.append(N.generate_noisy_torch(hr[i], noise_code='pr', param=pt, ori=False, clip=2))
+            lr_in = torch.stack(noisy).clamp(max=1.0)       # :481-485 with clip == HALF_CLIP
+            tgt = hr.clamp(0, 1)
+            t.append(time.perf_counter())
+            leaves = {k: w.detach().clone().requires_grad_(True) for k, w in sd.items()}
+            pred = O.unet_forward(leaves, lr_in)
+            t.append(time.perf_counter())
+            loss = O.l1_clamp_loss(pred, tgt)
+            loss.backward()
+            with torch.no_grad():
+                O.adam_step(sd, {k: w.grad for k, w in leaves.items()}, m, v, step, lr=1e-4)
+            t.append(time.perf_counter())
+            if step > warm:
+                for k, a, b in (('dataloader', 0, 1), ('preprocess', 1, 2), ('net', 2, 3), ('bp', 3, 4)):
+                    buckets[k] += t[b] - t[a]
+                total += t[4] - t[0]
+        return batch * timed / total, total, {k: round(val / timed, 3) for k, val in buckets.items()}
 
-    def one(b, h, w, step):
-        hr = torch.rand(b, 4, h, w)
-        t0 = time.perf_counter()
-        lr = torch.stack([N.generate_noisy_torch(hr[i], noise_code='pr', param=pt, ori=False, clip=2) for i in range(b)])
-        lr = lr.clamp(max=1.0)
-        split['preprocess_s'] = time.perf_counter() - t0           # the 'preprocess' bucket of trainer_SID.py:81-123
-        t0 = time.perf_counter()
-        out = O.train_step(sd, m, v, step, lr, hr, lr=1e-4)
-        split['net_bp_s'] = time.perf_counter() - t0               # its 'net' + 'bp' buckets (forward, loss, backward, Adam)
-        return out
-
-    one(1, 64, 64, 1)
-    t0 = time.perf_counter()
-    one(batch, H, W, 2)
-    dt = time.perf_counter() - t0
-    # the dataloader-side sampler (generate_noisy_obs: numpy, one core, as a DataLoader worker runs it), one crop
+    v_all, t_all, split_all = leg(all_cores, 4, 1, 2)
+    v_one, t_one, split_one = leg(1, 1, 1, 2)
+    torch.set_num_threads(all_cores)
+    # the dataloader-side sampler (generate_noisy_obs: numpy, one core, as a DataLoader worker runs it), one crop per code
+    obs = {}
     y = np.random.rand(4, H, W).astype(np.float32)
-    pn = dict(K=1.5, sigGs=6.0, sigTL=6.0, lam=0.0, sigR=1.0, q=1 / 2 ** 14, ratio=150.0, wp=16383, bl=512, bias=np.zeros(4))
-    N.generate_noisy_obs(y[:, :8, :8], param=pn, noise_code='pr', ori=False, clip=False)       # un-timed: first-call imports
-    t0 = time.perf_counter()
-    N.generate_noisy_obs(y, param=pn, noise_code='pr', ori=False, clip=False)
-    split['generate_noisy_obs_1crop_1core_s'] = time.perf_counter() - t0
-    return {"value": batch / dt, "unit": "crops/s", "cores": cores, "kind": "port",
-            "sample": f"1 train step (sampler 'pr' + UNet nf=32 fwd/L1/bwd/Adam) on {batch} crops of 4x{H}x{W}, torch {torch.__version__} CPU fp32, {cores} threads, {dt:.1f} s",
-            "split": {k: round(val, 3) for k, val in split.items()}}
+    for code in ('pr', 'pgrq'):
+        np.random.seed(1997)
+        pn = P.sample_params_max(camera_type='SonyA7S2', ratio=None)
+        pn['bias'] = np.zeros(4)
+        N.generate_noisy_obs(y[:, :8, :8], param=pn, noise_code=code, ori=False, clip=False)       # un-timed: first-call imports
+        t0 = time.perf_counter()
+        N.generate_noisy_obs(y, param=pn, noise_code=code, ori=False, clip=False)
+        obs[code] = round(time.perf_counter() - t0, 3)
+    return {"value": v_all, "unit": "crops/s", "cores": all_cores, "kind": "port",
+            "sample": (f"UNet nf=32 train step (sample_params_max + generate_noisy_torch 'pr' clip=2 + fwd/L1/bwd/Adam), 1 warm-up + 2 timed steps: "
+                       f"{all_cores} threads on 4 crops of 4x{H}x{W} ({t_all:.1f} s timed) and 1 thread on 1 crop ({t_one:.1f} s timed), "
+                       f"torch {torch.__version__} CPU fp32, host has {ncpu} logical CPUs"),
+            "split_s_per_step": split_all,
+            "one_thread": {"value": v_one, "unit": "crops/s", "cores": 1, "split_s_per_step": split_one},
+            "generate_noisy_obs_1crop_1core_s": obs}
+
+
+def csrc_sha():
+    """Content hash of the kernel sources: PMC-derived numbers stored under profiles/ are attached to a bench line only when
+    they were measured on exactly these kernels (the GPU box has no .git to ask for HEAD)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, 'pnnp_amd', 'csrc')
+    for f in sorted(os.listdir(d)):
+        if f.endswith(('.hip', '.h')):
+            h.update(f.encode()); h.update(open(os.path.join(d, f), 'rb').read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -86,6 +128,8 @@ def main():
     ap.add_argument('--arch', default='unet', choices=['unet', 'resunet'], help='resunet + --noise noiseflow = BASELINE config 5')
     ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '
+                    '(for rocprofv3 traces of the collective kernels on the side stream overlapping the backward pass)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline becomes whole-step)')
     args = ap.parse_args()
 
@@ -112,6 +156,9 @@ def main():
         dist.barrier()
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
+    if world == 1 and args.force_reducer:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+        dist.init_process_group('nccl', rank=0, world_size=1, device_id=dev)
 
     from pnnp_amd import ops
     from pnnp_amd.archs import NoiseFlow, ResUnet, UNetSeeInDark, initialize_weights
@@ -131,7 +178,7 @@ def main():
         proxy = proxy.to(dev).eval()
     net = net.to(dev)
     ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
-                      rank=rank, world=world)
+                      rank=rank, world=world, force_reducer=(world == 1 and args.force_reducer))
     B, S = args.batch, args.size
     if args.strong:
         if B % world:
@@ -159,7 +206,7 @@ def main():
     # HIP events on the launching stream: in the TIMED region only around the dominant kernel's launches (the `roofline` object);
     # the per-class table comes from a short un-timed pass afterwards, so that the headline number is not taxed by ~200 event
     # records per step (measured: 1.7 %).
-    wino_on = os.environ.get('PNNP_WINO', '1') != '0'
+    wino_on = net.engine.policy.wino
     dom_kinds = {'conv9_fwd_wino', 'conv9_dgrad_wino'} if wino_on else {'conv9_fwd', 'conv9_dgrad'}
     if not args.no_kernel_events:
         ops.PROFILE, ops.PROFILE_KINDS = [], dom_kinds
@@ -181,6 +228,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss[0])
+    spread = ts.replica_checksum() if world > 1 else None      # 0.0: every rank holds bit-identical weights after the run
 
     if rank == 0:
         crops = B * world * args.steps
@@ -194,6 +242,8 @@ def main():
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
             "final_loss": loss_val,
         }
+        if spread is not None:
+            out["replica_checksum_spread"] = spread
         step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
         classes = {}
         if prof:
@@ -208,21 +258,28 @@ def main():
             use_wino = bool(wino) and t_of(wino) >= t_of(direct)
             dom = wino if use_wino else direct
             n = sum(classes[k][0] for k in dom); fl = sum(classes[k][1] for k in dom); sec = sum(classes[k][3] for k in dom)
-            traffic = None     # HBM bytes per launch from the PMC passes of this command (tools/traffic_from_pmc.py)
+            # `frac` is a hardware fraction: FLOPs the matrix pipe EXECUTES per second / its dense peak.  The Winograd kernels
+            # execute 16 multiply-adds where the direct form has 36 (F(2x2,3x3)): executed = algorithmic x 16/36.
+            exec_factor = 16.0 / 36.0 if use_wino else 1.0
+            alg_tflops = fl / sec / 1e12
+            traffic, traffic_note = None, None      # HBM bytes per launch from the PMC passes of this command (tools/traffic_from_pmc.py)
             tj = os.path.join(REPO, 'profiles', 'traffic.json')
             if os.path.exists(tj) and args.arch == 'unet' and args.noise == 'physics' and B == 16 and S == 512:
-                traffic = json.load(open(tj)).get('wino' if use_wino else 'igemm9', {}).get('hbm_bytes_per_launch')
+                tdoc = json.load(open(tj))
+                if tdoc.get('csrc_sha') == csrc_sha():
+                    traffic = tdoc.get('wino' if use_wino else 'igemm9', {}).get('hbm_bytes_per_launch')
+                    traffic_note = f"PMC passes at commit {tdoc.get('commit')}, kernel sources {tdoc.get('csrc_sha')}"
+                else:
+                    traffic_note = f"profiles/traffic.json was measured on other kernel sources ({tdoc.get('csrc_sha')} != {csrc_sha()}): not attached"
             by = sum(classes[k][2] for k in dom)
-            out["roofline"] = {"bound": "mfma", "achieved": fl / sec / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": fl / sec / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            out["roofline"] = {"bound": "mfma", "achieved": alg_tflops * exec_factor, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": alg_tflops * exec_factor / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
                                "alg_bytes_per_launch": by / n,
-                               "kernel": ("wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3): 16 instead of 36 MFMA "
-                                          "multiply-adds per 2x2 outputs, v_mfma_f32_32x32x2_f32)") if use_wino else
+                               "kernel": ("wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)") if use_wino else
                                          "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
-                               "alg_gflop_per_launch": fl / n / 1e9}
-            if use_wino:       # `achieved` counts the layer's ALGORITHMIC flops; the matrix pipe executes 16/36 of them
-                out["roofline"]["mfma_executed_tflops"] = fl / sec / 1e12 * 16.0 / 36.0
+                               "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
+                               "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
             # per-class table: from the un-timed pass with events around every launch (extra_steps steps)
             call = {}
             for kind, fl2, by2, e0, e1 in (prof_all or []):
@@ -241,10 +298,11 @@ def main():
                                "frac": step_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": "whole train step"}
         out["step_tflops_per_gpu"] = step_tflops
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(min(B, 16), S, S)
+            out["cpu_baseline"] = cpu_baseline(S, S)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -13,6 +13,7 @@ The trainers read them with `yaml.load` and pull the hot-path settings out of th
 configured shape, which is what bench.py measures.
 """
 import argparse
+import os
 import sys
 
 import numpy as np
@@ -21,6 +22,30 @@ import yaml
 
 from . import archs, process
 from .trainer import HipTrainStep, NoiseFlowFitStep, get_cos_lr
+from .utils import load_weights
+
+PROXY_DATASETS = ('NF_Syn_Dataset', 'IMX686_NF_Syn_Dataset')      # trainer_SID.py:463, trainer_LRID.py:419
+
+
+def build_proxy(cfg, device='cuda'):
+    """`arch_proxy` of a run file -> the NoiseFlow proxy the train step samples from (trainer_SID.py:33-42,
+    trainer_LRID.py:33-39): built by name, weights from `<fast_ckpt>/<camera>_NoiseFlow_last_model.pth` when that file exists
+    (by_name as trainer_SID does; the checkpoints are not distributed with the reference, so a missing file leaves the
+    random-initialised flow and says so), then ``.eval()`` as trainer_SID.py:42 does.  Returns None when the run file has no proxy."""
+    proxy = cfg.get('arch_proxy')
+    if not proxy or cfg.get('mode', 'train') != 'train':
+        return None
+    cls = getattr(archs, proxy['name'], None)
+    if cls is None:
+        raise KeyError(proxy['name'])
+    net = cls(proxy)
+    dst = cfg.get('dst_train', cfg.get('dst'))
+    path = os.path.join(str(cfg.get('fast_ckpt', '')), f"{dst['camera_type']}_NoiseFlow_last_model.pth")
+    if os.path.exists(path):
+        net = load_weights(net, torch.load(path, map_location='cpu'), by_name=True)
+    else:
+        print(f'No checkpoint file!!!  ({path}: the {proxy["name"]} proxy keeps its initial weights)', flush=True)
+    return net.to(device).eval()
 
 
 def load(path):
@@ -54,8 +79,16 @@ def build(cfg, device='cuda', rank=0, world=1, group=None):
         return net, step, lr_schedule(hyper), shapes
     archs.initialize_weights(net)                                   # trainer_SID.py:31
     net = net.to(device)
+    proxy_kw = {}
+    if dst.get('dataset') in PROXY_DATASETS:                        # the preprocess branch is chosen by dst_train.dataset
+        proxy_net = build_proxy(cfg, device)
+        if proxy_net is None:
+            raise KeyError('arch_proxy')                            # the reference would fail on self.proxy_net
+        proxy_kw = dict(proxy_net=proxy_net)
+        if dst['dataset'] == 'IMX686_NF_Syn_Dataset':               # trainer_LRID.py:33: legal_ratio = [1, 2, 4, 8, 16]
+            proxy_kw['proxy_ratio_choices'] = (1, 2, 4, 8, 16)
     step = HipTrainStep(net, lr=float(hyper['learning_rate']), camera_type=dst['camera_type'], noise_code=dst['noise_code'],
-                        ori=bool(dst.get('ori', False)), clip=dst.get('clip', False), rank=rank, world=world, group=group)
+                        ori=bool(dst.get('ori', False)), clip=dst.get('clip', False), rank=rank, world=world, group=group, **proxy_kw)
     shapes = dict(batch=int(hyper.get('batch_size', 1)) * int(dst.get('crop_per_image', 1)), patch=int(dst['patch_size']),
                   channels=int(arch['in_nc']) * int(arch.get('nframes', 1)))
     return net, step, lr_schedule(hyper), shapes
@@ -87,7 +120,10 @@ def main(argv=None):
                 nll, sd = step.step(hr * 0.1, iso=(800, 1600, 3200)[k % 3], lr=lr)
                 losses.append(float(nll)); psnrs.append(float(sd))
                 continue
-            out = step.step(hr, lr=lr)
+            if step.proxy_net is not None and step.proxy_ratio_choices is not None:
+                out = step.step(hr * 0.05, lr=lr, iso=6400)         # LRID: the ISO comes with the data (trainer_LRID.py:423); 6400 = the calibrated one
+            else:
+                out = step.step(hr, lr=lr)
             losses.append(float(out[0])); psnrs.append(step.psnr_from(out, sh['channels'] * S * S))
         # base_trainer / trainer_SID log line format: epoch, lr, loss, psnr
         if isinstance(step, NoiseFlowFitStep):

@@ -112,13 +112,19 @@ class HipTrainStep:
     Adam keep the replicas bit-identical; ``replica_checksum`` lets a caller verify that at any time."""
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
-                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False):
+                 seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False,
+                 proxy_net=None, proxy_ratio_choices=None, proxy_iso=None):
+        """``proxy_net`` (a NoiseFlow, `arch_proxy` of the run files): noise comes from ``proxy_net.sample`` instead of the
+        physics sampler -- the 'NF_Syn_Dataset' branch of preprocess (trainer_SID.py:463-472: ratio ~ U(100,300) per crop,
+        one random legal ISO per batch) or, with ``proxy_ratio_choices`` (dst.ratio_list), the 'IMX686_NF_Syn_Dataset'
+        branch (trainer_LRID.py:33,419-427: one ratio of the list per batch, ISO from the data: ``proxy_iso`` or step(iso=))."""
         self.net = net
         self.engine = net.engine
         self.lr = lr
         self.camera_type, self.noise_code, self.ori, self.clip = camera_type, noise_code, ori, clip
         self.seed = seed
         self.tukey = tukey          # extension: let noise codes with 'g' run (Tukey-lambda read noise on the device)
+        self.proxy_net, self.proxy_ratio_choices, self.proxy_iso = proxy_net, proxy_ratio_choices, proxy_iso
         self.rank, self.world, self.group = rank, world, group
         self.bucket_bytes = bucket_bytes
         self.force_reducer = force_reducer
@@ -207,16 +213,19 @@ class HipTrainStep:
             noisy = noisy.clamp_(max=1.0) if self.clip == process.HALF_CLIP else noisy.clamp_(0.0, 1.0)
         return noisy, ratio, iso
 
-    def step(self, hr, plist=None, rows=None, noisy=None, lr=None, ratio=None):
+    def step(self, hr, plist=None, rows=None, noisy=None, lr=None, ratio=None, iso=None):
         """``ratio`` [B] (or [B,1,1,1]): the per-crop ratio for ``ori=True`` when ``noisy`` comes from outside (with the
-        built-in sampler it is the ratio column of the parameter rows)."""
+        built-in sampler it is the ratio column of the parameter rows).  ``iso``: the batch's ISO for a NoiseFlow proxy."""
         if not hr.is_cuda:
             raise PnnpError('HipTrainStep needs CUDA tensors (no CPU path)')
         dev = hr.device
         self._state(dev)
         e = self.engine
         B, C, H, W = hr.shape
-        if noisy is None:
+        if noisy is None and self.proxy_net is not None:
+            noisy, ratio, _ = self.make_noisy_proxy(hr, self.proxy_net, ratio=ratio, iso=iso if iso is not None else self.proxy_iso,
+                                                    ratio_choices=self.proxy_ratio_choices)
+        elif noisy is None:
             noisy, rows = self.make_noisy(hr, plist, rows)
         scale = None
         if self.ori:                                         # trainer_SID.py:97-98: pred = pred * ratio

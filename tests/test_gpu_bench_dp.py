@@ -1,0 +1,46 @@
+"""bench.py's own multi-rank path on ONE GPU (two ranks sharing the device, gloo moving the CUDA gradient buckets):
+`--strong` semantics (a GLOBAL batch split over the ranks, here 4 crops -> B_local = 2), the JSON contract
+fields the driver reads, and replica consistency after the run (rank 0's parameters are broadcast at the first step; the
+all-reduced gradients and the deterministic fused Adam must keep every rank bit-identical)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(extra, nproc=2):
+    env = dict(os.environ, PNNP_BENCH_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={nproc}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(REPO, 'bench.py'), '--gpus', str(nproc), '--steps', '3', '--warmup', '1',
+           '--size', '64', '--no-cpu-baseline'] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_strong_scaling_two_ranks_b_local_2():
+    out = _run(['--strong', '--batch', '4'])
+    assert out['scaling'] == 'strong' and out['n_gpus'] == 2
+    assert out['config']['crops_per_gpu'] == 2 and out['config']['global_batch'] == 4
+    assert out['steps'] == 3 and out['warmup'] == 1 and out['value'] > 0
+    assert abs(out['value'] - 4 * 3 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']       # whole-job crops / max-over-ranks time
+    assert out['replica_checksum_spread'] == 0.0
+    assert out['final_loss'] == out['final_loss'] and out['final_loss'] < 1.0                  # finite
+
+
+def test_weak_scaling_two_ranks():
+    out = _run(['--batch', '2'])
+    assert out['scaling'] == 'weak' and out['config']['crops_per_gpu'] == 2 and out['config']['global_batch'] == 4
+    assert out['replica_checksum_spread'] == 0.0

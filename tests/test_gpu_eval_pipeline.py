@@ -39,3 +39,48 @@ def test_eval_psnr_ssim_gpu_equals_cpu_path(arch):
     assert abs(float(res[0]) - psnr_cpu) < 1e-3, (float(res[0]), psnr_cpu)            # dB
     assert abs(float(res[1]) - ssim_cpu) < 2e-5, (float(res[1]), ssim_cpu)
     torch.set_num_threads(nthr)
+
+
+def test_evaluate_product_function_on_the_imx686_frame_vs_cpu_oracle():
+    """`pnnp_amd.evaluate` (row f1 as a product function) on the LRID frame 4x1736x2312 -- width % 16 = 8, so the
+    reflect-pad-4 / crop branch of trainer_SID.py:221-228 runs (4x1744x2320 through the net) -- with `ori` brightening,
+    IlluminanceCorrect, and PSNR/SSIM of the denoised AND the noisy frame, against the same steps on the CPU oracle.
+    Bars: PSNR 1e-3 dB (north_star: 0.02 dB), SSIM 2e-5; then the log line / metrics dict layout of :309-315."""
+    import torch.nn.functional as F
+    from oracle import metrics_np as M, net_torch as O
+    from pnnp_amd.archs import UNetSeeInDark
+    from pnnp_amd.evaluate import EvalLoop, evaluate
+    sd = O.init_state_he(O.unet_param_shapes(nf=32), seed=21)
+    net = UNetSeeInDark(dict(nframes=1, res=True, nf=32, in_nc=4, out_nc=4))
+    net.load_state_dict({k: v.clone() for k, v in sd.items()}); net = net.cuda().eval()
+    g = torch.Generator().manual_seed(13)
+    hr = (torch.rand(1, 4, 1736, 2312, generator=g) ** 2.2)
+    ratio = 8.0
+    lr = (hr / ratio + torch.randn(1, 4, 1736, 2312, generator=g) * 0.004)          # dark, un-brightened input (dst.ori = True)
+    out = evaluate(net, lr.cuda(), hr.cuda(), ratio=ratio, ori=True, brightness_correct=True, epoch=-1)
+    got = out['metrics'].cpu().numpy()
+    assert out['dn'].shape == hr.shape
+    nthr = torch.get_num_threads()
+    with torch.no_grad():
+        p = F.pad(lr, (4, 4, 4, 4), mode='reflect')
+        dn = O.unet_forward(sd, p, res=True)[..., 4:-4, 4:-4]
+        lr_c = (lr * ratio).clamp(0, 1); dn = (dn * ratio).clamp(0, 1)
+        dn = O.illuminance_correct(dn, hr)
+    tgt = M.tensor2im(hr.numpy())
+    ref = [M.psnr(tgt, M.tensor2im(dn.numpy())), M.ssim(tgt, M.tensor2im(dn.numpy())),
+           M.psnr(tgt, M.tensor2im(lr_c.numpy())), M.ssim(tgt, M.tensor2im(lr_c.numpy()))]
+    torch.set_num_threads(nthr)
+    assert abs(got[0] - ref[0]) < 1e-3 and abs(got[2] - ref[2]) < 1e-3, (got, ref)
+    assert abs(got[1] - ref[1]) < 2e-5 and abs(got[3] - ref[3]) < 2e-5, (got, ref)
+    loop = EvalLoop(net, ori=True, brightness_correct=True)
+    loop.step('frame_a', lr.cuda(), hr.cuda(), ratio=ratio)
+    loop.step('frame_b', lr.cuda(), hr.cuda(), ratio=ratio)
+    metrics, text = loop.finish(epoch=-1)
+    assert list(metrics) == ['frame_a', 'frame_b'] and abs(metrics['frame_a'][0] - ref[0]) < 1e-3
+    import re
+    lines = text.splitlines()
+    assert re.fullmatch(r'Epoch -1: PSNR=\d+\.\d\d', lines[0])
+    assert re.fullmatch(r'psnrs_lr=\d+\.\d\d, psnrs_dn=\d+\.\d\d', lines[1])
+    assert re.fullmatch(r'ssims_lr=\d\.\d{4}, ssims_dn=\d\.\d{4}', lines[2])
+    nums = [float(v) for v in re.findall(r'=(-?\d+\.\d+)', text)]
+    assert np.allclose(nums, [ref[0], ref[2], ref[0], ref[3], ref[1]], atol=6e-3)

@@ -54,3 +54,31 @@ def test_noiseflow_runfile_fits_the_proxy(capsys):
     assert len(lines) == 4 and lines[0].startswith('Epoch 0001')
     nll = [float(l.split('nll')[1].split('|')[0]) for l in lines]
     assert np.isfinite(nll).all() and nll[-1] < nll[0] - 0.05, nll
+
+
+@pytest.mark.gpu
+def test_arch_proxy_runfile_trains_on_noiseflow_samples(capsys, monkeypatch):
+    """runfiles/IMX686/NF.yml schema (BASELINE config 5): `arch_proxy` + dst.dataset = IMX686_NF_Syn_Dataset must route the
+    train step through NoiseFlow.sample (trainer_SID.py:33-42, trainer_LRID.py:419-427) -- not silently through the
+    physics sampler -- with the LRID ratio list; a run file naming a proxy dataset without `arch_proxy` fails like the
+    reference (no self.proxy_net)."""
+    from pnnp_amd import archs, runfile
+    from pnnp_amd.trainer import HipTrainStep
+    rf = os.path.join(HERE, 'fixtures', 'runfile_imx686_nf.yml')
+    cfg = runfile.load(rf)
+    np.random.seed(0); torch.manual_seed(0)
+    net, step, lr_of, sh = runfile.build(cfg)
+    assert isinstance(step.proxy_net, archs.NoiseFlow) and not step.proxy_net.training          # .eval() (trainer_SID.py:42)
+    assert step.proxy_ratio_choices == (1, 2, 4, 8, 16)
+    calls = []
+    real = step.proxy_net.sample
+    monkeypatch.setattr(step.proxy_net, 'sample', lambda **kw: (calls.append(kw['iso']), real(**kw))[1])
+    monkeypatch.setattr(HipTrainStep, 'make_noisy', lambda *a, **k: (_ for _ in ()).throw(AssertionError('physics sampler used')))
+    hr = torch.rand(sh['batch'], sh['channels'], 64, 64, device='cuda') * 0.05
+    out = step.step(hr, iso=6400)
+    assert calls == [6400] and torch.isfinite(out).all()
+    assert runfile.main([rf, '--synthetic', '--epochs', '2', '--steps', '3']) == 0
+    assert len([l for l in capsys.readouterr().out.splitlines() if l.startswith('Epoch')]) == 2
+    del cfg['arch_proxy']
+    with pytest.raises(KeyError):
+        runfile.build(cfg)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # on the GPU box, from the repo root: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of bench.py -> profiles-style CSVs + traffic.json
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_f /tmp/pmc_w
+# usage: bash tools/pmc_traffic.sh [commit]   (the commit is recorded in traffic.json next to the kernel-source hash)
+mkdir -p /root/repo/gpurun_out; cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/pmc_f /tmp/pmc_w
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pmc_f -o f --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pmc_w -o w --output-format csv -- python3 /root/repo/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
 cd /root/repo
@@ -13,4 +14,4 @@ for src, dst in ((sys.argv[1], 'gpurun_out/pmc_fetch_size.csv'), (sys.argv[2], '
     keep = [r for r in rows if any(k in r['Kernel_Name'] for k in ('wino_kernel', 'wino_wgrad_kernel', 'igemm_kernel<9', 'wgrad_kernel<9'))]
     w = csv.DictWriter(open(dst, 'w', newline=''), fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
 PY
-python tools/traffic_from_pmc.py gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv gpurun_out/traffic.json
+python tools/traffic_from_pmc.py gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv gpurun_out/traffic.json "$1"

@@ -3,8 +3,11 @@
 HBM bytes per launch of the dominant kernel classes (wino_kernel, igemm_kernel<9,...>, the weight-gradient kernels), corrected as
 MI355X_MICROARCH.md prescribes (FETCH_SIZE counts 64 B per 128-B request of wide coalesced reads: x2;
 both counters are in KiB)."""
-import collections, csv, json, re, sys
+import collections, csv, json, os, re, sys
 fetch_csv, write_csv, out = sys.argv[1:4]
+commit = sys.argv[4] if len(sys.argv) > 4 else None       # the commit the passes ran on (the GPU box has no .git: pass it in)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 def load(path, name):
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
@@ -24,5 +27,9 @@ for cls, pred in (('igemm9', lambda k: k.startswith('igemm_kernel<9')), ('wgrad9
     fs = sum(v[1] for k, v in f.items() if pred(k)); ws = sum(v[1] for k, v in w.items() if pred(k))
     res[cls] = {'launches': n, 'fetch_kib_per_launch_raw': fs / n, 'write_kib_per_launch': ws / n,
                 'hbm_bytes_per_launch': (2 * fs + ws) * 1024 / n}
+# bench.py attaches these numbers to its `roofline.traffic` only while the kernel sources still hash to csrc_sha
+res['csrc_sha'] = bench.csrc_sha()
+res['commit'] = commit
+res['command'] = 'python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-events (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)'
 json.dump(res, open(out, 'w'), indent=1)
 print(json.dumps(res))
