@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-2 GPU suite (run on the GPU box from the repo root):  bash tools/r2_suite.sh <tag> <commit>
+# tests, bench line, rocprofv3 kernel stats of the same command, PMC traffic passes, config-5 line + stats, RCCL overlap trace.
+TAG=${1:-a}; COMMIT=${2:-unknown}
+OUT=/root/repo/gpurun_out/r2$TAG; mkdir -p $OUT
+cd /root/repo
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
+if [ -z "$SKIP_TESTS" ]; then
+timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -25 > $OUT/pytest.log
+fi
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/rp_*
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_b -o b --output-format csv -- python3 /root/repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_bench.err
+cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+# config 5 (ResUnet + NoiseFlow proxy, B=12)
+cd /root/repo
+timeout 600 python bench.py --arch resunet --noise noiseflow --batch 12 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_c5 -o c --output-format csv -- python3 /root/repo/bench.py --arch resunet --noise noiseflow --batch 12 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_config5_under_rocprof.json 2> /dev/null
+cp $(find /tmp/rp_c5 -name "*kernel_stats.csv" | head -1) $OUT/bench_config5_kernel_stats.csv
+# RCCL kernels on the side stream vs the backward pass (1-rank group, forced reducer)
+timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_r -o r --output-format csv -- python3 /root/repo/bench.py --force-reducer --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/bench_force_reducer.json 2> $OUT/rocprof_reducer.err
+cd /root/repo
+python tools/overlap_from_trace.py $(find /tmp/rp_r -name "*kernel_trace.csv" | head -1) $OUT/rccl_overlap.json > $OUT/rccl_overlap.txt 2>&1
+# HBM traffic of the conv kernels (two --pmc passes)
+timeout 900 bash tools/pmc_traffic.sh $COMMIT > $OUT/pmc.log 2>&1
+cp gpurun_out/traffic.json gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv $OUT/ 2>/dev/null
+ls -la $OUT
