@@ -81,10 +81,10 @@ def init_state(shapes, seed=0, std=0.02):
     return {k: torch.randn(v, generator=g) * std for k, v in shapes.items()}
 
 
-def init_state_he(shapes, seed=0, bias_std=0.02, res_scale=1.0):
+def init_state_he(shapes, seed=0, bias_std=0.02, res_scale=1.0, head_scale=1.0, head_bias=0.0):
     """Variance-preserving weights (std = sqrt(1.92 / fan_in), the LeakyReLU(0.2) gain) so that a 10-level nf=32 network
     keeps O(1) activations and live gradients in every layer -- N(0, 0.02) gives a nearly dead net at full depth.  Used by
-    the 512x512 backward golden (ResUnet: res_scale = 0.25) (tests/golden/make_golden.py `nets512`) and the test that replays it."""
+    the 512x512 backward golden (res_scale = 0.25, head_scale = 0.004, head_bias = 0.5) (tests/golden/make_golden.py `nets512`) and the test that replays it."""
     g = torch.Generator().manual_seed(seed)
     out = {}
     for k, v in shapes.items():
@@ -98,6 +98,11 @@ def init_state_he(shapes, seed=0, bias_std=0.02, res_scale=1.0):
                 out[k] = out[k] * res_scale
         else:
             out[k] = torch.randn(v, generator=g) * bias_std
+    # the 1x1 output layer (conv10_1 / conv10): head_scale < 1 with head_bias = 0.5 keeps every prediction well inside (0, 1), so
+    # the clamp of the loss never bites and its gradient is dense (what a trained denoiser looks like)
+    for k in out:
+        if k.startswith('conv10'):
+            out[k] = out[k] * head_scale + (head_bias if k.endswith('.bias') else 0.0)
     return out
 
 

@@ -307,36 +307,60 @@ def gen_nets(archs, losses):
 
 
 def gen_nets512(archs, losses):
-    """G4b: loss.backward() of the reference modules at the benchmark's full crop size (1 x 4 x 512 x 512, nf = 32) on
-    variance-preserving weights (oracle.net_torch.init_state_he: live gradients in all layers): loss, output probes and,
-    per parameter tensor, 64 probe elements + sum + L2 of its gradient."""
+    """G4b: loss.backward() of the reference modules at the benchmark's full crop size (1 x 4 x 512 x 512, nf = 32).
+
+    L1(clamp(pred), t) is discontinuous in pred (sign of pred - t, the clamp's pass-through mask): with random targets a
+    last-bit difference between two fp32 implementations flips a few signs, and one flip moves a weight gradient by
+    O(1/sqrt(active outputs)) -- 0.1-3 % here, measured between the direct and the Winograd kernels and against torch-CPU
+    alike.  The fixture therefore keeps the reference's loss but puts it where it is stable: variance-preserving weights
+    with a small output head (oracle.net_torch.init_state_he: predictions 0.5 +- ~0.1, the clamp never bites, dense
+    gradient) and BINARY targets t in {0, 1} (|pred - t| >= ~0.2: no sign can flip).  What is left are (Leaky)ReLU mask
+    and max-pool argmax flips of single elements under a dense gradient -- negligible.
+    Even so, fp32 itself limits the agreement at this depth and size: the reference module run in float32 and in float64
+    (same weights, same input) disagree by ~2e-3 relative L2 per gradient tensor (1e-6 on the loss).  The fixture therefore
+    stores BOTH runs of the reference -- `g:<name>:val` (float32, what the trainer computes) and `g64:<name>:val` (float64,
+    the ground truth) at 1024 probe positions per tensor, plus sum / L2 of the float32 gradient -- and the test holds the
+    HIP path to "as close to the truth as the reference's own float32 run" instead of to an unattainable distance from
+    the float32 run."""
     import torch
     sys.path.insert(0, REPO)
     from oracle import net_torch as O
     torch.set_num_threads(8)
     for arch, cls, shapes_fn in (('unet', archs.UNetSeeInDark, O.unet_param_shapes),
                                  ('resunet', archs.ResUnet, O.resunet_param_shapes)):
-        net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
-        sd = O.init_state_he(shapes_fn(nf=32), seed=11, res_scale=0.25)
-        net.load_state_dict(sd)
+        sd = O.init_state_he(shapes_fn(nf=32), seed=11, res_scale=0.25, head_scale=0.004, head_bias=0.5)
         g = torch.Generator().manual_seed(2)
         x = torch.rand(1, 4, 512, 512, generator=g)
-        t = torch.rand(1, 4, 512, 512, generator=g)
-        y = net(x)
-        loss = losses.Unet_Loss()(y.clamp(0, 1), t)
-        loss.backward()
-        pr = probes(y.detach().numpy(), 1024)
-        out = {'loss': np.float64(loss.item()), 'y:idx': pr['idx'], 'y:val': pr['val'], 'y:sum': np.array([pr['sum'], pr['l2']]),
+        t = (torch.rand(1, 4, 512, 512, generator=g) > 0.5).float()
+        runs = {}
+        for dt in (torch.float32, torch.float64):
+            net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
+            net.load_state_dict(sd)
+            net = net.to(dt)
+            y = net(x.to(dt))
+            loss = losses.Unet_Loss()(y.clamp(0, 1), t.to(dt))
+            loss.backward()
+            runs[dt] = (y.detach(), loss.item(), {k: p.grad.detach() for k, p in net.named_parameters()})
+        y, loss, grads = runs[torch.float32]
+        y64, loss64, grads64 = runs[torch.float64]
+        pr = probes(y.numpy(), 1024)
+        out = {'loss': np.float64(loss), 'loss64': np.float64(loss64), 'y:idx': pr['idx'], 'y:val': pr['val'],
+               'y64:val': y64.numpy().reshape(-1)[pr['idx']], 'y:sum': np.array([pr['sum'], pr['l2']]),
                'x_sha': np.array(sha(x.numpy())), 't_sha': np.array(sha(t.numpy())),
                'w_sha': np.array(sha(np.concatenate([v.numpy().reshape(-1) for v in sd.values()]))),
-               'inside': np.float64(((y > 0) & (y < 1)).float().mean().item())}
-        for k, p in net.named_parameters():
-            pg = probes(p.grad.numpy(), 64)
+               'y_range': np.array([y.min().item(), y.max().item()])}
+        assert 0.02 < out['y_range'][0] and out['y_range'][1] < 0.98, out['y_range']
+        worst = 0.0
+        for k in grads:
+            pg = probes(grads[k].numpy(), 1024)
             out['g:' + k + ':idx'] = pg['idx']; out['g:' + k + ':val'] = pg['val']
+            out['g64:' + k + ':val'] = grads64[k].numpy().reshape(-1)[pg['idx']]
             out['g:' + k + ':sum'] = np.array([pg['sum'], pg['l2']])
+            e = float((grads[k].double() - grads64[k]).norm() / grads64[k].norm())
+            out['g:' + k + ':err32'] = np.float64(e)             # the reference's own float32 error on the WHOLE tensor
+            worst = max(worst, e)
         np.savez_compressed(os.path.join(HERE, f'{arch}_nf32_512_bwd.npz'), **out)
-        print(arch, 'loss', loss.item(), 'fraction of outputs inside (0,1):', float(out['inside']),
-              'min grad l2', min(float(out[k][1]) for k in out if k.endswith(':sum') and k.startswith('g:')))
+        print(arch, 'loss', loss, loss64, 'output range', out['y_range'], 'worst float32-vs-float64 gradient rel L2 of the reference:', worst)
 
 
 # ------------------------------------------------------------------ G6/G7 misc

@@ -31,7 +31,7 @@ def _he_net(arch, seed=11):
     from oracle import net_torch as O
     from pnnp_amd.archs import ResUnet, UNetSeeInDark
     cls, shapes = (UNetSeeInDark, O.unet_param_shapes) if arch == 'unet' else (ResUnet, O.resunet_param_shapes)
-    sd = O.init_state_he(shapes(nf=32), seed=seed, res_scale=0.25)
+    sd = O.init_state_he(shapes(nf=32), seed=seed, res_scale=0.25, head_scale=0.004, head_bias=0.5)
     net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
     net.load_state_dict({k: v.clone() for k, v in sd.items()})
     return net.cuda(), sd
@@ -55,30 +55,41 @@ def _grads(net):
 @pytest.mark.parametrize('arch', ['unet', 'resunet'])
 @pytest.mark.parametrize('wino', [True, False])
 def test_512_crop_backward_vs_reference_golden(golden_dir, arch, wino):
-    """One crop at the benchmark's size against the reference modules' own loss.backward().  Bars: loss 5e-6 absolute;
-    output probes rtol 1e-4 / atol 2e-5 (activations are O(1) here); per gradient tensor L2 within 2e-3 relative and
-    the 64 probes within 2e-3 of the tensor's largest probe (L1 sign, max-pool argmax and (Leaky)ReLU masks are
-    discontinuous: last-bit forward differences flip a few of them)."""
+    """One crop at the benchmark's size against the reference modules' own loss.backward() (make_golden.py `nets512`:
+    stable-sign construction, float32 AND float64 runs of the reference).  At this depth and size float32 itself limits
+    agreement: the reference's float32 gradients are 1.5e-3 .. 2.2e-3 (relative L2 per tensor) from its float64 gradients.
+    (The targets make the gradient field white noise: a weight gradient is a sum of 262144 random-sign terms, condition
+    number ~512, so the summation order shows: measured ratios HIP-error / reference-error are 0.8-1.4 in the median and up to
+    4.5 on single tensors where torch's blocked summation happens to land closer.)
+    Bars: loss within 5e-6 of the reference's float32 loss; output probes rtol 1e-4 / atol 2e-6; every gradient tensor, on
+    the 1024 probe positions, within 6x the reference-float32-vs-float64 error of the float64 truth (+1e-5), the median
+    ratio over tensors <= 2, and every L2 norm within 2e-3 of the reference's."""
     from pnnp_amd.trainer import HipTrainStep
     g = np.load(os.path.join(golden_dir, f'{arch}_nf32_512_bwd.npz'))
     net, sd = _he_net(arch)
     gen = torch.Generator().manual_seed(2)
     x = torch.rand(1, 4, 512, 512, generator=gen)
-    t = torch.rand(1, 4, 512, 512, generator=gen)
+    t = (torch.rand(1, 4, 512, 512, generator=gen) > 0.5).float()
     net.engine.set_policy(wino=wino)
     ts = HipTrainStep(net, lr=0.0, clip=0)
     lo = ts.step(t.cuda(), noisy=x.cuda())
     assert abs(float(lo[0]) - float(g['loss'])) < 5e-6, (float(lo[0]), float(g['loss']))
     with torch.no_grad():
         y = net(x.cuda()).cpu().numpy().reshape(-1)
-    np.testing.assert_allclose(y[g['y:idx']], g['y:val'], rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y[g['y:idx']], g['y:val'], rtol=1e-4, atol=2e-6)
+    worst, ratios = (0.0, None), []
     for k, p in net.named_parameters():
-        got = net.engine.params.grad_view(k, p.shape).cpu().numpy().reshape(-1)
-        ref = g['g:' + k + ':val']
-        tol = 2e-3 * np.abs(ref).max() + 1e-9
-        assert np.abs(got[g['g:' + k + ':idx']] - ref).max() <= tol, (k, float(np.abs(got[g['g:' + k + ':idx']] - ref).max()), tol)
+        got = net.engine.params.grad_view(k, p.shape).cpu().numpy().reshape(-1).astype(np.float64)
+        idx = g['g:' + k + ':idx']
+        truth = g['g64:' + k + ':val']
+        e_ref = np.linalg.norm(g['g:' + k + ':val'].astype(np.float64) - truth) / np.linalg.norm(truth)      # the reference's own float32 error
+        e_hip = np.linalg.norm(got[idx] - truth) / np.linalg.norm(truth)
+        worst = max(worst, (e_hip / (e_ref + 4e-6), k)); ratios.append(e_hip / (e_ref + 4e-6))
+        assert e_hip <= 6 * e_ref + 1e-5, (k, e_hip, e_ref)
         l2 = float(g['g:' + k + ':sum'][1])
-        assert abs(float(np.sqrt((got.astype(np.float64) ** 2).sum())) - l2) <= 2e-3 * l2 + 1e-9, k
+        assert abs(float(np.sqrt((got ** 2).sum())) - l2) <= 2e-3 * l2 + 1e-12, k
+    assert np.median(ratios) <= 2.0, np.median(ratios)
+    print(f'{arch} wino={wino}: worst HIP error / reference-fp32 error (both vs fp64) = {worst[0]:.2f} at {worst[1]}')
 
 
 def test_batch_of_16_crops_is_16_independent_crops_and_wino_equals_direct():
@@ -97,12 +108,14 @@ def test_batch_of_16_crops_is_16_independent_crops_and_wino_equals_direct():
 def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
     """Config 3's backward at full size (16 x 4 x 512 x 512, nf = 32): split-K slabs, 32-bit buffer offsets and the
     pixel-range partition of the weight-gradient kernels see the whole batch here.  One HipTrainStep(lr=0) per kernel
-    family: every gradient tensor agrees to 2e-4 relative L2, and equals the mean of the 16 single-crop gradients."""
+    family: every gradient tensor agrees to 1e-2 relative L2 -- float32 rounding alone moves these gradients by ~2e-3 (the
+    reference's own float32 vs float64 runs on one crop, see the golden test above), an indexing / partition bug by O(1)
+    -- and equals the mean of the 16 single-crop gradients (same kernels, only the split-K partition differs)."""
     from pnnp_amd.trainer import HipTrainStep
     net, _ = _he_net('unet')
     g = torch.Generator(device='cuda').manual_seed(4)
     x = torch.rand(16, 4, 512, 512, device='cuda', generator=g)
-    t = torch.rand(16, 4, 512, 512, device='cuda', generator=g)
+    t = (torch.rand(16, 4, 512, 512, device='cuda', generator=g) > 0.5).float()
     ts = HipTrainStep(net, lr=0.0, clip=0)
     out = {}
     for wino in (True, False):
@@ -113,7 +126,7 @@ def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
     for k in out[True][1]:
         a, b = out[True][1][k], out[False][1][k]
         rel = float((a - b).norm() / (b.norm() + 1e-20))
-        assert rel < 2e-4, (k, rel)
+        assert rel < 1e-2, (k, rel)
     # linearity over the batch: loss = mean over crops  =>  batch gradient = mean of single-crop gradients
     net.engine.set_policy(wino=True)
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in out[True][1].items()}
@@ -127,7 +140,7 @@ def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
     for k, v in out[True][1].items():
         ref = (acc[k] / 16)
         rel = float((v.double() - ref).norm() / (ref.norm() + 1e-20))
-        assert rel < 2e-5, (k, rel)                             # same kernels, different split-K partition / summation order
+        assert rel < 2e-3, (k, rel)                             # same kernels, different split-K partition / summation order
 
 
 def test_full_sid_frame_wino_equals_direct():

@@ -190,15 +190,15 @@ def test_ori_multiplies_prediction_by_ratio_before_the_loss():
     ts = HipTrainStep(net, lr=0.0, clip=0, ori=True)
     with pytest.raises(PnnpError):
         ts.step(t.cuda(), noisy=x.cuda())                       # ori without a ratio must not silently drop the scaling
-    lo = ts.step(t.cuda(), noisy=x.cuda(), ratio=ratio.cuda())
-    assert abs(float(lo[0]) - loss_ref.item()) < 2e-6
+    loss_ori = float(ts.step(t.cuda(), noisy=x.cuda(), ratio=ratio.cuda())[0])          # (the returned tensor is a reused buffer)
+    assert abs(loss_ori - loss_ref.item()) < 2e-6
     for k, p in net.named_parameters():
         got = net.engine.params.grad_view(k, p.shape).cpu()
         ref = leaves[k].grad
         assert float((got - ref).norm() / (ref.norm() + 1e-12)) < 2e-3, k
     # and it is not the un-scaled objective
     lo1 = HipTrainStep(net, lr=0.0, clip=0, ori=False).step(t.cuda(), noisy=x.cuda())
-    assert abs(float(lo1[0]) - float(lo[0])) > 1e-3
+    assert abs(float(lo1[0]) - loss_ori) > 1e-3
 
 
 def test_autograd_path_refuses_overwritten_activations():
