@@ -164,6 +164,24 @@ int pnnp_pack_jobs_add_wino(PnnpPackJob* jobs, int* n, int cap, const float* w, 
                             int Cout, int Cin);
 int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const float* w, float* dst, int Cout, int Cin);
 
+/* ---- Conv2d 3x3 / stride 1 / pad 1 on the bf16 matrix cores with float32 operands split into three bf16 pieces
+ * (csrc/conv_x3.hip: a = hi + mid + lo exactly, six of the nine piece products kept, fp32 accumulation -- float32-accurate
+ * results at 6/16 of the fp32-MFMA time).  Same contracts as pnnp_conv_fwd_f32 / pnnp_conv_bwd_data_f32 /
+ * pnnp_conv_bwd_data_res_f32 with taps = 9 (archs/Unet.py:16-52,54-92; archs/modules.py:176-197); the weights are x3 packs:
+ * kind-2 jobs of the pack table, pnnp_x3_weight_bytes(K, N) bytes each (K = channels reduced over, N = channels written). */
+int pnnp_x3_supported(int K, int N);
+int64_t pnnp_x3_weight_bytes(int K, int N);
+int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/,
+                          int Cout, int Cin, int Cin_pad);
+int pnnp_conv3x3_x3_fwd_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias,
+                            const float* residual, float* y, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad,
+                                 float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                 float* dx2 /*or null*/, int C2, const float* mask2, int mode2, int accum2,
+                                 int B, int H, int W, void* stream);
+int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int C1,
+                                     const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream);
+
 /* (The Winograd kernel's cycle-stamp hook `pnnp_wino_set_debug` exists only in profiling builds, -DPNNP_WINO_DEBUG=1: the shipped
  * library exports no debug hook, reads no environment variable and keeps no state between calls besides idempotent per-device
  * caches of device facts.) */

@@ -3,6 +3,7 @@
 #include "igemm.h"
 
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s);
+int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);       // csrc/conv_x3.hip (3x3, bf16x3 split)
 
 namespace {
 
@@ -21,6 +22,43 @@ void base_args(IgemmArgs& a) {
     a = IgemmArgs{};
     a.in_mul = 1; a.out_mul = 1;
     a.n_split = 1 << 30;
+}
+
+// argument builders shared by the fp32-MFMA entry points and their bf16x3 twins
+void fwd_args(IgemmArgs& a, const float* x1, int C1, const float* x2, int C2, const void* w_packed, const float* bias,
+              const float* residual, float* y, int B, int H, int W, int Cout, int act) {
+    base_args(a);
+    a.seg[0] = IgemmSeg{x1, C1, 0, 0, 0};
+    a.nseg = 1;
+    if (x2) { a.seg[1] = IgemmSeg{x2, C2, 0, 0, 0}; a.nseg = 2; }
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = reinterpret_cast<const float*>(w_packed); a.Ntot = Cout;
+    a.dst[0] = y; a.dst_cs[0] = Cout;
+    a.bias = bias; a.act = act; a.addsrc = residual;
+}
+
+void bwd_args(IgemmArgs& a, const float* g, int Cout, const void* w_dgrad, float* dx1, int C1, const float* mask1, int mode1, int accum1,
+              float* dx2, int C2, const float* mask2, int mode2, int accum2, int B, int H, int W) {
+    base_args(a);
+    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = reinterpret_cast<const float*>(w_dgrad); a.Ntot = C1 + (dx2 ? C2 : 0);
+    a.dst[0] = dx1; a.dst_cs[0] = C1; a.mask[0] = mask1; a.mask_mode[0] = mask1 ? mode1 : 0; a.accum[0] = accum1;
+    if (dx2) {
+        a.n_split = C1;                              // destination is chosen per output column (lane)
+        a.dst[1] = dx2; a.dst_cs[1] = C2; a.mask[1] = mask2; a.mask_mode[1] = mask2 ? mode2 : 0; a.accum[1] = accum2;
+    }
+}
+
+void bwd_res_args(IgemmArgs& a, const float* g, int Cout, const void* w_dgrad, float* dx, int C1, const float* addsrc, const float* mask,
+                  int mode, int B, int H, int W) {
+    base_args(a);
+    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = reinterpret_cast<const float*>(w_dgrad); a.Ntot = C1;
+    a.dst[0] = dx; a.dst_cs[0] = C1; a.addsrc = addsrc; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
 }
 
 }  // namespace
@@ -61,14 +99,8 @@ int pnnp_conv_fwd_f32(const float* x1, int C1, const float* x2, int C2, const fl
                       const float* residual, float* y, int B, int H, int W, int Cout, int taps, int act, void* stream) {
     if (!x1 || !w_packed || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    a.seg[0] = IgemmSeg{x1, C1, 0, 0, 0};
-    a.nseg = 1;
-    if (x2) { a.seg[1] = IgemmSeg{x2, C2, 0, 0, 0}; a.nseg = 2; }
-    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
-    a.w = w_packed; a.Ntot = Cout;
-    a.dst[0] = y; a.dst_cs[0] = Cout;
-    a.bias = bias; a.act = act; a.addsrc = residual;
+    IgemmArgs a;
+    fwd_args(a, x1, C1, x2, C2, w_packed, bias, residual, y, B, H, W, Cout, act);
     return pnnp_igemm_launch(a, taps, C1, as_stream(stream));
 }
 
@@ -82,16 +114,8 @@ int pnnp_conv_bwd_data_f32(const float* g, int Cout, const float* w_dgrad,
                            int B, int H, int W, int taps, void* stream) {
     if (!g || !w_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
-    a.nseg = 1;
-    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
-    a.w = w_dgrad; a.Ntot = C1 + (dx2 ? C2 : 0);
-    a.dst[0] = dx1; a.dst_cs[0] = C1; a.mask[0] = mask1; a.mask_mode[0] = mask1 ? mode1 : 0; a.accum[0] = accum1;
-    if (dx2) {
-        a.n_split = C1;                              // destination is chosen per output column (lane)
-        a.dst[1] = dx2; a.dst_cs[1] = C2; a.mask[1] = mask2; a.mask_mode[1] = mask2 ? mode2 : 0; a.accum[1] = accum2;
-    }
+    IgemmArgs a;
+    bwd_args(a, g, Cout, w_dgrad, dx1, C1, mask1, mode1, accum1, dx2, C2, mask2, mode2, accum2, B, H, W);
     return pnnp_igemm_launch(a, taps, Cout, as_stream(stream));
 }
 
@@ -101,13 +125,43 @@ int pnnp_conv_bwd_data_res_f32(const float* g, int Cout, const float* w_dgrad, f
                                const float* addsrc, const float* mask, int mode, int B, int H, int W, int taps, void* stream) {
     if (!g || !w_dgrad || !dx || !addsrc || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    a.seg[0] = IgemmSeg{g, Cout, 0, 0, 0};
-    a.nseg = 1;
-    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
-    a.w = w_dgrad; a.Ntot = C1;
-    a.dst[0] = dx; a.dst_cs[0] = C1; a.addsrc = addsrc; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+    IgemmArgs a;
+    bwd_res_args(a, g, Cout, w_dgrad, dx, C1, addsrc, mask, mode, B, H, W);
     return pnnp_igemm_launch(a, taps, Cout, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- 3x3 / stride 1 / pad 1 on the bf16 matrix cores (bf16x3 split)
+// Same contracts as pnnp_conv_fwd_f32 / pnnp_conv_bwd_data_f32 / pnnp_conv_bwd_data_res_f32 with taps = 9; the weights are the x3
+// packs of pnnp_pack_jobs_add_x3 (C1 < 16 allowed: the pack's reduction length is padded to 16).
+int pnnp_x3_supported(int K, int N) { return (K > 0 && (K % 8) == 0 && N > 0 && (N % 32) == 0) ? 1 : 0; }
+
+int pnnp_conv3x3_x3_fwd_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias,
+                            const float* residual, float* y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_x3 || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    fwd_args(a, x1, C1, x2, C2, w_x3, bias, residual, y, B, H, W, Cout, act);
+    return pnnp_igemm_x3_launch(a, C1, as_stream(stream));
+}
+
+int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad,
+                                 float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                 float* dx2, int C2, const float* mask2, int mode2, int accum2,
+                                 int B, int H, int W, void* stream) {
+    if (!g || !w_x3_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    bwd_args(a, g, Cout, w_x3_dgrad, dx1, C1, mask1, mode1, accum1, dx2, C2, mask2, mode2, accum2, B, H, W);
+    return pnnp_igemm_x3_launch(a, Cout, as_stream(stream));
+}
+
+int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int C1,
+                                     const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream) {
+    if (!g || !w_x3_dgrad || !dx || !addsrc || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    bwd_res_args(a, g, Cout, w_x3_dgrad, dx, C1, addsrc, mask, mode, B, H, W);
+    return pnnp_igemm_x3_launch(a, Cout, as_stream(stream));
 }
 
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47

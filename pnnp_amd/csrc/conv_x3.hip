@@ -1,0 +1,377 @@
+// 3x3 convolution (forward / backward-data) with fp32 operands SPLIT INTO THREE bf16 PIECES, on the bf16 matrix cores.
+//
+// Why: on gfx950 the fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at the fp32 VECTOR rate -- 157 TFLOP/s, 1/16 of the bf16
+// MFMA rate, and it blocks the SIMD's vector issue while it runs.  A float32 value a is EXACTLY
+//      a = hi + mid + lo,   hi = bf16(a), mid = bf16(a - hi), lo = bf16(a - hi - mid)
+// (3 x 8 significand bits + signs cover the 24-bit significand; both subtractions are exact in fp32), so a product of two
+// float32 values is the sum of nine bf16 x bf16 products, each of which the matrix core forms exactly and adds into an
+// fp32 accumulator.  Six of the nine are kept:
+//      a*b ~= hi*hi' + (hi*mid' + mid*hi') + (hi*lo' + lo*hi' + mid*mid')          dropped: mid*lo', lo*mid', lo*lo' <= 2^-24 |ab|
+// i.e. the truncation is one fp32 rounding per product -- the same order as the rounding of the fp32 MFMA's own multiply --
+// while v_mfma_f32_32x32x16_bf16 does 8x the multiply-adds of the fp32 instruction in half its cycles: 6 passes cost
+// 6/16 of the fp32 MFMA time (2.67x), and the VALU / LDS / global work of the loop now runs UNDER the matrix pipe instead
+// of in front of it.  Results stay float32-accurate (tests: same tolerances as the fp32-MFMA kernels, and the 512x512
+// gradient test measures the error against a float64 run of the reference next to the reference's own float32 error).
+//
+// Structure (reference ops: archs/Unet.py:16-52 Conv2d 3x3 pad 1 (+LeakyReLU), archs/modules.py:130-197):
+//   M = output pixels: tile of 8 rows x 32 px; N = BN = 32 or 64 output channels; K = 16 channels x one filter ROW
+//   (3 taps) per work item.  Persistent workgroups (4 waves, each 2 pixel rows x BN channels) walk (tile, channel chunk,
+//   filter row) items:
+//     * activations: fp32 NHWC halo tile (10 x 34 px x 16 ch) global -> registers (buffer loads, hardware zero for the
+//       halo outside the image) -> split into hi/mid/lo -> LDS planes xs[k-octet][piece][pixel][8 bf16]; loaded one
+//       chunk ahead (issue early / write late), re-used by the three filter rows;
+//     * weights: pre-split and pre-ordered per (32-channel block, chunk, tap) at pack time (csrc/pack_jobs.hip kind 2), so
+//       an item's 9 / 18 KB come in by LDS-DMA (buffer_load ... lds, no registers, no VALU), double buffered, one item ahead;
+//     * one ds_read_b128 = the 8 k-values a lane feeds to one v_mfma_f32_32x32x16_bf16; per filter tap a wave reads
+//       (2 + BN/32) x 3 operands and issues 2 x BN/32 x 6 MFMAs;
+//     * epilogue as in csrc/conv_igemm.hip (bias, activation, act' mask, residual, accumulate, split destinations,
+//       16-byte stores through a wave-private LDS patch).
+#include "igemm.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
+
+namespace {
+
+constexpr int TH = 8, HR = TH + 2, HC = 34, NPIX = HR * HC;       // 340 halo pixels
+constexpr int XS_BYTES = 2 * 3 * NPIX * 16;                        // [k-octet 2][piece 3][pixel][16 B]
+constexpr int WBLK = 3 * 2 * 3 * 32 * 16;                          // one filter row of one 32-channel block: [tap 3][octet 2][piece 3][32][16 B] = 9216
+constexpr int NSLOT = 3;                                           // halo staging slots per thread: 680 (pixel, octet) pairs / 256
+
+template <int BN> struct X3Cfg {
+    static constexpr int NT = BN / 32;
+    static constexpr int WS_STAGE = NT * WBLK;
+    static constexpr int EPI = 4 * 2048;                           // 4 waves x (16 pixels x 32 channels) floats
+    static constexpr int LDS_BYTES = XS_BYTES + 2 * WS_STAGE + EPI;
+};
+
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // RNE, low half = a
+    unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+
+// 8 floats -> three 16-byte words of 8 bf16 each (hi, mid, lo); element e sits in bits 16(e&1) of dword e>>1
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& H, u32x4& M, u32x4& L) {
+    const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float a0 = a[2 * p], a1 = a[2 * p + 1];
+        const unsigned h = cvt_pk_bf16(a0, a1);
+        const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);      // exact
+        const unsigned m = cvt_pk_bf16(r0, r1);
+        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
+        H[p] = h; M[p] = m; L[p] = cvt_pk_bf16(s0, s1);
+    }
+}
+
+template <int BN>
+__global__ void __launch_bounds__(256, 2)
+igemm_x3_kernel(const IgemmArgs a) {
+    using Cfg = X3Cfg<BN>;
+    constexpr int NT = Cfg::NT, MT = 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);
+    char* wsb = smem + XS_BYTES;
+    float* epi = reinterpret_cast<float*>(smem + XS_BYTES + 2 * Cfg::WS_STAGE);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (the LDS-DMA pieces and barriers depend on it)
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tiles_x = (a.DW + 31) >> 5, tiles_y = (a.DH + TH - 1) / TH;
+    const int n_tiles = (a.Ntot + BN - 1) / BN;
+    const int total = tiles_x * tiles_y * a.B * n_tiles;
+    const int G = gridDim.x;
+    const int nchunks = a.nseg * a.chunks_per_seg;                  // 16-channel chunks of K
+
+    // ---- per-thread constants of the halo staging pattern: slot s = tid + 256 k -> (pixel s>>1, channel octet s&1)
+    constexpr unsigned OOB = 0x80000000u;
+    // (680 slots over 3 x 256: a thread whose third slot would be past the end repeats its second one -- same address, same
+    //  data, same thread -- so every slot is live and the staging code has no branches)
+    int rk[NSLOT], qk[NSLOT]; unsigned pixk[NSLOT]; int xdst[NSLOT];
+    const int oct = tid & 1;
+#pragma unroll
+    for (int k = 0; k < NSLOT; ++k) {
+        int s = tid + 256 * k;
+        if (s >= 2 * NPIX) s -= 256;
+        const int pix = s >> 1;
+        const int r = pix / HC, q = pix - r * HC;
+        rk[k] = r - 1;
+        qk[k] = q - 1;
+        pixk[k] = (unsigned)(r * a.IW + q);
+        xdst[k] = (oct * 3) * NPIX + pix;                           // + piece * NPIX
+    }
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+
+    struct Tile { int b, y0, x0, n0; };
+    auto decode = [&](int t) {
+        Tile o;
+        const int nt_i = t % n_tiles;
+        int m_i = t / n_tiles;
+        const int tx = m_i % tiles_x; m_i /= tiles_x;
+        o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN;
+        return o;
+    };
+
+    f32x4 ra[NSLOT][2];                                             // halo registers of the NEXT chunk (8 channels per slot)
+
+    // global loads of the halo tile of (tile, chunk g) -> ra (no wait)
+    auto load_halo = [&](const Tile& tl, int g) {
+        const int si = g / a.chunks_per_seg, cc = g - si * a.chunks_per_seg;
+        const IgemmSeg sg = a.seg[si];
+        const int c0 = sg.coff + cc * 16;
+        const int rlo = -tl.y0, rhi = a.IH - tl.y0, qlo = -tl.x0, qhi = a.IW - tl.x0;
+        const int shift = (2 * a.IW + 2) * sg.cstride;             // the resource starts before the image: the scalar offset below stays >= 0
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(sg.ptr + ((int64_t)tl.b * a.IH * a.IW * sg.cstride - shift)), 0, 0x7fffffff, 0x00020000);
+        const int soff = (((tl.y0 - 1) * a.IW + tl.x0 - 1) * sg.cstride + c0 + shift) * 4;
+        const unsigned cs4 = (unsigned)sg.cstride * 4u;
+        // validity as ONE bitwise expression (a short-circuit && chain becomes per-lane branches around the loads, and the
+        // register allocator then serialises the staging with vmcnt(0) waits)
+        const int cvalid = a.seg_channels - cc * 16 - oct * 8;     // > 0: this thread's octet exists (the last chunk of a segment may be half empty)
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            const int bad = (rk[k] - rlo) | (rhi - 1 - rk[k]) | (qk[k] - qlo) | (qhi - 1 - qk[k]) | (cvalid - 1);     // sign bit set <=> outside
+            const unsigned vo = bad < 0 ? OOB : __umul24(pixk[k], cs4) + oct * 32;
+            ra[k][0] = bload(rs, vo, soff);
+            ra[k][1] = bload(rs, vo, soff + 16);
+        }
+    };
+    // split ra and write the three piece planes
+    auto store_halo = [&]() {
+#pragma unroll
+        for (int k = 0; k < NSLOT; ++k) {
+            u32x4 H, M, L;
+            split8(ra[k][0], ra[k][1], H, M, L);
+            xs[xdst[k]] = H; xs[xdst[k] + NPIX] = M; xs[xdst[k] + 2 * NPIX] = L;
+        }
+    };
+    // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: NT blocks of 9216 contiguous bytes
+    const int K16 = nchunks;
+    auto dma_weights = [&](const Tile& tl, int g, int tr, int st) {
+#pragma unroll
+        for (int i = 0; i < (NT * 9 + 3) / 4; ++i) {
+            // wave-uniform 1 KB piece of the stage; past the end a wave repeats the last piece (same bytes to the same place) instead of branching
+            const int ins = min(wave + 4 * i, NT * 9 - 1);
+            const int j = ins / 9, r = ins - 9 * j;
+            const int nb = (tl.n0 >> 5) + j;
+            const bool ok = nb * 32 < a.Ntot;
+            const int soff = ok ? ((nb * K16 + g) * 27648 + tr * WBLK + r * 1024) : 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + j * WBLK + r * 1024),
+                                                     16, ok ? (unsigned)lane * 16u : OOB, soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // MFMA over the three taps of filter row TR out of weight stage st
+    auto mfma_row = [&](int tr, int st) {
+        const char* wst = wsb + st * Cfg::WS_STAGE;
+        u32x4 av[2][MT][3], bv[2][NT][3];
+        auto lds_load = [&](int tp, u32x4 (&ax)[MT][3], u32x4 (&bx)[NT][3]) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    ax[i][p] = xs[(half * 3 + p) * NPIX + (wave * MT + i + tr) * HC + tp + l31];
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+                    bx[j][p] = *reinterpret_cast<const u32x4*>(wst + j * WBLK + (((tp * 2 + half) * 3 + p) * 32 + l31) * 16);
+        };
+        lds_load(0, av[0], bv[0]);
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            if (tp + 1 < 3) lds_load(tp + 1, av[(tp + 1) & 1], bv[(tp + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+            const u32x4 (&ax)[MT][3] = av[tp & 1];
+            const u32x4 (&bx)[NT][3] = bv[tp & 1];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+#define X3_MFMA(PA, PB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[i][PA]), __builtin_bit_cast(bf16x8, bx[j][PB]), acc[i][j], 0, 0, 0)
+                    X3_MFMA(0, 2); X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 1); X3_MFMA(1, 0); X3_MFMA(0, 0);
+#undef X3_MFMA
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
+    // channel base are wave-uniform per 32-column block); half a 32x32 tile (16 pixels) at a time through a 2 KB patch
+    auto epilogue = [&](const Tile& tl) {
+        const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
+        float* eb = epi + wave * 512;
+        const int q4 = (lane & 7) * 4, pr = lane >> 3;
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
+            const bool n_ok = nwv + q4 < a.Ntot;
+            const int du = nwv >= a.n_split ? 1 : 0;
+            const int chw = nwv - (du ? a.n_split : 0);
+            const int cs2 = a.dst_cs[du], mm2 = a.mask_mode[du], acc2 = a.accum[du];
+            const int64_t imgo = (int64_t)b * a.OH * a.OW * cs2;
+            const int ibytes = a.OH * a.OW * cs2 * 4;
+            float* dstb = a.dst[du] + imgo;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dstb, 0, ibytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(mm2 ? a.mask[du] + imgo : dstb), 0, ibytes, 0x00020000);
+            const bool use_add2 = a.addsrc && du == 0;
+            const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)(use_add2 ? a.addsrc + imgo : dstb), 0, ibytes, 0x00020000);
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nwv + q4);
+            const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f), mslope = mm2 == 1 ? 0.2f : 0.f;
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int py = y0 + wave * MT + i;
+                const bool rowok = py < a.DH;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][8 * h2 + r];
+                        acc[i][k][8 * h2 + r] = 0.f;
+                    }
+                    unsigned vo[2];
+                    f32x4 v2[2], m2[2], ad2[2];
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int p = pr + 8 * e, px = x0 + 16 * h2 + p;
+                        const bool ok2 = rowok && px < a.DW && n_ok;
+                        vo[e] = ok2 ? (unsigned)(((py * a.OW + px) * cs2 + chw + q4) * 4) : OOB;
+                        v2[e] = *reinterpret_cast<const f32x4*>(eb + p * 32 + q4);
+                    }
+                    if (mm2) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) m2[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, vo[e], 0, 0));
+                    }
+                    if (use_add2) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) ad2[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, vo[e], 0, 0));
+                    }
+                    if (acc2) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) ad2[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, vo[e], 0, 0));
+                    }
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        f32x4 o = v2[e] + bias4;
+                        if (use_add2) o += ad2[e];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+                        if (mm2) {
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] *= (m2[e][c] > 0.f) ? 1.f : mslope;
+                        }
+                        if (acc2) o += ad2[e];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[e], 0, 0);
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- main loop over (tile, 16-channel chunk); the three filter rows of a chunk are straight-line code, so every
+    // s_waitcnt below is exact: vector-memory operations complete in issue order, and the order of issue is
+    //   row 0: [weights of row 1 -> stage st^1] [halo of the NEXT chunk -> registers, 2*NSLOT loads]      row 1: [weights of row 2 -> st]
+    //   row 2: [weights of the next chunk's row 0 -> st^1]
+    int t = xcd_remap(blockIdx.x, G);
+    if (t >= total) return;
+    Tile cur = decode(t), nxt = decode(t + G < total ? t + G : t);       // nxt: the tile this workgroup takes after cur
+    int g = 0, st = 0;
+    dma_weights(cur, 0, 0, 0);
+    load_halo(cur, 0);
+    bool first = true;
+    for (;;) {
+        int ng = g + 1, nt = t;
+        if (ng == nchunks) { ng = 0; nt = t + G; }
+        const bool more = nt < total;
+        const Tile& ntile = nt == t ? cur : nxt;
+        // ---- filter row 0: halo registers + this row's weights have landed
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
+        if (!first) __syncthreads();                                // every wave is past the previous chunk: xs may be overwritten
+        first = false;
+        store_halo();
+        __syncthreads();
+        dma_weights(cur, g, 1, st ^ 1);
+        load_halo(more ? ntile : cur, more ? ng : g);               // (past the last chunk: a harmless re-load keeps the code branch-free)
+        mfma_row(0, st);
+        // ---- filter row 1
+        __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * NSLOT));           // the weights of row 1; the halo loads stay in flight
+        __syncthreads();
+        dma_weights(cur, g, 2, st);
+        mfma_row(1, st ^ 1);
+        // ---- filter row 2
+        __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: in-order completion, wait for all
+        __syncthreads();
+        if (more) dma_weights(ntile, ng, 0, st ^ 1);
+        mfma_row(2, st);
+        if (ng == 0) epilogue(cur);
+        if (!more) break;
+        if (nt != t) { cur = nxt; nxt = decode(nt + G < total ? nt + G : nt); }
+        t = nt; g = ng; st ^= 1;
+    }
+}
+
+template <int BN>
+int launch_x3(const IgemmArgs& a, hipStream_t s) {
+    using Cfg = X3Cfg<BN>;
+    auto kern = igemm_x3_kernel<BN>;
+    static PnnpPerDevice lds_once, occ;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int per_cu = occ.get([&] {
+        int n = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) n = 1;
+        return n;
+    });
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int tiles = ((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + BN - 1) / BN);
+    if (tiles <= 0) return PNNP_OK;
+    int wgs = per_cu * cus;
+    if (wgs > tiles) wgs = tiles;
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), Cfg::LDS_BYTES, s, a);
+    return pnnp_launch_status();
+}
+
+}  // namespace
+
+// a.w: the x3 pack of csrc/pack_jobs.hip (kind 2).  chan_per_seg: channels each K segment contributes (multiple of 8;
+// of 16 when there are several segments).  Only what the 3x3 / stride-1 layers need: in_mul = out_mul = 1, no sub-pixel N.
+int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
+    if (a.nseg < 1 || a.nseg > 2 || chan_per_seg <= 0 || (chan_per_seg & 7) || (a.nseg > 1 && (chan_per_seg & 15)) || a.Ntot <= 0) return PNNP_E_INVALID;
+    if ((a.Ntot & 31) || a.in_mul != 1 || a.out_mul != 1 || a.n_sub || a.out_yoff || a.out_xoff) return PNNP_E_UNSUPPORTED;
+    if (a.dst[1] && (a.n_split & 31)) return PNNP_E_UNSUPPORTED;
+    if (a.addsrc && a.accum[0]) return PNNP_E_UNSUPPORTED;
+    if ((a.dst_cs[0] & 3) || (a.dst[1] && (a.dst_cs[1] & 3))) return PNNP_E_UNSUPPORTED;
+    if ((((uintptr_t)a.dst[0]) | ((uintptr_t)a.dst[1]) | ((uintptr_t)a.bias) | ((uintptr_t)a.mask[0]) | ((uintptr_t)a.mask[1]) |
+         ((uintptr_t)a.addsrc) | ((uintptr_t)a.w)) & 15) return PNNP_E_INVALID;
+    for (int i = 0; i < a.nseg; ++i) {
+        if (a.seg[i].yoff || a.seg[i].xoff || (a.seg[i].cstride & 3) || (((uintptr_t)a.seg[i].ptr) & 15)) return PNNP_E_UNSUPPORTED;
+        if (((int64_t)a.IH + 4) * a.IW * a.seg[i].cstride * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;     // 32-bit offsets inside one image
+    }
+    for (int d = 0; d < 2; ++d)
+        if (a.dst[d] && (int64_t)a.OH * a.OW * a.dst_cs[d] * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    IgemmArgs b = a;
+    b.chunks_per_seg = (chan_per_seg + 15) / 16;
+    b.seg_channels = chan_per_seg;
+    const int64_t wbytes = (int64_t)((a.Ntot + 31) / 32) * b.nseg * b.chunks_per_seg * 27648;
+    if (wbytes >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    return a.Ntot >= 64 ? launch_x3<64>(b, s) : launch_x3<32>(b, s);
+}

@@ -34,6 +34,7 @@ struct IgemmSeg {
 struct IgemmArgs {
     IgemmSeg seg[9];               // up to 9 K segments (a stride-2 3x3 conv is 9 strided 1x1 taps)
     int nseg, chunks_per_seg;      // K = nseg * chunks_per_seg * KC channels (x TAPS)
+    int seg_channels;              // (csrc/conv_x3.hip) channels a segment contributes; its last 16-channel chunk may be half empty
     int in_mul, IH, IW;
     int B, DH, DW;                 // tile domain (what M iterates over)
     const float* w;                // packed [TAPS][Ktot/4][Ntot][4]

@@ -4,6 +4,7 @@
 // argument, <= 32 per launch) and every workgroup finds its job from a prefix of block counts.
 //   job kind 0: strided gather  dst[((t*(K/4)+kq)*Ndst + n_off + n)*4 + kr] = src[off + k*sk + n*sn + ts*st]  (k < Kvalid else 0)
 //   job kind 1: Winograd filter transform into the kernel's chunked order (csrc/wino.hip)
+//   job kind 2: 3x3 filters split into three bf16 pieces in the order csrc/conv_x3.hip streams them by LDS-DMA
 // The builders below produce exactly the jobs the per-layer entry points used to launch (same formulas, same layouts).
 #include "common.h"
 
@@ -65,6 +66,45 @@ __device__ __forceinline__ void wino_job(const PnnpPackJob& j, int64_t blk, int 
     }
 }
 
+// bf16x3 pack of a 3x3 Conv2d weight for csrc/conv_x3.hip:  dst (uint16) [N/32][K16][tap 9][octet 2][piece 3][32][8]
+//   element (k = chunk*16 + octet*8 + e, n = nb*32 + nn, tap):  forward  W = w[n][k][tap]        (K = Cin, N = Cout)
+//                                                               dgrad    W = w[k][n][8 - tap]    (K = Cout, N = Cin)
+//   pieces hi = bf16(W), mid = bf16(W - hi), lo = bf16(W - hi - mid) (round to nearest even; W = hi + mid + lo exactly);
+//   k >= Kvalid (channel padding up to a multiple of 16) -> 0.   job: K = Cout, N = Cin, T = dgrad, Kvalid = padded K.
+__device__ __forceinline__ unsigned short bf16_rne(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);      // NaN stays NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void x3_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
+    const int Cout = j.K, Cin = j.N, dgrad = j.T;
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int Kp = j.Kvalid, K16 = Kp / 16;                       // padded reduction length
+    const int64_t total = (int64_t)Kp * ((N + 31) / 32 * 32) * 9;
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
+        // enumerate in DESTINATION order (coalesced 2-byte stores of one piece plane; the three planes are 512 B apart)
+        const int e = (int)(t & 7);
+        int64_t r = t >> 3;
+        const int nn = (int)(r & 31); r >>= 5;
+        const int oct = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9); r /= 9;
+        const int c = (int)(r % K16);
+        const int nb = (int)(r / K16);
+        const int k = c * 16 + oct * 8 + e, n = nb * 32 + nn;
+        float v = 0.f;
+        if (k < K && n < N) v = dgrad ? w[((int64_t)k * Cin + n) * 9 + (8 - tap)] : w[((int64_t)n * Cin + k) * 9 + tap];
+        const unsigned short h = bf16_rne(v);
+        const float r1 = v - __uint_as_float((unsigned)h << 16);
+        const unsigned short m = bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)m << 16);
+        const unsigned short l = bf16_rne(r2);
+        unsigned short* o = u + ((((int64_t)nb * K16 + c) * 9 + tap) * 2 + oct) * (3 * 32 * 8) + nn * 8 + e;
+        o[0] = h; o[32 * 8] = m; o[2 * 32 * 8] = l;
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     int j = 0;
     while (j + 1 < tb.n && (int)blockIdx.x >= tb.blk_end[j]) ++j;          // uniform: <= 32 scalar compares
@@ -72,11 +112,12 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     const int nblk = tb.blk_end[j] - b0;
     const PnnpPackJob& job = tb.job[j];
     if (job.kind == 1) wino_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else if (job.kind == 2) x3_job(job, (int64_t)blockIdx.x - b0, nblk);
     else gather_job(job, (int64_t)blockIdx.x - b0, nblk);
 }
 
 int job_blocks(const PnnpPackJob& j) {
-    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (int64_t)j.T * j.K * j.N;
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -109,7 +150,7 @@ int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
         int blocks = 0;
         for (int i = 0; i < tb.n; ++i) {
             const PnnpPackJob& j = jobs[i0 + i];
-            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3)))) return PNNP_E_INVALID;
+            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15)))) return PNNP_E_INVALID;
             tb.job[i] = j;
             blocks += job_blocks(j);
             tb.blk_end[i] = blocks;
@@ -155,6 +196,27 @@ int pnnp_pack_jobs_add_wino(PnnpPackJob* jobs, int* n, int cap, const float* w, 
     }
     return ok ? PNNP_OK : PNNP_E_WORKSPACE;
 }
+
+// bf16x3 packs of a 3x3 Conv2d weight for the pnnp_conv3x3_x3_* kernels (csrc/conv_x3.hip): fwd (K = Cin padded to Cin_pad, a
+// multiple of 16; N = Cout) and / or dgrad (K = Cout padded up to a multiple of 16; N = Cin).  N is padded up to a multiple of
+// 32 inside the pack (zeros).  Sizes: pnnp_x3_weight_bytes.
+int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin, int Cin_pad) {
+    if (!jobs || !n || !w || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || (Cin_pad & 15)) return PNNP_E_INVALID;
+    bool ok = true;
+    for (int d = 0; d < 2; ++d) {
+        void* dst = d ? dgrad : fwd;
+        if (!dst) continue;
+        PnnpPackJob j{};
+        j.src = w; j.dst = reinterpret_cast<float*>(dst); j.kind = 2; j.T = d; j.K = Cout; j.N = Cin;
+        j.Kvalid = d ? (Cout + 15) / 16 * 16 : Cin_pad;
+        // the kernel enumerates N in blocks of 32: K/N of the job are (Cout, Cin); x3_job pads both
+        ok = ok && push(jobs, n, cap, j);
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+// bytes of one x3 pack: K (reduction channels, rounded up to 16) x N (channels written, rounded up to 32) x 9 taps x 3 pieces x 2 B
+int64_t pnnp_x3_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16 * 16) * ((N + 31) / 32 * 32) * 9 * 6; }
 
 // Backward-data weights of the stride-2 3x3 conv (see pnnp_pack_conv3x3s2_dgrad_f32): 9 slices ordered by input-pixel parity class.
 int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const float* w, float* dst, int Cout, int Cin) {

@@ -37,6 +37,7 @@ def _prep():
         L.pnnp_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_wino_weight_floats.restype = C.c_int64
         L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
+        L.pnnp_x3_weight_bytes.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -80,6 +81,13 @@ class PackJobs:
         check(_prep().pnnp_pack_jobs_add_wino(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci), 'pack_jobs_add_wino')
         self.keep += [w, fwd, dgrad]
 
+    def add_x3(self, w, fwd, dgrad, cin_pad=None):
+        """bf16x3 packs (csrc/conv_x3.hip) of a 3x3 Conv2d weight; fwd / dgrad: uint8 buffers of x3_weight_bytes, or None."""
+        co, ci = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_x3(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci,
+                                            cin_pad or (ci + 15) // 16 * 16), 'pack_jobs_add_x3')
+        self.keep += [w, fwd, dgrad]
+
     def add_s2_dgrad(self, w, dst):
         co, ci = w.shape[0], w.shape[1]
         check(_prep().pnnp_pack_jobs_add_conv3x3s2_dgrad(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(dst), co, ci), 'pack_jobs_add_s2_dgrad')
@@ -112,6 +120,44 @@ def conv_bwd_data(g, w_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask
     with _Timed('conv%d_dgrad' % taps, 2.0 * B * H * W * Cout * (C1 + C2) * taps, 4.0 * B * H * W * (C1 + C2 + Cout)):
         check(_prep().pnnp_conv_bwd_data_f32(ptr(g), Cout, ptr(w_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
                                              ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, taps, stream()), 'conv_bwd_data')
+
+
+def x3_supported(K, N):
+    return bool(_prep().pnnp_x3_supported(int(K), int(N)))
+
+
+def x3_weight_bytes(K, N):
+    return int(_prep().pnnp_x3_weight_bytes(int(K), int(N)))
+
+
+def conv_x3_fwd(x1, x2, w_x3, bias, y, cout, act, residual=None):
+    """3x3 / stride 1 / pad 1 forward on the bf16 matrix cores, fp32 operands split in three (same contract as conv_fwd, taps=9)."""
+    require_cuda(x1, x2, w_x3, y)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_x3', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv3x3_x3_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_x3), ptr(bias), ptr(residual), ptr(y), B, H, W, cout, act,
+                                              stream()), 'conv_x3_fwd')
+    return y
+
+
+def conv_x3_bwd_data(g, w_x3_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask2=None, mode2=0, accum2=0):
+    require_cuda(g, w_x3_dgrad, dx1)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]
+    C2 = dx2.shape[3] if dx2 is not None else 0
+    with _Timed('conv9_dgrad_x3', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv3x3_x3_bwd_data_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
+                                                   ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv_x3_bwd_data')
+
+
+def conv_x3_bwd_data_res(g, w_x3_dgrad, dx, addsrc, mask=None, mode=0):
+    require_cuda(g, w_x3_dgrad, dx, addsrc)
+    B, H, W, Cout = g.shape
+    C1 = dx.shape[3]
+    with _Timed('conv9_dgrad_x3', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
+        check(_prep().pnnp_conv3x3_x3_bwd_data_res_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
+                                                       B, H, W, stream()), 'conv_x3_bwd_data_res')
 
 
 def wino_supported(K, N):

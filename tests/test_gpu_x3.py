@@ -1,0 +1,132 @@
+"""GPU parity of the bf16x3 convolution kernels (csrc/conv_x3.hip: float32 operands split into three bf16 pieces on the
+bf16 matrix cores) against torch-fp32 CPU references of the same op -- at the SAME tolerances as the fp32-MFMA kernels
+(tests/test_gpu_conv.py: rtol 1e-4 / atol 1e-5 of the largest sum) -- and, to show the split is not a precision loss,
+against a float64 reference next to the fp32-MFMA kernel's own error."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from test_gpu_conv import close, nchw, nhwc, _rand
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, H, W, C1, C2 (0 = no concat), Cout
+    (1, 8, 32, 8, 0, 32), (2, 16, 48, 32, 0, 32), (1, 12, 40, 16, 0, 64), (1, 6, 70, 64, 0, 128),
+    (2, 8, 32, 32, 32, 32), (1, 8, 36, 64, 64, 64), (1, 5, 17, 128, 128, 128), (1, 4, 4, 256, 0, 256),
+    (1, 16, 32, 32, 0, 256), (1, 9, 33, 24, 0, 96), (3, 19, 50, 48, 48, 32),
+]
+
+
+def _packs(w, fwd=True, dgrad=True, cin_pad=None):
+    from pnnp_amd import ops
+    co, ci = w.shape[:2]
+    jobs = ops.PackJobs()
+    f = torch.zeros(ops.x3_weight_bytes(cin_pad or ci, co), dtype=torch.uint8, device='cuda') if fwd else None
+    d = torch.zeros(ops.x3_weight_bytes(co, ci), dtype=torch.uint8, device='cuda') if dgrad else None
+    jobs.add_x3(w, f, d, cin_pad=cin_pad)
+    jobs.run()
+    return f, d
+
+
+def test_x3_pack_reconstructs_the_float32_weights_exactly():
+    """hi + mid + lo == w bit for bit (the split is exact), and the pack order is the one the kernel streams."""
+    w = (_rand(64, 24, 3, 3, seed=3) * torch.logspace(-6, 3, 64 * 24 * 9).reshape(64, 24, 3, 3)).cuda()
+    f, d = _packs(w)
+    def unpack(buf, K, N):                       # [N/32][K16][tap][oct][piece][32][8] uint16 -> float32 [piece][K][N][tap]
+        K16 = (K + 15) // 16
+        a = buf.view(torch.int16).cpu().numpy().view(np.uint16).reshape(N // 32, K16, 9, 2, 3, 32, 8)
+        a = (a.astype(np.uint32) << 16).view(np.float32)
+        return a.transpose(4, 1, 3, 6, 0, 5, 2).reshape(3, K16 * 16, N, 9)
+    wn = w.cpu().numpy()
+    pf = unpack(f, 24, 64)
+    rec = (pf[0].astype(np.float64) + pf[1] + pf[2]).astype(np.float32)
+    assert np.array_equal(rec[:24], wn.transpose(1, 0, 2, 3).reshape(24, 64, 9)) and not rec[24:].any()
+    pd = unpack(d, 64, 32)                       # dgrad: K = Cout, N = Cin padded to 32, taps flipped
+    rec = (pd[0].astype(np.float64) + pd[1] + pd[2]).astype(np.float32)
+    assert np.array_equal(rec[:, :24], wn.reshape(64, 24, 9)[:, :, ::-1]) and not rec[:, 24:].any()
+    assert np.abs(pf[1]).max() <= np.abs(pf[0]).max() * 2.0 ** -8 and np.abs(pf[2]).max() <= np.abs(pf[0]).max() * 2.0 ** -16
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_x3_fwd(case):
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2); b = _rand(Co, seed=4)
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    f, _ = _packs(w.cuda(), dgrad=False)
+    for act in (0, 1, 2):
+        ref = F.conv2d(xin, w, b, padding=1)
+        ref = F.leaky_relu(ref, 0.2) if act == 1 else (F.relu(ref) if act == 2 else ref)
+        y = torch.full((B, H, W, Co), float('nan'), device='cuda')
+        ops.conv_x3_fwd(nhwc(x1).cuda(), nhwc(x2).cuda() if C2 else None, f, b.cuda(), y, Co, act)
+        close(nchw(y), ref, what=f'x3 fwd {case} act{act}')
+    r = _rand(B, Co, H, W, seed=9)
+    y = torch.empty((B, H, W, Co), device='cuda')
+    ops.conv_x3_fwd(nhwc(x1).cuda(), nhwc(x2).cuda() if C2 else None, f, b.cuda(), y, Co, 2, residual=nhwc(r).cuda())
+    close(nchw(y), F.relu(F.conv2d(xin, w, b, padding=1) + r), what='x3 residual')
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[3] % 32 == 0])
+def test_x3_bwd_data(case):
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2)
+    g = _rand(B, Co, H, W, seed=5)
+    xin = _rand(B, C1 + C2, H, W, seed=6).requires_grad_(True)
+    F.conv2d(xin, w, None, padding=1).backward(g)
+    ref = xin.grad
+    _, dg = _packs(w.cuda(), fwd=False)
+    m1 = _rand(B, C1, H, W, seed=7); m2 = _rand(B, max(C2, 1), H, W, seed=8)
+    d1 = torch.full((B, H, W, C1), float('nan'), device='cuda')
+    d2 = torch.full((B, H, W, C2), float('nan'), device='cuda') if C2 else None
+    ops.conv_x3_bwd_data(nhwc(g).cuda(), dg, d1, dx2=d2)
+    close(nchw(d1), ref[:, :C1], what=f'x3 dgrad {case}')
+    if C2:
+        close(nchw(d2), ref[:, C1:], what=f'x3 dgrad2 {case}')
+    base2 = _rand(B, max(C2, 1), H, W, seed=10)
+    d1 = torch.empty((B, H, W, C1), device='cuda')
+    d2 = nhwc(base2).cuda().clone() if C2 else None
+    ops.conv_x3_bwd_data(nhwc(g).cuda(), dg, d1, mask1=nhwc(m1).cuda(), mode1=1, dx2=d2,
+                         mask2=nhwc(m2).cuda() if C2 else None, mode2=2, accum2=1)
+    close(nchw(d1), ref[:, :C1] * torch.where(m1 > 0, 1.0, 0.2), what='x3 mask1')
+    if C2:
+        close(nchw(d2), base2 + ref[:, C1:] * (m2 > 0).float(), what='x3 mask2+accum')
+    if not C2:
+        add = _rand(B, C1, H, W, seed=11)
+        dx = torch.empty((B, H, W, C1), device='cuda')
+        ops.conv_x3_bwd_data_res(nhwc(g).cuda(), dg, dx, addsrc=nhwc(add).cuda(), mask=nhwc(m1).cuda(), mode=2)
+        close(nchw(dx), (ref + add) * (m1 > 0).float(), what='x3 dgrad res')
+
+
+def test_x3_padded_network_input():
+    """conv1_1: the 4-channel input travels as 8-channel NHWC; the x3 pack pads the reduction to 16 with zeros."""
+    from pnnp_amd import ops
+    B, H, W, Co = 2, 16, 64, 32
+    x = _rand(B, 4, H, W, seed=1); w = _rand(Co, 4, 3, 3, seed=2, scale=0.3); b = _rand(Co, seed=3)
+    x8 = torch.empty((B, H, W, 8), device='cuda'); ops.nchw_to_nhwc(x.cuda(), x8, 8)
+    f, _ = _packs(w.cuda(), dgrad=False, cin_pad=16)
+    y = torch.empty((B, H, W, Co), device='cuda')
+    ops.conv_x3_fwd(x8, None, f, b.cuda(), y, Co, 1)
+    close(nchw(y), F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2), what='x3 conv1_1')
+
+
+def test_x3_is_as_accurate_as_the_fp32_mfma_kernel():
+    """Both kernels against a float64 reference on a deep reduction (K = 9 x 512) with operands spanning 8 decades: the
+    bf16x3 error must stay within 2x the fp32-MFMA kernel's (measured: ~1x), and both at float32 level."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 16, 32, 512, 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, Ci, H, W, generator=g) * torch.logspace(-4, 4, Ci, base=10.0).reshape(1, Ci, 1, 1).roll(1, 1)
+    w = torch.randn(Co, Ci, 3, 3, generator=g) * 0.05
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    f3, _ = _packs(w.cuda(), dgrad=False)
+    f32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), f32, None)
+    y3 = torch.empty((B, H, W, Co), device='cuda'); y32 = torch.empty_like(y3)
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f3, None, y3, Co, 0)
+    ops.conv_fwd(nhwc(x).cuda(), None, f32, None, y32, Co, 9, 0)
+    e3 = float((nchw(y3).cpu().double() - ref).norm() / ref.norm())
+    e32 = float((nchw(y32).cpu().double() - ref).norm() / ref.norm())
+    print(f'relative L2 error vs float64: bf16x3 {e3:.2e}, fp32 MFMA {e32:.2e}')
+    assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7

@@ -22,6 +22,7 @@ def main():
     ap.add_argument('--reps', type=int, default=5)
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layers', default='')
+    ap.add_argument('--x3', action='store_true', help='bf16x3 kernels (csrc/conv_x3.hip) for fwd / dgrad')
     a = ap.parse_args()
     B, S = a.batch, a.size
     dev = torch.device('cuda')
@@ -51,8 +52,14 @@ def main():
         dW = torch.empty_like(w); db = torch.empty(Co, device=dev)
         ws = torch.empty(ops.wgrad_workspace_floats(B, H, H, Co, C1 + C2, 9), device=dev)
         flops = 2.0 * B * H * H * Co * (C1 + C2) * 9
-        fns = {'fwd': lambda: ops.conv_fwd(x1, x2, f, bias, y, Co, 9, 1),
-               'dgrad': lambda: ops.conv_bwd_data(g, d, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1),
+        if a.x3:
+            jobs = ops.PackJobs()
+            f3 = torch.zeros(ops.x3_weight_bytes(C1 + C2, Co), dtype=torch.uint8, device=dev)
+            d3 = torch.zeros(ops.x3_weight_bytes(Co, C1 + C2), dtype=torch.uint8, device=dev)
+            jobs.add_x3(w, f3, d3, cin_pad=(C1 + C2 + 15) // 16 * 16); jobs.run()
+        fns = {'fwd': (lambda: ops.conv_x3_fwd(x1, x2, f3, bias, y, Co, 1)) if a.x3 else (lambda: ops.conv_fwd(x1, x2, f, bias, y, Co, 9, 1)),
+               'dgrad': (lambda: ops.conv_x3_bwd_data(g, d3, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)) if (a.x3 and C1 % 32 == 0) else
+                        (lambda: ops.conv_bwd_data(g, d, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)),
                'wgrad': lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws)}
         for k in kinds:
             fns[k](); torch.cuda.synchronize()
