@@ -29,6 +29,18 @@ sys.path.insert(0, REPO)
 
 GFLOP_PER_CROP_TRAIN = {'unet': 289.70, 'resunet': 375.07}   # fwd + dgrad + wgrad, nf=32 @4x512x512
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md (~2.5 PF dense): v_mfma_f32_32x32x16_bf16, 256 CUs x 4 SIMD x 1024 FLOP/clk x 2.4 GHz
+# Kernel families of the 3x3 forward / backward-data convolutions: FLOPs the matrix pipe EXECUTES per algorithmic FLOP, its
+# dense peak, and what the kernel is.  `roofline.frac` = executed / peak (a hardware fraction, always <= 1).
+FAMILY = {
+    'x3':     (6.0, PEAK_BF16_MFMA_TFLOPS, ('conv9_fwd_x3', 'conv9_dgrad_x3'),
+               "igemm_x3_kernel (conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: six v_mfma_f32_32x32x16_bf16 "
+               "passes per fp32 product block, fp32 accumulation)"),
+    'wino':   (16.0 / 36.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd_wino', 'conv9_dgrad_wino'),
+               "wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 multiply-adds where the direct form has 36)"),
+    'direct': (1.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd', 'conv9_dgrad'),
+               "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)"),
+}
 
 
 def cpu_baseline(H, W):
@@ -127,6 +139,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--arch', default='unet', choices=['unet', 'resunet'], help='resunet + --noise noiseflow = BASELINE config 5')
     ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
+    ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
+                    help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '
                     '(for rocprofv3 traces of the collective kernels on the side stream overlapping the backward pass)')
@@ -177,6 +191,7 @@ def main():
                     v.normal_(0, 0.05)
         proxy = proxy.to(dev).eval()
     net = net.to(dev)
+    net.engine.set_policy(x3=args.family == 'x3', wino=args.family != 'direct')
     ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
                       rank=rank, world=world, force_reducer=(world == 1 and args.force_reducer))
     B, S = args.batch, args.size
@@ -206,8 +221,9 @@ def main():
     # HIP events on the launching stream: in the TIMED region only around the dominant kernel's launches (the `roofline` object);
     # the per-class table comes from a short un-timed pass afterwards, so that the headline number is not taxed by ~200 event
     # records per step (measured: 1.7 %).
-    wino_on = net.engine.policy.wino
-    dom_kinds = {'conv9_fwd_wino', 'conv9_dgrad_wino'} if wino_on else {'conv9_fwd', 'conv9_dgrad'}
+    pol = net.engine.policy
+    fam0 = 'x3' if pol.x3 else ('wino' if pol.wino else 'direct')
+    dom_kinds = set(FAMILY[fam0][2])
     if not args.no_kernel_events:
         ops.PROFILE, ops.PROFILE_KINDS = [], dom_kinds
     t0 = time.perf_counter()
@@ -236,7 +252,7 @@ def main():
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)" if pol.x3 else "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else "NoiseFlow.sample proxy (iso 6400, ratio in {1,2,4,8,16})") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
@@ -250,33 +266,28 @@ def main():
             for kind, fl, by, e0, e1 in prof:
                 c = classes.setdefault(kind, [0, 0.0, 0.0, 0.0])
                 c[0] += 1; c[1] += fl; c[2] += by; c[3] += e0.elapsed_time(e1) * 1e-3
-            # dominant kernel = the one with the largest share of the step: wino_kernel (Winograd F(2x2,3x3) conv3x3
-            # forward + backward-data) when the engine uses it, else the direct implicit-GEMM igemm_kernel<9,...>
-            wino = [k for k in classes if k in ('conv9_fwd_wino', 'conv9_dgrad_wino')]
-            direct = [k for k in classes if k in ('conv9_fwd', 'conv9_dgrad')]
-            t_of = lambda ks: sum(classes[k][3] for k in ks)
-            use_wino = bool(wino) and t_of(wino) >= t_of(direct)
-            dom = wino if use_wino else direct
+            # dominant kernel = the family of 3x3 forward / backward-data launches timed in the timed region
+            fam = fam0
+            dom = [k for k in classes if k in FAMILY[fam][2]]
+            use_wino = fam == 'wino'
             n = sum(classes[k][0] for k in dom); fl = sum(classes[k][1] for k in dom); sec = sum(classes[k][3] for k in dom)
             # `frac` is a hardware fraction: FLOPs the matrix pipe EXECUTES per second / its dense peak.  The Winograd kernels
             # execute 16 multiply-adds where the direct form has 36 (F(2x2,3x3)): executed = algorithmic x 16/36.
-            exec_factor = 16.0 / 36.0 if use_wino else 1.0
+            exec_factor, peak, _, kdesc = FAMILY[fam]
             alg_tflops = fl / sec / 1e12
             traffic, traffic_note = None, None      # HBM bytes per launch from the PMC passes of this command (tools/traffic_from_pmc.py)
             tj = os.path.join(REPO, 'profiles', 'traffic.json')
             if os.path.exists(tj) and args.arch == 'unet' and args.noise == 'physics' and B == 16 and S == 512:
                 tdoc = json.load(open(tj))
                 if tdoc.get('csrc_sha') == csrc_sha():
-                    traffic = tdoc.get('wino' if use_wino else 'igemm9', {}).get('hbm_bytes_per_launch')
+                    traffic = tdoc.get({'x3': 'x3', 'wino': 'wino', 'direct': 'igemm9'}[fam], {}).get('hbm_bytes_per_launch')
                     traffic_note = f"PMC passes at commit {tdoc.get('commit')}, kernel sources {tdoc.get('csrc_sha')}"
                 else:
                     traffic_note = f"profiles/traffic.json was measured on other kernel sources ({tdoc.get('csrc_sha')} != {csrc_sha()}): not attached"
             by = sum(classes[k][2] for k in dom)
-            out["roofline"] = {"bound": "mfma", "achieved": alg_tflops * exec_factor, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": alg_tflops * exec_factor / PEAK_F32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_note,
-                               "alg_bytes_per_launch": by / n,
-                               "kernel": ("wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32)") if use_wino else
-                                         "igemm_kernel<9,...> (conv3x3 forward + backward-data, v_mfma_f32_32x32x2_f32)",
+            out["roofline"] = {"bound": "mfma", "achieved": alg_tflops * exec_factor, "peak": peak, "unit": "TFLOP/s",
+                               "frac": alg_tflops * exec_factor / peak, "traffic": traffic, "traffic_source": traffic_note,
+                               "alg_bytes_per_launch": by / n, "kernel": kdesc,
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
                                "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
@@ -294,8 +305,8 @@ def main():
                                              "tflops": (v[1] / v[3] / 1e12) if v[3] > 0 else None} for k, v in sorted(call.items())}
                 out["mfma_time_frac_of_step"] = sum(v[3] for v in call.values()) / extra_steps / (dt / args.steps)
         else:
-            out["roofline"] = {"bound": "mfma", "achieved": step_tflops, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                               "frac": step_tflops / PEAK_F32_MFMA_TFLOPS, "traffic": None, "kernel": "whole train step"}
+            out["roofline"] = {"bound": "mfma", "achieved": None, "peak": FAMILY[fam0][1], "unit": "TFLOP/s", "frac": None, "traffic": None,
+                               "kernel": "not measured (--no-kernel-events)", "step_algorithmic_tflops": step_tflops}
         out["step_tflops_per_gpu"] = step_tflops
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, S)

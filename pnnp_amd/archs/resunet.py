@@ -56,10 +56,10 @@ class ResUnetEngine(_EngineBase):
         self.cout_pad = (self.cout + 7) // 8 * 8
 
     # ---------------------------------------------------------------- weights
-    def _buf(self, key, n, dev):
+    def _buf(self, key, n, dev, dtype=torch.float32):
         k = (key, dev)
         if k not in self.packed or self.packed[k].numel() != n:
-            self.packed[k] = torch.empty(n, dtype=torch.float32, device=dev)
+            self.packed[k] = torch.empty(n, dtype=dtype, device=dev)
         return self.packed[k]
 
     def pack_weights(self, train):
@@ -75,26 +75,36 @@ class ResUnetEngine(_EngineBase):
     def _build_pack_jobs(self, train, dev, P):
         jobs = ops.PackJobs(cap=512)
         W = {}
-        self.WU = {}
-        def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True):
+        self.WU, self.WX = {}, {}
+        def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True, c1=None):
             w = P[pname]
             co, ci, kh, kw = w.shape
             t = kh * kw
-            f = self._buf(name + ':f', t * (cin_pad or ci) * co, dev)
-            d = self._buf(name + ':d', t * (cout_pad or co) * ci, dev) if (train and dgrad) else None
+            cip = cin_pad or ci
+            bwd = train and dgrad
+            xf, xd = self.policy.use_x3(co, cip, t, c1)
+            xd = xd and bwd
             wf, wd = self._wino(co, ci, t)
-            wd = wd and train and dgrad
-            if not wf or (d is not None and not wd):
-                jobs.add_conv(w, None if wf else f, d if not wd else None, cin_pad=cin_pad, cout_pad=cout_pad)
+            wf, wd = wf and not xf, wd and bwd and not xd
+            df, dd = not (xf or wf), bwd and not (xd or wd)        # what is left for the direct fp32 kernels
+            f = self._buf(name + ':f', t * cip * co, dev) if df else None
+            d = self._buf(name + ':d', t * (cout_pad or co) * ci, dev) if dd else None
+            if df or dd:
+                jobs.add_conv(w, f, d, cin_pad=cin_pad, cout_pad=cout_pad)
             uf = self._buf(name + ':uf', 16 * co * ci, dev) if wf else None
             ud = self._buf(name + ':ud', 16 * co * ci, dev) if wd else None
             if wf or wd:
                 jobs.add_wino(w, uf, ud)
+            x3f = self._buf(name + ':x3f', ops.x3_weight_bytes(cip, co), dev, torch.uint8) if xf else None
+            x3d = self._buf(name + ':x3d', ops.x3_weight_bytes(co, ci), dev, torch.uint8) if xd else None
+            if xf or xd:
+                jobs.add_x3(w, x3f, x3d, cin_pad=(cip + 15) // 16 * 16)
             W[name] = (f, d)
             self.WU[name] = (uf, ud)
+            self.WX[name] = (x3f, x3d)
         conv('conv_in', 'conv_in.weight', cin_pad=self.cin_pad, dgrad=False)
         for i in range(1, 10):
-            conv(f'b{i}_0', f'conv{i}.block.0.conv.conv.weight')
+            conv(f'b{i}_0', f'conv{i}.block.0.conv.conv.weight', c1=self.ch[9 - i] if i >= 6 else None)     # decoder: cat([up, skip])
             conv(f'b{i}_1', f'conv{i}.block.1.conv.conv.weight')
             if i >= 6:
                 conv(f'sc{i}', f'conv{i}.short_cut.0.conv.conv.weight')
@@ -122,13 +132,19 @@ class ResUnetEngine(_EngineBase):
         return self.policy.use_wino(co, ci, taps)
 
     def _cf(self, name, src, src2, bias, out, cout, act, residual=None):
-        """3x3 forward: Winograd kernel where packed for it, else the direct implicit GEMM."""
+        """3x3 forward: bf16x3 / Winograd kernel where packed for it, else the direct implicit GEMM."""
+        x3 = self.WX.get(name, (None, None))[0]
+        if x3 is not None:
+            return ops.conv_x3_fwd(src, src2, x3, bias, out, cout, act, residual=residual)
         u = self.WU.get(name, (None, None))[0]
         if u is not None:
             return ops.conv_wino_fwd(src, src2, u, bias, out, cout, act, residual=residual)
         return ops.conv_fwd(src, src2, self.W[name][0], bias, out, cout, 9, act, residual=residual)
 
     def _dg(self, name, gsrc, dx1, **kw):
+        x3 = self.WX.get(name, (None, None))[1]
+        if x3 is not None:
+            return ops.conv_x3_bwd_data(gsrc, x3, dx1, **kw)
         u = self.WU.get(name, (None, None))[1]
         if u is not None:
             return ops.conv_wino_bwd_data(gsrc, u, dx1, **kw)
@@ -158,7 +174,7 @@ class ResUnetEngine(_EngineBase):
         hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
         a = {}
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad)
-        a['t0'] = ops.conv_fwd(a['x8'], None, W['conv_in'][0], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], 9, RELU)
+        a['t0'] = self._cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
         xin = a['t0']
         for l in range(1, 6):
             lv = l - 1
@@ -243,7 +259,10 @@ class ResUnetEngine(_EngineBase):
             g_x = gb('t0' if l == 1 else f'd{l - 1}', xin)
             # identity shortcut: d/d(xin) = dgrad(block) + g ; xin = t0 is a ReLU output (mask), d_l is not
             ud = self.WU.get(f'b{l}_0', (None, None))[1]
-            if ud is not None:
+            x3d = self.WX.get(f'b{l}_0', (None, None))[1]
+            if x3d is not None:
+                ops.conv_x3_bwd_data_res(g_t, x3d, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+            elif ud is not None:
                 ops.conv_wino_bwd_data_res(g_t, ud, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
             else:
                 ops.conv_bwd_data_res(g_t, W[f'b{l}_0'][1], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)

@@ -20,17 +20,29 @@ LRELU, RELU = 1, 2
 
 
 class ConvPolicy:
-    """Which kernel family a 3x3 layer runs on.  ``wino``: Winograd F(2x2,3x3) forward / backward-data where the layer
+    """Which kernel family a 3x3 layer runs on.
+    ``x3``: forward / backward-data on the bf16 matrix cores with float32 operands split into three bf16 pieces
+    (csrc/conv_x3.hip: float32-accurate, 6/16 of the fp32-MFMA time) wherever the layer qualifies (reduction % 8 == 0,
+    channels written % 32 == 0) -- the default;
+    ``wino``: Winograd F(2x2,3x3) on the fp32 matrix cores for forward / backward-data where x3 is off and the layer
     qualifies (channels written % 64 == 0, reduction >= ``wino_mink`` channels), ``wino_wgrad``: the Winograd
-    backward-weight kernel likewise; everything else (and everything when both are off) uses the direct implicit-GEMM
+    backward-weight kernel likewise; everything else (and everything when all are off) uses the direct fp32 implicit-GEMM
     kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
     families against each other at full size)."""
 
-    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32):
-        self.wino, self.wino_wgrad, self.wino_mink = bool(wino), bool(wino_wgrad), int(wino_mink)
+    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True):
+        self.wino, self.wino_wgrad, self.wino_mink, self.x3 = bool(wino), bool(wino_wgrad), int(wino_mink), bool(x3)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3)
+
+    def use_x3(self, co, ci, taps=9, c1=None):
+        """(forward, backward-data) of a 3x3 Conv2d(ci -> co) on the bf16x3 kernel?  ``c1``: channels of the first of two
+        concatenated inputs (its gradient is a separate destination: the split must fall on a 32-column block)."""
+        if taps != 9 or not self.x3:
+            return False, False
+        return (ops.x3_supported(ci, co) and (c1 is None or c1 % 16 == 0),
+                ops.x3_supported(co, ci) and (c1 is None or c1 % 32 == 0))
 
     def use_wino(self, co, ci, taps=9):
         """(forward, backward-data) of a Conv2d(ci -> co, taps) on the Winograd kernel?"""
@@ -42,7 +54,7 @@ class ConvPolicy:
         return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
 
 
-DEFAULT_POLICY = ConvPolicy(wino=os.environ.get('PNNP_WINO', '1') != '0')      # host-side default only; the library reads no environment
+DEFAULT_POLICY = ConvPolicy(wino=os.environ.get('PNNP_WINO', '1') != '0', x3=os.environ.get('PNNP_X3', '1') != '0')      # host-side defaults only; the library reads no environment
 
 
 class _EngineBase:
@@ -58,7 +70,12 @@ class _EngineBase:
         self._dirty_epoch = 0
 
     def set_policy(self, policy=None, **kw):
-        self.policy = policy if policy is not None else ConvPolicy(**kw)
+        """``set_policy(x3=False)`` etc.: fields not named keep their current value."""
+        if policy is None:
+            cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3)
+            cur.update(kw)
+            policy = ConvPolicy(**cur)
+        self.policy = policy
         self._pack_key = None        # re-pack for the other kernel family
         self._jobs_key = None
 
@@ -166,27 +183,33 @@ class UNetEngine(_EngineBase):
 
     def _build_pack_jobs(self, need_dgrad, dev, P):
         jobs = ops.PackJobs()
+        self._x3, self._wn = {}, {}            # per layer: (forward, backward-data) on the bf16x3 / Winograd kernel
+        def buf(key, n, dt=torch.float32):
+            if key not in self.packed:
+                self.packed[key] = torch.empty(n, dtype=dt, device=dev)
+            return self.packed[key]
         for name in self._conv_names():
             w = P[name + '.weight']
             co, ci, kh, kw = w.shape
             taps = kh * kw
             cip = self.cin_pad if name == 'conv1_1' else ci
             cop = self.cout_pad if name == 'conv10_1' else co
-            key = (name, dev)
-            if key not in self.packed:
-                self.packed[key] = (torch.empty(taps * cip * co, dtype=torch.float32, device=dev),
-                                    torch.empty(taps * cop * ci, dtype=torch.float32, device=dev))
-            f, d = self.packed[key]
+            bwd = need_dgrad and name != 'conv1_1'                 # no gradient w.r.t. the network input
+            c1 = ci // 2 if (name.endswith('_1') and name[4] in '6789') else None       # decoder conv{6..9}_1 read cat([up, skip])
+            xf, xd = self.policy.use_x3(co, cip, taps, c1)
+            xd = xd and bwd
             wf, wd = self._wino(name, co, ci, taps)
-            if not (wf and (wd or not need_dgrad)):
-                jobs.add_conv(w, None if wf else f, d if (need_dgrad and not wd) else None, cin_pad=cip, cout_pad=cop)
-            if wf or (wd and need_dgrad):
-                wkey = (name, dev, 'wino')
-                if wkey not in self.packed:
-                    self.packed[wkey] = (torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wf else None,
-                                         torch.empty(16 * co * ci, dtype=torch.float32, device=dev) if wd else None)
-                uf, ud = self.packed[wkey]
-                jobs.add_wino(w, uf, ud if need_dgrad else None)
+            wf, wd = wf and not xf, wd and bwd and not xd
+            df, dd = not (xf or wf), bwd and not (xd or wd)        # what is left for the direct fp32 kernels
+            self._x3[name], self._wn[name] = (xf, xd), (wf, wd)
+            if df or dd:
+                jobs.add_conv(w, buf((name, dev, 'f'), taps * cip * co) if df else None, buf((name, dev, 'd'), taps * cop * ci) if dd else None,
+                              cin_pad=cip, cout_pad=cop)
+            if xf or xd:
+                jobs.add_x3(w, buf((name, dev, 'x3f'), ops.x3_weight_bytes(cip, co), torch.uint8) if xf else None,
+                            buf((name, dev, 'x3d'), ops.x3_weight_bytes(co, ci), torch.uint8) if xd else None, cin_pad=(cip + 15) // 16 * 16)
+            if wf or wd:
+                jobs.add_wino(w, buf((name, dev, 'uf'), 16 * co * ci) if wf else None, buf((name, dev, 'ud'), 16 * co * ci) if wd else None)
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
             key = (name, dev)
@@ -198,7 +221,11 @@ class UNetEngine(_EngineBase):
         return jobs
 
     def _w(self, name):
-        return self.packed[(name, self.params.flat.device)]
+        """(forward, backward-data) direct packs of a layer (ConvTranspose2d: the pair built by add_convt)."""
+        dev = self.params.flat.device
+        if (name, dev) in self.packed:
+            return self.packed[(name, dev)]
+        return self.packed.get((name, dev, 'f')), self.packed.get((name, dev, 'd'))
 
     def _wino(self, name, co, ci, taps=9):
         """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  (self.policy)"""
@@ -209,7 +236,12 @@ class UNetEngine(_EngineBase):
         return self.policy.use_wino_wgrad(h, w, cout, c1, c2, g_cs, x_cs)
 
     def _wu(self, name):
-        return self.packed[(name, self.params.flat.device, 'wino')]
+        dev = self.params.flat.device
+        return self.packed.get((name, dev, 'uf')), self.packed.get((name, dev, 'ud'))
+
+    def _wx(self, name):
+        dev = self.params.flat.device
+        return self.packed.get((name, dev, 'x3f')), self.packed.get((name, dev, 'x3d'))
 
     # ------------------------------------------------------------------ forward
     def forward(self, x, train):
@@ -237,8 +269,9 @@ class UNetEngine(_EngineBase):
 
         def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
             y = out if out is not None else g(name, (B, h, w, cout))
-            cin_t = src.shape[3] + (src2.shape[3] if src2 is not None else 0)
-            if self._wino(name, cout, cin_t, taps)[0]:
+            if self._x3.get(name, (False, False))[0]:
+                return ops.conv_x3_fwd(src, src2, self._wx(name)[0], P[name + '.bias'], y, cout, act)
+            if self._wn.get(name, (False, False))[0]:
                 return ops.conv_wino_fwd(src, src2, self._wu(name)[0], P[name + '.bias'], y, cout, act)
             return ops.conv_fwd(src, src2, self._w(name)[0], P[name + '.bias'], y, cout, taps, act)
 
@@ -292,9 +325,9 @@ class UNetEngine(_EngineBase):
         wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, W),), dev)
 
         def dgrad(name, gsrc, dx1, **kw):
-            co = gsrc.shape[3]
-            ci = dx1.shape[3] + (kw['dx2'].shape[3] if kw.get('dx2') is not None else 0)
-            if self._wino(name, co, ci)[1]:
+            if self._x3.get(name, (False, False))[1]:
+                ops.conv_x3_bwd_data(gsrc, self._wx(name)[1], dx1, **kw)
+            elif self._wn.get(name, (False, False))[1]:
                 ops.conv_wino_bwd_data(gsrc, self._wu(name)[1], dx1, **kw)
             else:
                 ops.conv_bwd_data(gsrc, self._w(name)[1], dx1, **kw)

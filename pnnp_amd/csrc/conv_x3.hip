@@ -14,12 +14,16 @@
 // gradient test measures the error against a float64 run of the reference next to the reference's own float32 error).
 //
 // Structure (reference ops: archs/Unet.py:16-52 Conv2d 3x3 pad 1 (+LeakyReLU), archs/modules.py:130-197):
-//   M = output pixels: tile of 8 rows x 32 px; N = BN = 32 or 64 output channels; K = 16 channels x one filter ROW
-//   (3 taps) per work item.  Persistent workgroups (4 waves, each 2 pixel rows x BN channels) walk (tile, channel chunk,
-//   filter row) items:
-//     * activations: fp32 NHWC halo tile (10 x 34 px x 16 ch) global -> registers (buffer loads, hardware zero for the
-//       halo outside the image) -> split into hi/mid/lo -> LDS planes xs[k-octet][piece][pixel][8 bf16]; loaded one
-//       chunk ahead (issue early / write late), re-used by the three filter rows;
+//   M = output pixels: tile of 16 rows x 32 px; N = BN = 32 or 64 output channels; K = 16 channels x one filter ROW
+//   (3 taps) per work item.  ONE persistent workgroup of 8 waves per CU (each wave 2 pixel rows x BN channels; two waves
+//   per SIMD that meet at a barrier every item -- two independent 4-wave workgroups per CU ran unfairly: the older one
+//   wins the matrix-pipe arbitration, finishes its tiles early and leaves the other alone at half occupancy) walks
+//   (tile, channel chunk, filter row) items:
+//     * activations: fp32 NHWC halo tile (18 x 34 px x 16 ch) global -> registers (buffer loads, hardware zero for the
+//       halo outside the image), requested at the first filter row of the PREVIOUS chunk; split into hi/mid/lo and
+//       written to the other of two LDS images xs[buf][k-octet][piece][pixel][8 bf16] in slices BETWEEN the MFMAs of that
+//       chunk's last filter row (measured: done in one lump behind a barrier the split cost 8 % of a 64-channel layer
+//       and 30-40 % of a 32-channel one -- every wave stages at the same time and the matrix pipe idles);
 //     * weights: pre-split and pre-ordered per (32-channel block, chunk, tap) at pack time (csrc/pack_jobs.hip kind 2), so
 //       an item's 9 / 18 KB come in by LDS-DMA (buffer_load ... lds, no registers, no VALU), double buffered, one item ahead;
 //     * one ds_read_b128 = the 8 k-values a lane feeds to one v_mfma_f32_32x32x16_bf16; per filter tap a wave reads
@@ -27,6 +31,7 @@
 //     * epilogue as in csrc/conv_igemm.hip (bias, activation, act' mask, residual, accumulate, split destinations,
 //       16-byte stores through a wave-private LDS patch).
 #include "igemm.h"
+#include <type_traits>
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -34,16 +39,25 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
 
 namespace {
 
-constexpr int TH = 8, HR = TH + 2, HC = 34, NPIX = HR * HC;       // 340 halo pixels
-constexpr int XS_BYTES = 2 * 3 * NPIX * 16;                        // [k-octet 2][piece 3][pixel][16 B]
+constexpr int NTHR = 512, NWAVE = 8, MT = 2;
+constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row tile, 612 halo pixels
+constexpr int XS_F4 = 2 * 3 * NPIX;                                // one halo image in 16-byte words: [k-octet 2][piece 3][pixel]
+constexpr int XS_BYTES = XS_F4 * 16;                               // 58752
 constexpr int WBLK = 3 * 2 * 3 * 32 * 16;                          // one filter row of one 32-channel block: [tap 3][octet 2][piece 3][32][16 B] = 9216
-constexpr int NSLOT = 3;                                           // halo staging slots per thread: 680 (pixel, octet) pairs / 256
+constexpr int NSLOT = 3;                                           // halo staging slots per thread: 1224 (pixel, octet) pairs / 512
 
 template <int BN> struct X3Cfg {
     static constexpr int NT = BN / 32;
-    static constexpr int WS_STAGE = NT * WBLK;
-    static constexpr int EPI = 4 * 2048;                           // 4 waves x (16 pixels x 32 channels) floats
-    static constexpr int LDS_BYTES = XS_BYTES + 2 * WS_STAGE + EPI;
+    static constexpr int WS_STAGE = NT * WBLK;                     // 9216 / 18432
+    static constexpr int NDMA = WS_STAGE / 1024;                   // 1 KB LDS-DMA pieces per stage
+    static constexpr int DPW = (NDMA + NWAVE - 1) / NWAVE;         // LDS-DMA instructions per wave and item: 2 / 3
+    // Weight ring: BN = 64 requests an item's weights one item ahead (an item is 72 MFMAs per wave, ~2.3 us with two waves
+    // per SIMD: more than the L2 round trip); a BN = 32 item is half as long, so its weights are requested TWO items ahead.
+    static constexpr int NSTAGE = BN == 32 ? 3 : 2, AHEAD = NSTAGE - 1;
+    static constexpr int EPI = NWAVE * 2048;                       // per wave: (16 pixels x 32 channels) floats
+    // BN = 64: the epilogue patches live in the weight stage the tile's last item has just consumed (a barrier in between)
+    static constexpr bool EPI_ALIAS = WS_STAGE >= EPI;
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // 154368 / 161536
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
@@ -55,32 +69,27 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // RNE,
     unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
 }
 
-// 8 floats -> three 16-byte words of 8 bf16 each (hi, mid, lo); element e sits in bits 16(e&1) of dword e>>1
-__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& H, u32x4& M, u32x4& L) {
-    const float a[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const float a0 = a[2 * p], a1 = a[2 * p + 1];
-        const unsigned h = cvt_pk_bf16(a0, a1);
-        const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);      // exact
-        const unsigned m = cvt_pk_bf16(r0, r1);
-        const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);      // exact
-        H[p] = h; M[p] = m; L[p] = cvt_pk_bf16(s0, s1);
-    }
+// two floats -> one dword each of the hi / mid / lo words (a = hi + mid + lo exactly; both subtractions are exact)
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
 }
 
 template <int BN>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(NTHR)
 igemm_x3_kernel(const IgemmArgs a) {
     using Cfg = X3Cfg<BN>;
-    constexpr int NT = Cfg::NT, MT = 2;
+    constexpr int NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    u32x4* xs = reinterpret_cast<u32x4*>(smem);
-    char* wsb = smem + XS_BYTES;
-    float* epi = reinterpret_cast<float*>(smem + XS_BYTES + 2 * Cfg::WS_STAGE);
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                     // two halo images
+    char* wsb = smem + 2 * XS_BYTES;                                // two weight stages
+    float* epi_sep = reinterpret_cast<float*>(smem + 2 * XS_BYTES + Cfg::NSTAGE * Cfg::WS_STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (the LDS-DMA pieces and barriers depend on it)
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (the LDS-DMA pieces depend on it)
     const int l31 = lane & 31, half = lane >> 5;
 
     const int tiles_x = (a.DW + 31) >> 5, tiles_y = (a.DH + TH - 1) / TH;
@@ -89,22 +98,22 @@ igemm_x3_kernel(const IgemmArgs a) {
     const int G = gridDim.x;
     const int nchunks = a.nseg * a.chunks_per_seg;                  // 16-channel chunks of K
 
-    // ---- per-thread constants of the halo staging pattern: slot s = tid + 256 k -> (pixel s>>1, channel octet s&1)
-    constexpr unsigned OOB = 0x80000000u;
-    // (680 slots over 3 x 256: a thread whose third slot would be past the end repeats its second one -- same address, same
+    // ---- per-thread constants of the halo staging pattern: slot s = tid + 512 k -> (pixel s>>1, channel octet s&1)
+    // (1224 slots over 3 x 512: a thread whose third slot would be past the end repeats its second one -- same address, same
     //  data, same thread -- so every slot is live and the staging code has no branches)
+    constexpr unsigned OOB = 0x80000000u;
     int rk[NSLOT], qk[NSLOT]; unsigned pixk[NSLOT]; int xdst[NSLOT];
     const int oct = tid & 1;
 #pragma unroll
     for (int k = 0; k < NSLOT; ++k) {
-        int s = tid + 256 * k;
-        if (s >= 2 * NPIX) s -= 256;
+        int s = tid + NTHR * k;
+        if (s >= 2 * NPIX) s -= NTHR;
         const int pix = s >> 1;
         const int r = pix / HC, q = pix - r * HC;
         rk[k] = r - 1;
         qk[k] = q - 1;
         pixk[k] = (unsigned)(r * a.IW + q);
-        xdst[k] = (oct * 3) * NPIX + pix;                           // + piece * NPIX
+        xdst[k] = (oct * 3) * NPIX + pix;                           // + piece * NPIX (+ image * XS_F4)
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
@@ -122,6 +131,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     };
 
     f32x4 ra[NSLOT][2];                                             // halo registers of the NEXT chunk (8 channels per slot)
+    u32x4 sh[NSLOT], sm[NSLOT], sl[NSLOT];                          // their hi / mid / lo words while the split is in progress
 
     // global loads of the halo tile of (tile, chunk g) -> ra (no wait)
     auto load_halo = [&](const Tile& tl, int g) {
@@ -145,27 +155,35 @@ igemm_x3_kernel(const IgemmArgs a) {
             ra[k][1] = bload(rs, vo, soff + 16);
         }
     };
-    // split ra and write the three piece planes
-    auto store_halo = [&]() {
-#pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            u32x4 H, M, L;
-            split8(ra[k][0], ra[k][1], H, M, L);
-            xs[xdst[k]] = H; xs[xdst[k] + NPIX] = M; xs[xdst[k] + 2 * NPIX] = L;
+    // One of the 12 slices of the halo staging: split two floats of slot q/4 (pair q%4); after a slot's fourth pair its three
+    // 16-byte words go to halo image `img`.  Sliced so that it can sit between MFMA groups (~12 VALU + at most 3 LDS stores each).
+    auto stage_slice = [&](int q, int img) {
+#ifdef X3_SKIP_STORE              // timing experiment only (wrong results): no split, no LDS store
+        return;
+#endif
+        const int k = q >> 2, p = q & 3;
+        const f32x4 v = ra[k][p >> 1];
+        unsigned h, m, l;
+        split2(v[(p & 1) * 2], v[(p & 1) * 2 + 1], h, m, l);
+        sh[k][p] = h; sm[k][p] = m; sl[k][p] = l;
+        if (p == 3) {
+            u32x4* d = xs + img * XS_F4 + xdst[k];
+            d[0] = sh[k]; d[NPIX] = sm[k]; d[2 * NPIX] = sl[k];
         }
     };
-    // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: NT blocks of 9216 contiguous bytes
+    // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: per 32-channel block 9216 contiguous
+    // bytes of the pack, as 1 KB pieces dealt over the 8 waves
     const int K16 = nchunks;
-    auto dma_weights = [&](const Tile& tl, int g, int tr, int st) {
+    auto dma_weights = [&](const Tile& tl, int g, int tr, int st, bool valid = true) {
 #pragma unroll
-        for (int i = 0; i < (NT * 9 + 3) / 4; ++i) {
-            // wave-uniform 1 KB piece of the stage; past the end a wave repeats the last piece (same bytes to the same place) instead of branching
-            const int ins = min(wave + 4 * i, NT * 9 - 1);
+        for (int i = 0; i < (Cfg::NDMA + NWAVE - 1) / NWAVE; ++i) {
+            // wave-uniform piece; past the end a wave repeats the last piece (same bytes to the same place) instead of branching
+            const int ins = min(wave + NWAVE * i, Cfg::NDMA - 1);
             const int j = ins / 9, r = ins - 9 * j;
             const int nb = (tl.n0 >> 5) + j;
-            const bool ok = nb * 32 < a.Ntot;
+            const bool ok = valid && nb * 32 < a.Ntot;           // (an invalid request still issues: the vmcnt bookkeeping below counts instructions)
             const int soff = ok ? ((nb * K16 + g) * 27648 + tr * WBLK + r * 1024) : 0;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + j * WBLK + r * 1024),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + ins * 1024),
                                                      16, ok ? (unsigned)lane * 16u : OOB, soff, 0, 0);
         }
     };
@@ -178,16 +196,24 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // MFMA over the three taps of filter row TR out of weight stage st
-    auto mfma_row = [&](int tr, int st) {
+    // MFMA over the three taps of filter row tr: halo image img, weight stage st.  FILL: the 12 staging slices of the next
+    // chunk's halo (into image img ^ 1) are dealt over the 3 * MT * NT groups of six MFMAs.  `requests` (the LDS-DMA / halo
+    // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right AFTER the first group
+    // of MFMAs has been issued -- in front of the first LDS reads it kept the matrix pipe idle at the start of every item.
+    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto&& requests) {
+        constexpr bool FILL = decltype(fill_tag)::value;
+#ifdef X3_REQ_FIRST               // experiment: requests in front of the item's first LDS reads (the previous placement)
+        requests();
+#endif
         const char* wst = wsb + st * Cfg::WS_STAGE;
+        const u32x4* xim = xs + img * XS_F4;
         u32x4 av[2][MT][3], bv[2][NT][3];
         auto lds_load = [&](int tp, u32x4 (&ax)[MT][3], u32x4 (&bx)[NT][3]) {
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
-                    ax[i][p] = xs[(half * 3 + p) * NPIX + (wave * MT + i + tr) * HC + tp + l31];
+                    ax[i][p] = xim[(half * 3 + p) * NPIX + (wave * MT + i + tr) * HC + tp + l31];
 #pragma unroll
             for (int j = 0; j < NT; ++j)
 #pragma unroll
@@ -206,9 +232,27 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+#ifdef X3_SKIP_MFMA               // timing experiment only: staging without the matrix work
+#define X3_MFMA(PA, PB) acc[i][j][0] += __uint_as_float(ax[i][PA][0] ^ bx[j][PB][0])
+#else
 #define X3_MFMA(PA, PB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[i][PA]), __builtin_bit_cast(bf16x8, bx[j][PB]), acc[i][j], 0, 0, 0)
+#endif
                     X3_MFMA(0, 2); X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 1); X3_MFMA(1, 0); X3_MFMA(0, 0);
 #undef X3_MFMA
+#ifndef X3_REQ_FIRST
+                    if (tp == 0 && i == 0 && j == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        requests();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#endif
+                    if constexpr (FILL) {
+                        constexpr int NGRP = 3 * MT * NT, PER = 12 / NGRP;      // 12 groups: 1 slice each; 6 groups: 2 each
+                        const int grp = (tp * MT + i) * NT + j;
+#pragma unroll
+                        for (int e = 0; e < PER; ++e) stage_slice(grp * PER + e, img ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);                    // keep the slice behind ITS group of MFMAs
+                    }
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -216,7 +260,7 @@ igemm_x3_kernel(const IgemmArgs a) {
 
     // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
     // channel base are wave-uniform per 32-column block); half a 32x32 tile (16 pixels) at a time through a 2 KB patch
-    auto epilogue = [&](const Tile& tl) {
+    auto epilogue = [&](const Tile& tl, float* epi) {
         const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
         float* eb = epi + wave * 512;
         const int q4 = (lane & 7) * 4, pr = lane >> 3;
@@ -287,45 +331,112 @@ igemm_x3_kernel(const IgemmArgs a) {
         }
     };
 
-    // ---- main loop over (tile, 16-channel chunk); the three filter rows of a chunk are straight-line code, so every
-    // s_waitcnt below is exact: vector-memory operations complete in issue order, and the order of issue is
-    //   row 0: [weights of row 1 -> stage st^1] [halo of the NEXT chunk -> registers, 2*NSLOT loads]      row 1: [weights of row 2 -> st]
-    //   row 2: [weights of the next chunk's row 0 -> st^1]
+    // ---- main loop over (tile, 16-channel chunk).  A chunk's three filter rows are straight-line code, so every s_waitcnt
+    // below is exact: vector-memory operations complete in issue order.  Items are numbered it = 3 * chunk + row; item it
+    // reads weight stage it % NSTAGE and, right after its barrier, requests the weights of item it + AHEAD.
     int t = xcd_remap(blockIdx.x, G);
     if (t >= total) return;
     Tile cur = decode(t), nxt = decode(t + G < total ? t + G : t);       // nxt: the tile this workgroup takes after cur
-    int g = 0, st = 0;
+    int g = 0, img = 0;
+    constexpr int D = Cfg::DPW, HL = 2 * NSLOT;                          // vmcnt units: weight requests of one item, halo loads of one chunk
+    // the k-th chunk after the current one: (tile, chunk, exists); past the end of this workgroup's work it falls back to the
+    // current chunk (requests stay branch-free and the instruction counts exact; weights are then requested with valid = false)
+    struct Ck { Tile tile; int g; bool ok; };
+    auto chunk_at = [&](int k) {
+        int gk = g + k, tk = t;
+        while (gk >= nchunks) { gk -= nchunks; tk += G; }
+        Ck c;
+        c.ok = tk < total;
+        c.g = c.ok ? gk : g;
+        c.tile = !c.ok || tk == t ? cur : (tk == t + G ? nxt : decode(tk));
+        return c;
+    };
     dma_weights(cur, 0, 0, 0);
     load_halo(cur, 0);
-    bool first = true;
-    for (;;) {
-        int ng = g + 1, nt = t;
-        if (ng == nchunks) { ng = 0; nt = t + G; }
-        const bool more = nt < total;
-        const Tile& ntile = nt == t ? cur : nxt;
-        // ---- filter row 0: halo registers + this row's weights have landed
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
-        if (!first) __syncthreads();                                // every wave is past the previous chunk: xs may be overwritten
-        first = false;
-        store_halo();
-        __syncthreads();
-        dma_weights(cur, g, 1, st ^ 1);
-        load_halo(more ? ntile : cur, more ? ng : g);               // (past the last chunk: a harmless re-load keeps the code branch-free)
-        mfma_row(0, st);
-        // ---- filter row 1
-        __builtin_amdgcn_s_waitcnt(0x0f70 | (2 * NSLOT));           // the weights of row 1; the halo loads stay in flight
-        __syncthreads();
-        dma_weights(cur, g, 2, st);
-        mfma_row(1, st ^ 1);
-        // ---- filter row 2
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: in-order completion, wait for all
-        __syncthreads();
-        if (more) dma_weights(ntile, ng, 0, st ^ 1);
-        mfma_row(2, st);
-        if (ng == 0) epilogue(cur);
-        if (!more) break;
-        if (nt != t) { cur = nxt; nxt = decode(nt + G < total ? nt + G : nt); }
-        t = nt; g = ng; st ^= 1;
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) stage_slice(q, 0);                     // the first chunk's halo: nothing to hide it behind yet
+    if constexpr (BN == 64) {
+        // two weight stages, one item ahead.  Issue order per chunk:
+        //   row 0: [weights row 1][halo of the NEXT chunk]   row 1: [weights row 2]   row 2: [weights of the next chunk's row 0]
+        int st = 0;
+#ifdef X3_STAMPS                  // debug build: where does an item's time go?  (cycle sums per wave, dumped into dst[0] at the end)
+        long long tw = 0, tb = 0, tm = 0, te = 0, tall = clock64();
+#define X3_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
+        long long tlast_ = clock64();
+#else
+#define X3_T(v)
+#endif
+        for (;;) {
+            const Ck n1 = chunk_at(1);
+            // ---- filter row 0: its weights have landed; the barrier publishes them and halo image img (written during the
+            // previous chunk's row 2), and says every wave is done with the other image and stage
+            __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
+            X3_T(tw)
+            __syncthreads();
+            X3_T(tb)
+            mfma_row(0, st, img, std::false_type{}, [&] { dma_weights(cur, g, 1, st ^ 1); load_halo(n1.tile, n1.g); });
+            X3_T(tm)
+            // ---- filter row 1
+            __builtin_amdgcn_s_waitcnt(0x0f70 | HL);                    // the weights of row 1; the halo loads stay in flight
+            X3_T(tw)
+            __syncthreads();
+            X3_T(tb)
+            mfma_row(1, st ^ 1, img, std::false_type{}, [&] { dma_weights(cur, g, 2, st); });
+            X3_T(tm)
+            // ---- filter row 2 (+ the next chunk's halo: registers -> split -> image img^1, between the MFMAs)
+            __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: wait for all
+            X3_T(tw)
+            __syncthreads();
+            X3_T(tb)
+            mfma_row(2, st, img, std::true_type{}, [&] { dma_weights(n1.tile, n1.g, 0, st ^ 1, n1.ok); });
+            X3_T(tm)
+            if (g == nchunks - 1) {
+                __syncthreads();                                        // every wave has finished reading stage st: it holds the epilogue patches now
+                epilogue(cur, reinterpret_cast<float*>(wsb + st * Cfg::WS_STAGE));
+                X3_T(te)
+            }
+            if (!n1.ok) break;
+            if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
+            st ^= 1; img ^= 1;
+        }
+#ifdef X3_STAMPS
+        if (lane == 0) {
+            __syncthreads();
+            float* d = a.dst[0] + ((int64_t)blockIdx.x * NWAVE + wave) * 8;
+            d[0] = (float)tw; d[1] = (float)tb; d[2] = (float)tm; d[3] = (float)te; d[4] = (float)(clock64() - tall);
+        }
+#endif
+    } else {
+        // three weight stages, two items ahead: with three items per chunk, filter row r always lives in stage r.  The halo of
+        // chunk c+2 is requested at the END of chunk c's row 2 (as soon as the registers are free): three items of flight
+        // time.  Issue order per chunk:
+        //   row 0: [weights row 2]   row 1: [weights next row 0]   row 2: [weights next row 1] [halo of the chunk after next]
+        {
+            const Ck n1 = chunk_at(1);                                  // what the steady state requested one chunk earlier
+            dma_weights(cur, 0, 1, 1);
+            load_halo(n1.tile, n1.g);
+        }
+        for (;;) {
+            const Ck n1 = chunk_at(1), n2 = chunk_at(2);
+            // ---- row 0: outstanding [w row 0][w row 1][halo next]
+            __builtin_amdgcn_s_waitcnt(0x0f70 | (D + HL));
+            __syncthreads();
+            mfma_row(0, 0, img, std::false_type{}, [&] { dma_weights(cur, g, 2, 2); });
+            // ---- row 1: outstanding [w row 1][halo next][w row 2]
+            __builtin_amdgcn_s_waitcnt(0x0f70 | (HL + D));
+            __syncthreads();
+            mfma_row(1, 1, img, std::false_type{}, [&] { dma_weights(n1.tile, n1.g, 0, 0, n1.ok); });
+            // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
+            __builtin_amdgcn_s_waitcnt(0x0f70 | D);
+            __syncthreads();
+            mfma_row(2, 2, img, std::true_type{}, [&] { dma_weights(n1.tile, n1.g, 1, 1, n1.ok); });
+            load_halo(n2.tile, n2.g);
+            if (g == nchunks - 1) epilogue(cur, epi_sep);
+            if (!n1.ok) break;
+            if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
+            img ^= 1;
+        }
     }
 }
 
@@ -333,20 +444,16 @@ template <int BN>
 int launch_x3(const IgemmArgs& a, hipStream_t s) {
     using Cfg = X3Cfg<BN>;
     auto kern = igemm_x3_kernel<BN>;
-    static PnnpPerDevice lds_once, occ;
+    static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
-    const int per_cu = occ.get([&] {
-        int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, reinterpret_cast<const void*>(kern), 256, Cfg::LDS_BYTES) != hipSuccess || n < 1) n = 1;
-        return n;
-    });
+    const int per_cu = 1;                                           // ~150 KB of LDS: one 8-wave workgroup per CU
     int cus = pnnp_device_cus();
     if (cus < 1) cus = 256;
     const int tiles = ((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + BN - 1) / BN);
     if (tiles <= 0) return PNNP_OK;
     int wgs = per_cu * cus;
     if (wgs > tiles) wgs = tiles;
-    hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();
 }
 

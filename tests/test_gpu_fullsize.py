@@ -5,8 +5,8 @@
 * config 3's batch (16 crops of 4x512x512, nf=32), forward AND backward, through size-independent properties:
   every crop's output equals that crop run alone (no cross-crop leakage in tiles, halos, persistent work lists, split-K
   slabs), the batch gradient is the mean of the 16 single-crop gradients (the loss is a mean over the batch), and the
-  Winograd and direct kernel families agree on every gradient tensor;
-* config 2's frame (4x1424x2128: odd 89x133 maps at the bottom level): Winograd and direct forward agree."""
+  bf16x3 / Winograd / direct kernel families agree on every gradient tensor;
+* config 2's frame (4x1424x2128: odd 89x133 maps at the bottom level): the bf16x3, Winograd and direct forward agree."""
 import os
 
 import numpy as np
@@ -37,8 +37,13 @@ def _he_net(arch, seed=11):
     return net.cuda(), sd
 
 
-def _fwd(net, x, wino):
-    net.engine.set_policy(wino=wino)
+FAMILIES = {'x3': dict(x3=True, wino=True), 'wino': dict(x3=False, wino=True), 'direct': dict(x3=False, wino=False)}
+# x3: 3x3 forward / backward-data on the bf16 matrix cores (float32 operands split in three), Winograd backward-weight;
+# wino: Winograd F(2x2,3x3) on the fp32 matrix cores where it applies; direct: fp32 implicit GEMM everywhere
+
+
+def _fwd(net, x, family):
+    net.engine.set_policy(**FAMILIES[family])
     with torch.no_grad():
         return net(x).clone()
 
@@ -53,8 +58,8 @@ def _grads(net):
 
 
 @pytest.mark.parametrize('arch', ['unet', 'resunet'])
-@pytest.mark.parametrize('wino', [True, False])
-def test_512_crop_backward_vs_reference_golden(golden_dir, arch, wino):
+@pytest.mark.parametrize('family', ['x3', 'wino', 'direct'])
+def test_512_crop_backward_vs_reference_golden(golden_dir, arch, family):
     """One crop at the benchmark's size against the reference modules' own loss.backward() (make_golden.py `nets512`:
     stable-sign construction, float32 AND float64 runs of the reference).  At this depth and size float32 itself limits
     agreement: the reference's float32 gradients are 1.5e-3 .. 2.2e-3 (relative L2 per tensor) from its float64 gradients.
@@ -70,7 +75,7 @@ def test_512_crop_backward_vs_reference_golden(golden_dir, arch, wino):
     gen = torch.Generator().manual_seed(2)
     x = torch.rand(1, 4, 512, 512, generator=gen)
     t = (torch.rand(1, 4, 512, 512, generator=gen) > 0.5).float()
-    net.engine.set_policy(wino=wino)
+    net.engine.set_policy(**FAMILIES[family])
     ts = HipTrainStep(net, lr=0.0, clip=0)
     lo = ts.step(t.cuda(), noisy=x.cuda())
     assert abs(float(lo[0]) - float(g['loss'])) < 5e-6, (float(lo[0]), float(g['loss']))
@@ -89,20 +94,21 @@ def test_512_crop_backward_vs_reference_golden(golden_dir, arch, wino):
         l2 = float(g['g:' + k + ':sum'][1])
         assert abs(float(np.sqrt((got ** 2).sum())) - l2) <= 2e-3 * l2 + 1e-12, k
     assert np.median(ratios) <= 2.0, np.median(ratios)
-    print(f'{arch} wino={wino}: worst HIP error / reference-fp32 error (both vs fp64) = {worst[0]:.2f} at {worst[1]}')
+    print(f'{arch} {family}: worst HIP error / reference-fp32 error (both vs fp64) = {worst[0]:.2f} at {worst[1]}')
 
 
 def test_batch_of_16_crops_is_16_independent_crops_and_wino_equals_direct():
     net = _net()
     g = torch.Generator(device='cuda').manual_seed(0)
     x = torch.rand(16, 4, 512, 512, device='cuda', generator=g)
-    yw = _fwd(net, x, True)
-    yd = _fwd(net, x, False)
-    assert torch.isfinite(yw).all() and float(yw.abs().max()) > 1e-3
-    assert _rel(yw, yd) < 2e-5                                  # same fp32 arithmetic up to summation order / transforms
-    for b in (0, 7, 15):
-        alone = _fwd(net, x[b:b + 1].contiguous(), True)
-        assert _rel(alone[0], yw[b]) < 1e-6                     # identical tiling per crop: (near) bit-equal
+    yd = _fwd(net, x, 'direct')
+    assert torch.isfinite(yd).all() and float(yd.abs().max()) > 1e-3
+    for fam in ('x3', 'wino'):
+        yf = _fwd(net, x, fam)
+        assert _rel(yf, yd) < 2e-5, fam                         # float32 arithmetic up to summation order / transforms / the 2^-24 split remainder
+        for b in (0, 7, 15):
+            alone = _fwd(net, x[b:b + 1].contiguous(), fam)
+            assert _rel(alone[0], yf[b]) < 1e-6, fam            # identical tiling per crop: (near) bit-equal
 
 
 def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
@@ -118,17 +124,19 @@ def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
     t = (torch.rand(16, 4, 512, 512, device='cuda', generator=g) > 0.5).float()
     ts = HipTrainStep(net, lr=0.0, clip=0)
     out = {}
-    for wino in (True, False):
-        net.engine.set_policy(wino=wino)
+    for fam in FAMILIES:
+        net.engine.set_policy(**FAMILIES[fam])
         lo = ts.step(t, noisy=x)
-        out[wino] = (float(lo[0]), _grads(net))
-    assert abs(out[True][0] - out[False][0]) < 2e-6
-    for k in out[True][1]:
-        a, b = out[True][1][k], out[False][1][k]
-        rel = float((a - b).norm() / (b.norm() + 1e-20))
-        assert rel < 1e-2, (k, rel)
+        out[fam] = (float(lo[0]), _grads(net))
+    for fam in ('x3', 'wino'):
+        assert abs(out[fam][0] - out['direct'][0]) < 2e-6
+        for k in out[fam][1]:
+            a, b = out[fam][1][k], out['direct'][1][k]
+            rel = float((a - b).norm() / (b.norm() + 1e-20))
+            assert rel < 1e-2, (fam, k, rel)
     # linearity over the batch: loss = mean over crops  =>  batch gradient = mean of single-crop gradients
-    net.engine.set_policy(wino=True)
+    out[True] = out['x3']
+    net.engine.set_policy(**FAMILIES['x3'])
     acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in out[True][1].items()}
     loss_sum = 0.0
     for b in range(16):
@@ -147,7 +155,8 @@ def test_full_sid_frame_wino_equals_direct():
     net = _net()
     g = torch.Generator(device='cuda').manual_seed(1)
     x = torch.rand(1, 4, 1424, 2128, device='cuda', generator=g)
-    yw = _fwd(net, x, True)
-    yd = _fwd(net, x, False)
-    assert yw.shape == x.shape and torch.isfinite(yw).all()
-    assert _rel(yw, yd) < 2e-5
+    yd = _fwd(net, x, 'direct')
+    for fam in ('x3', 'wino'):
+        yf = _fwd(net, x, fam)
+        assert yf.shape == x.shape and torch.isfinite(yf).all()
+        assert _rel(yf, yd) < 2e-5, fam
