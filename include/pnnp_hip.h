@@ -181,6 +181,13 @@ int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgra
                                  int B, int H, int W, void* stream);
 int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int C1,
                                      const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream);
+/* backward-weight of the same layers (csrc/wgrad_x3.hip; pixel-major LDS images read with ds_read_b64_tr_b16): same contract
+ * as pnnp_conv_bwd_weight_f32 with taps = 9; channel counts in multiples of 32; workspace from the query. */
+int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2);
+int64_t pnnp_x3_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
+int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
+                                   const float* x2 /*or null*/, int x2_cs, int C2, float* dW, float* dbias /*or null*/,
+                                   int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
 
 /* (The Winograd kernel's cycle-stamp hook `pnnp_wino_set_debug` exists only in profiling builds, -DPNNP_WINO_DEBUG=1: the shipped
  * library exports no debug hook, reads no environment variable and keeps no state between calls besides idempotent per-device

@@ -220,7 +220,9 @@ class ResUnetEngine(_EngineBase):
 
         def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
             c2 = x2.shape[3] if x2 is not None else 0
-            if taps == 9 and self.policy.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
+            if taps == 9 and self.policy.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2):
+                ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+            elif taps == 9 and self.policy.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             else:
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
@@ -284,7 +286,8 @@ class ResUnetEngine(_EngineBase):
         need = 1024 * max(ch)
         for lv in range(5):
             h, w, c = H >> lv, W >> lv, ch[lv]
-            need = max(need, ops.wino_wgrad_workspace_floats(B, h, w, c, c), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c))
+            need = max(need, ops.wino_wgrad_workspace_floats(B, h, w, c, c), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c),
+                       ops.x3_wgrad_workspace_floats(B, h, w, c, c), ops.x3_wgrad_workspace_floats(B, h, w, c, 2 * c))
             need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9),
                        ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 1), ops.wgrad_workspace_floats(B, h, w, c, self.cin, 9))
             if lv < 4:

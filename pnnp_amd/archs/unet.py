@@ -50,6 +50,10 @@ class ConvPolicy:
             return False, False
         return (ops.wino_supported(ci, co) and ci >= self.wino_mink, ops.wino_supported(co, ci) and co >= self.wino_mink)
 
+    def use_x3_wgrad(self, h, w, cout, c1, c2):
+        """backward-weight of a 3x3 layer on the bf16x3 kernel (csrc/wgrad_x3.hip)?"""
+        return self.x3 and ops.x3_wgrad_supported(h, w, cout, c1, c2)
+
     def use_wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
         return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
 
@@ -338,7 +342,10 @@ class UNetEngine(_EngineBase):
 
         def wgrad(name, gpre, cout, x1, c1, x2=None, taps=9):
             c2 = x2.shape[3] if x2 is not None else 0
-            if taps == 9 and self._wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
+            if taps == 9 and self.policy.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2):
+                ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
+                                       G(name + '.bias', (cout,)), wsf, accumulate=acc)
+            elif taps == 9 and self._wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
                                          G(name + '.bias', (cout,)), wsf, accumulate=acc)
             else:
@@ -392,6 +399,8 @@ class UNetEngine(_EngineBase):
             h, w = H >> lvl, W >> lvl
             c = ch[lvl]
             cin = self.cin if lvl == 0 else ch[lvl - 1]
+            need = max(need, ops.x3_wgrad_workspace_floats(B, h, w, c, c), ops.x3_wgrad_workspace_floats(B, h, w, c, 2 * c),
+                       ops.x3_wgrad_workspace_floats(B, h, w, c, cin) if cin % 32 == 0 else 0)
             need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, cin, 9),
                        ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9), ops.wino_wgrad_workspace_floats(B, h, w, c, c),
                        ops.wino_wgrad_workspace_floats(B, h, w, c, cin), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c))

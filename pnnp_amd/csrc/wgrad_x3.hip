@@ -1,0 +1,403 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores, float32 operands split into three bf16
+// pieces (the scheme of csrc/conv_x3.hip: a = hi + mid + lo exactly, six of the nine piece products, fp32 accumulation).
+//
+//   dW[m][n][t] = sum over pixels p of  G[p][m] * X[p + tap(t)][n]        (archs/Unet.py:16-50 via autograd;
+//   G = dL/d(pre-activation output) [B][H][W][M = Cout], X = the layer's input [B][H][W][N = Cin], possibly the
+//   un-materialised cat of two tensors), plus the bias gradient dbias[m] = sum_p G[p][m].
+//
+// GEMM view: M = Cout, N = Cin, K = pixels.  v_mfma_f32_32x32x16_bf16 wants, per lane, 8 consecutive k (pixels) of one
+// channel, but the tensors are NHWC (a pixel's channels are contiguous).  The LDS images therefore stay pixel-major,
+//   gs[32-channel block][piece][pixel][32 ch]      xs[32-channel block][piece][halo pixel][32 ch]          (bf16, 64-byte rows)
+// and the operands are fetched with ds_read_b64_tr_b16, gfx950's transposing LDS read: per 16 lanes a 4-pixel x 16-channel
+// block arrives channel-major, so two reads give a lane its 8 pixels of one channel of one piece (conflict-free on 64-byte
+// rows: a 32-lane half touches 4 x 64 consecutive bytes).  A filter tap is a pixel offset into the halo image.
+//
+// One workgroup of 8 waves per CU owns an output tile of (32 WM) x (32 WN) channels x 9 taps and a strided share of the
+// pixel tiles (TH rows x 32 px); a wave owns one 32 x 32 x 9 accumulator block (144 VGPRs) and 1/WK of a tile's 16-pixel
+// k-steps.  Per k-step and wave: 6 transposed reads for G (shared by the 9 taps), 6 per tap for X, 54 MFMAs.
+// Staging: fp32 tiles global -> registers one tile ahead (issued late in tile i for tile i+2, a full tile of flight time),
+// split and written to the OTHER image between the MFMAs of the late part of tile i+1; one barrier per tile.
+// Partial results go to per-workgroup slabs that a second kernel sums in a fixed order (deterministic, no float atomics).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+struct Wx3Args {
+    const float* G; int Gcs;            // [B][H][W][Gcs], channels [0, M) used
+    const float* X[2]; int Xcs[2];      // n < n_split -> X[0][n], else X[1][n - n_split]
+    int n_split;
+    int B, H, W, M, N;
+    float* slab;                        // [Z][9][M][N]
+    float* bias_slab;                   // [Z][M] or null
+    int Z;
+};
+
+constexpr int NTHR = 512, NWAVE = 8;
+
+template <int WM, int WN, int TH>
+struct Wx3Cfg {
+    static constexpr int WK = NWAVE / (WM * WN);
+    static constexpr int KS = TH * 2 / WK;                          // 16-pixel k-steps per wave and tile
+    static constexpr int GPIX = TH * 32, XR = TH + 2, XC = 34, XPIX = XR * XC;
+    static constexpr int G_BYTES = WM * 3 * GPIX * 64, X_BYTES = WN * 3 * XPIX * 64;
+    static constexpr int IMG_BYTES = G_BYTES + X_BYTES;
+    static constexpr int LDS_BYTES = 2 * IMG_BYTES;
+    // staging slots (one float4 = 4 channels of a pixel): a 32-channel block of G / X is staged by the waves with wave % WM == block
+    static constexpr int G_THR = NTHR / WM, X_THR = NTHR / WN;
+    static constexpr int NG = (GPIX * 8 + G_THR - 1) / G_THR, NX = (XPIX * 8 + X_THR - 1) / X_THR;
+    static_assert(WM * WN * WK == NWAVE && KS >= 1 && KS * WK == TH * 2, "wave layout");
+    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NWAVE * 16 * 64 * 4, "LDS budget (images; reduction scratch aliases them)");
+};
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // RNE, low half = a
+    unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+template <int WM, int WN, int TH>
+__global__ void __launch_bounds__(NTHR)
+wgrad_x3_kernel(const Wx3Args a) {
+    using Cfg = Wx3Cfg<WM, WN, TH>;
+    constexpr int WK = Cfg::WK, KS = Cfg::KS, GPIX = Cfg::GPIX, XC = Cfg::XC, XPIX = Cfg::XPIX, NG = Cfg::NG, NX = Cfg::NX;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int wk = wave % WK, wno = (wave / WK) % WN, wmo = wave / (WK * WN);
+
+    const int n_tiles = a.N / (32 * WN);
+    int id = blockIdx.x;
+    const int z = id % a.Z; id /= a.Z;
+    const int ni = id % n_tiles, mi = id / n_tiles;
+    const int m0 = mi * 32 * WM, n0 = ni * 32 * WN;
+
+    const int tiles_x = (a.W + 31) >> 5, tiles_y = (a.H + TH - 1) / TH;
+    const int ntile = tiles_x * tiles_y * a.B;
+
+    // ---- staging pattern.  G: block gb = wave % WM, slot j = (wave / WM) * 64 + lane + G_THR * k over (pixel j >> 3, quad j & 7);
+    //      X: block xb = wave % WN likewise over the halo pixels.  Slots past the end repeat the thread's previous slot.
+    const int gb = wave % WM, xb = wave % WN;
+    const int q8 = lane & 7;                                        // this thread's channel quad inside its 32-channel block
+    int g_r[NG], g_c[NG]; unsigned g_off[NG]; int g_dst[NG];
+#pragma unroll
+    for (int k = 0; k < NG; ++k) {
+        int j = (wave / WM) * 64 + lane + Cfg::G_THR * k;
+        if (j >= GPIX * 8) j -= Cfg::G_THR;
+        const int pix = j >> 3;
+        g_r[k] = pix >> 5; g_c[k] = pix & 31;
+        g_off[k] = (unsigned)((g_r[k] * a.W + g_c[k]) * a.Gcs + q8 * 4) * 4u;
+        g_dst[k] = (gb * 3 * GPIX + pix) * 64 + q8 * 8;             // byte offset in an image; + piece * GPIX * 64
+    }
+    const int xd = (n0 + 32 * xb >= a.n_split) ? 1 : 0;             // wave-uniform source of this wave's X block
+    const int xch0 = n0 + 32 * xb - (xd ? a.n_split : 0);
+    const int xcs = a.Xcs[xd];
+    int x_r[NX], x_c[NX]; unsigned x_off[NX]; int x_dst[NX];
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        int j = (wave / WN) * 64 + lane + Cfg::X_THR * k;
+        if (j >= XPIX * 8) j -= Cfg::X_THR;
+        const int pix = j >> 3;
+        x_r[k] = pix / XC; x_c[k] = pix - x_r[k] * XC;              // halo coordinates, 0-based: image pixel (y0 - 1 + r, x0 - 1 + c)
+        x_off[k] = (unsigned)((x_r[k] * a.W + x_c[k]) * xcs + q8 * 4) * 4u;
+        x_dst[k] = Cfg::G_BYTES + (xb * 3 * XPIX + pix) * 64 + q8 * 8;
+    }
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * gb), 0, 0x7fffffff, 0x00020000);
+    // (the X resource starts one row + one pixel BEFORE the tensor so that the scalar offset of a halo tile is never negative)
+    const int xshift = (a.W + 1) * xcs;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X[xd] + xch0 - xshift), 0, 0x7fffffff, 0x00020000);
+    auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    };
+
+    f32x4 rg[NG], rx[NX];
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    auto load_tile = [&](int tile) {
+        int q = tile;
+        const int tx = q % tiles_x; q /= tiles_x;
+        const int ty = q % tiles_y;
+        const int b = q / tiles_y;
+        const int x0 = tx * 32, y0 = ty * TH;
+        const int gso = (((b * a.H + y0) * a.W) + x0) * a.Gcs * 4;
+        const int xso = ((((b * a.H + y0 - 1) * a.W) + x0 - 1) * xcs + xshift) * 4;
+        const int rlim = a.H - y0, clim = a.W - x0;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int bad = (rlim - 1 - g_r[k]) | (clim - 1 - g_c[k]);                 // sign bit set <=> pixel outside the image
+            rg[k] = bload(rsg, bad < 0 ? OOB : g_off[k], gso);
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const int yy = y0 - 1 + x_r[k], xx = x0 - 1 + x_c[k];
+            const int bad = yy | (a.H - 1 - yy) | xx | (a.W - 1 - xx);
+            rx[k] = bload(rsx, bad < 0 ? OOB : x_off[k], xso);
+        }
+    };
+    // one staging slice: split slot s (G slots first, then X) and write its three 8-byte words to image `img`
+    auto stage_slice = [&](int s, int img) {
+        char* ib = smem + img * Cfg::IMG_BYTES;
+        const bool isg = s < NG;
+        const f32x4 v = isg ? rg[isg ? s : 0] : rx[isg ? 0 : s - NG];
+        const int dst = isg ? g_dst[isg ? s : 0] : x_dst[isg ? 0 : s - NG];
+        const int pstride = (isg ? GPIX : XPIX) * 64;
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split2(v.x, v.y, h0, m0_, l0);
+        split2(v.z, v.w, h1, m1, l1);
+        const u32x2 h = {h0, h1}, m = {m0_, m1}, l = {l0, l1};
+        *reinterpret_cast<u32x2*>(ib + dst) = h;
+        *reinterpret_cast<u32x2*>(ib + dst + pstride) = m;
+        *reinterpret_cast<u32x2*>(ib + dst + 2 * pstride) = l;
+        if (isg && a.bias_slab) {                                    // bias gradient: column sums of G, gathered while it is staged
+            // (a duplicated last slot would count twice: only configurations with exact G slot counts exist, see static_assert below)
+            bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;
+        }
+    };
+    static_assert((GPIX * 8) % Cfg::G_THR == 0, "G slots must divide evenly (bias sums count every pixel once)");
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // transposed-read lane geometry: 16-lane group g = lane >> 4 reads channels 16 (g & 1) .., pixels 8 (g >> 1) ..; inside a
+    // group lane 4 q + p supplies the address of pixel row q, channel chunk 4 p
+    const int tr_lane = ((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto tr_read = [&](const char* base) {                           // 8 pixels x 1 channel per lane: two transposed reads
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * 64));
+        u32x4 r;
+        const u32x2 a0 = __builtin_bit_cast(u32x2, lo), a1 = __builtin_bit_cast(u32x2, hi);
+        r.x = a0.x; r.y = a0.y; r.z = a1.x; r.w = a1.y;
+        return r;
+    };
+
+    constexpr int NSL = NG + NX;                                    // staging slices per tile
+    constexpr int NGRP = KS * 9;                                     // groups of six MFMAs per tile and wave
+    constexpr int SL0 = NGRP - 1 - NSL;                              // first group that carries a slice (the last group carries the loads)
+    static_assert(SL0 >= 0, "more staging slices than MFMA groups");
+
+    if (z >= ntile) {                                               // (more pixel splits than tiles never happens: Z <= ntile)
+        return;
+    }
+    // ---- prologue: the first tile goes straight into image 0, the second one into registers
+    load_tile(z);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) stage_slice(s, 0);
+    if (z + a.Z < ntile) load_tile(z + a.Z);
+    int img = 0;
+    for (int tile = z; tile < ntile; tile += a.Z) {
+        __syncthreads();                                            // image `img` is complete; every wave is done with the other one
+        const char* gimg = smem + img * Cfg::IMG_BYTES;
+        const char* ximg = gimg + Cfg::G_BYTES;
+        const bool have_next = tile + a.Z < ntile, have_next2 = tile + 2 * a.Z < ntile;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = wk * KS + ks;                            // k-step of the tile: pixel row kk >> 1, pixels 16 (kk & 1) ..
+            const int r = kk >> 1, c0 = (kk & 1) * 16;
+            const char* gbase = gimg + ((wmo * 3) * GPIX + r * 32 + c0) * 64 + tr_lane;
+            u32x4 av[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) av[p] = tr_read(gbase + p * GPIX * 64);
+            u32x4 bv[2][3];
+            auto xload = [&](int t, u32x4 (&bx)[3]) {
+                const int dy = t / 3, dx = t - 3 * dy;
+                const char* xbase = ximg + ((wno * 3) * XPIX + (r + dy) * XC + c0 + dx) * 64 + tr_lane;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) bx[p] = tr_read(xbase + p * XPIX * 64);
+            };
+            xload(0, bv[0]);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                if (t + 1 < 9) xload(t + 1, bv[(t + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 (&bx)[3] = bv[t & 1];
+                // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+#define WX3_MFMA(PA, PB) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA]), __builtin_bit_cast(bf16x8, bx[PB]), acc[t], 0, 0, 0)
+                WX3_MFMA(0, 2); WX3_MFMA(2, 0); WX3_MFMA(1, 1); WX3_MFMA(0, 1); WX3_MFMA(1, 0); WX3_MFMA(0, 0);
+#undef WX3_MFMA
+                __builtin_amdgcn_sched_barrier(0);
+                const int grp = ks * 9 + t;
+                if (grp >= SL0 && grp < SL0 + NSL) {                // the late groups carry the next tile's staging, one slice each
+                    if (grp == SL0) __builtin_amdgcn_s_waitcnt(0x0f70);        // its loads were issued a full tile ago
+                    if (have_next) stage_slice(grp - SL0, img ^ 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (grp == NGRP - 1 && have_next2) load_tile(tile + 2 * a.Z);   // registers are free again: the tile after next
+            }
+        }
+        img ^= 1;
+    }
+
+    // ---- reduce the WK pixel-split waves through LDS (the images are dead now), then write the slab [z][tap][m][n]
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+    const int64_t slab_base = (int64_t)z * a.M * a.N * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        f32x16 v = acc[t];
+        if (WK > 1) {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = v[r];
+            __syncthreads();
+            if (wk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WK; ++k) s += red[((wave + k) * 16 + r) * 64 + lane];
+                    v[r] = s;
+                }
+            }
+        }
+        if (wk == 0) {
+            const int n = n0 + wno * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wmo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = v[r];
+            }
+        }
+    }
+    if (a.bias_slab && ni == 0) {                                   // block-uniform
+        // a thread summed 4 channels (quad q8 of block gb) over its pixels: add up the threads that share (gb, q8)
+        __syncthreads();
+        float* bs = reinterpret_cast<float*>(smem);                 // [WM][8 quads][4] partial sums per contributing thread slot
+        // threads with the same (gb, q8): tid' = all with wave % WM == gb and lane & 7 == q8: (NWAVE / WM) waves x 8 lanes
+        const int slot = (wave / WM) * 8 + (lane >> 3);             // 0 .. (NWAVE / WM) * 8 - 1
+        constexpr int NSLOTS = (NWAVE / WM) * 8;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) bs[((gb * 8 + q8) * 4 + c) * NSLOTS + slot] = bsum[c];
+        __syncthreads();
+        if (tid < WM * 32) {
+            const int blk = tid >> 5, ch = tid & 31;
+            float s = 0.f;
+            for (int k = 0; k < NSLOTS; ++k) s += bs[((blk * 8 + (ch >> 2)) * 4 + (ch & 3)) * NSLOTS + k];
+            a.bias_slab[(int64_t)z * a.M + m0 + blk * 32 + ch] = s;
+        }
+    }
+}
+
+// out[o(i)] (+)= sum_z slab[z][i]; i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t  (the parameter's own layout)
+__global__ void __launch_bounds__(256)
+wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate, int64_t mn, int taps) {
+    __shared__ float red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n; i0 += (int64_t)gridDim.x * 32) {
+        const int64_t i = i0 + tx;
+        float s0 = 0.f, s1 = 0.f;
+        if (i < n) {
+            int zz = ty;
+            for (; zz + 8 < Z; zz += 16) { s0 += slab[(int64_t)zz * n + i]; s1 += slab[(int64_t)(zz + 8) * n + i]; }
+            for (; zz < Z; zz += 8) s0 += slab[(int64_t)zz * n + i];
+        }
+        red[ty][tx] = s0 + s1;
+        __syncthreads();
+        if (ty == 0 && i < n) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += red[k][tx];
+            const int64_t o = taps == 1 ? i : (i % mn) * taps + i / mn;
+            out[o] = accumulate ? out[o] + s : s;
+        }
+        __syncthreads();
+    }
+}
+
+template <int WM, int WN, int TH>
+int launch_wx3(const Wx3Args& a, hipStream_t s) {
+    using Cfg = Wx3Cfg<WM, WN, TH>;
+    auto kern = wgrad_x3_kernel<WM, WN, TH>;
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int blocks = (a.M / (32 * WM)) * (a.N / (32 * WN)) * a.Z;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTHR), Cfg::LDS_BYTES, s, a);
+    return pnnp_launch_status();
+}
+
+// output-tile shape: 64 x 64 (two pixel splits inside the workgroup), 64 x 32 / 32 x 64 (four), 32 x 32 (eight)
+int wx3_shape(int M, int N) { return (M % 64 == 0 ? 1 : 0) + (N % 64 == 0 ? 2 : 0); }
+int wx3_th(int shape) { return shape == 0 ? 4 : 2; }
+
+int wx3_splits(int B, int H, int W, int M, int N) {
+    const int shape = wx3_shape(M, N);
+    const int bm = (shape & 1) ? 64 : 32, bn = (shape & 2) ? 64 : 32;
+    const int th = wx3_th(shape);
+    const int tiles = ((W + 31) / 32) * ((H + th - 1) / th) * B;
+    const int out_tiles = (M / bm) * (N / bn);
+    int cus = pnnp_device_cus();
+    if (cus <= 0) cus = 256;
+    int z = (cus + out_tiles - 1) / out_tiles;                      // one 8-wave workgroup per CU
+    if (z > tiles) z = tiles;
+    return z < 1 ? 1 : z;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2) {
+    return (H > 0 && W > 0 && Cout > 0 && C1 > 0 && Cout % 32 == 0 && C1 % 32 == 0 && C2 % 32 == 0) ? 1 : 0;
+}
+
+int64_t pnnp_x3_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin) {
+    if (Cout % 32 || Cin % 32) return 0;
+    return (int64_t)wx3_splits(B, H, W, Cout, Cin) * ((int64_t)9 * Cout * Cin + Cout);
+}
+
+// dW [Cout][C1+C2][3][3] (+ dbias [Cout]) of a 3x3 / stride 1 / pad 1 convolution; same contract as pnnp_conv_bwd_weight_f32
+// with taps = 9 (g: dL/d(pre-activation output), x1 / x2: the layer's input(s)).
+int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
+                                   const float* x2, int x2_cs, int C2, float* dW, float* dbias,
+                                   int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
+    if (!g || !x1 || !dW || !workspace || B <= 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    const int N = C1 + (x2 ? C2 : 0);
+    if (!pnnp_x3_wgrad_supported(H, W, Cout, C1, x2 ? C2 : 0)) return PNNP_E_UNSUPPORTED;
+    if (g_cs < Cout || x1_cs < C1 || (x2 && x2_cs < C2) || (g_cs & 3) || (x1_cs & 3) || (x2 && (x2_cs & 3))) return PNNP_E_INVALID;
+    if ((((uintptr_t)g) | ((uintptr_t)x1) | ((uintptr_t)x2)) & 15) return PNNP_E_INVALID;
+    // 32-bit byte offsets into the whole tensors (bit 31 marks "outside")
+    const int64_t cmax = g_cs > x1_cs ? g_cs : x1_cs;
+    if (((int64_t)B * H + 2) * W * cmax * 4 >= (1ll << 31) || (x2 && ((int64_t)B * H + 2) * W * x2_cs * 4 >= (1ll << 31))) return PNNP_E_UNSUPPORTED;
+    if (workspace_floats < pnnp_x3_wgrad_workspace_floats(B, H, W, Cout, N)) return PNNP_E_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    Wx3Args a{};
+    a.G = g; a.Gcs = g_cs;
+    a.X[0] = x1; a.Xcs[0] = x1_cs; a.X[1] = x2 ? x2 : x1; a.Xcs[1] = x2 ? x2_cs : x1_cs; a.n_split = x2 ? C1 : (1 << 30);
+    a.B = B; a.H = H; a.W = W; a.M = Cout; a.N = N;
+    a.Z = wx3_splits(B, H, W, Cout, N);
+    a.slab = workspace;
+    a.bias_slab = dbias ? workspace + (int64_t)a.Z * 9 * Cout * N : nullptr;
+    int rc;
+    switch (wx3_shape(Cout, N)) {
+        case 3: rc = launch_wx3<2, 2, 2>(a, st); break;
+        case 1: rc = launch_wx3<2, 1, 2>(a, st); break;
+        case 2: rc = launch_wx3<1, 2, 2>(a, st); break;
+        default: rc = launch_wx3<1, 1, 4>(a, st); break;
+    }
+    if (rc != PNNP_OK) return rc;
+    const int64_t n = (int64_t)Cout * N * 9;
+    hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0, st,
+                       a.slab, dW, n, a.Z, accumulate, (int64_t)Cout * N, 9);
+    if (dbias)
+        hipLaunchKernelGGL(wx3_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, st, a.bias_slab, dbias, (int64_t)Cout, a.Z,
+                           accumulate, (int64_t)Cout, 1);
+    return pnnp_launch_status();
+}
+
+}  // extern "C"

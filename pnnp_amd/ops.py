@@ -38,6 +38,7 @@ def _prep():
         L.pnnp_wino_weight_floats.restype = C.c_int64
         L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3_weight_bytes.restype = C.c_int64
+        L.pnnp_x3_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -158,6 +159,25 @@ def conv_x3_bwd_data_res(g, w_x3_dgrad, dx, addsrc, mask=None, mode=0):
     with _Timed('conv9_dgrad_x3', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
         check(_prep().pnnp_conv3x3_x3_bwd_data_res_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
                                                        B, H, W, stream()), 'conv_x3_bwd_data_res')
+
+
+def x3_wgrad_supported(H, W, cout, c1, c2=0):
+    return bool(_prep().pnnp_x3_wgrad_supported(int(H), int(W), int(cout), int(c1), int(c2)))
+
+
+def x3_wgrad_workspace_floats(B, H, W, cout, cin):
+    return int(_prep().pnnp_x3_wgrad_workspace_floats(B, H, W, cout, cin))
+
+
+def conv_x3_bwd_weight(g, cout, x1, c1, x2, dW, dbias, workspace, accumulate=0):
+    """dW [cout][c1+c2][3][3] (+ dbias) on the bf16 matrix cores, fp32 operands split in three (same contract as conv_bwd_weight, taps=9)."""
+    require_cuda(g, x1, dW, workspace)
+    B, H, W, gcs = g.shape
+    c2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_wgrad_x3', 2.0 * B * H * W * cout * (c1 + c2) * 9, 4.0 * B * H * W * (gcs + x1.shape[3] + c2)):
+        check(_prep().pnnp_conv3x3_x3_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), c2, c2, ptr(dW), ptr(dbias),
+                                                     B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
+              'conv_x3_bwd_weight')
 
 
 def wino_supported(K, N):

@@ -130,3 +130,31 @@ def test_x3_is_as_accurate_as_the_fp32_mfma_kernel():
     e32 = float((nchw(y32).cpu().double() - ref).norm() / ref.norm())
     print(f'relative L2 error vs float64: bf16x3 {e3:.2e}, fp32 MFMA {e32:.2e}')
     assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7
+
+
+@pytest.mark.parametrize('case', [(2, 16, 48, 32, 0, 32), (1, 12, 40, 32, 0, 64), (1, 6, 70, 64, 0, 128), (2, 8, 32, 32, 32, 32),
+                                  (1, 8, 36, 64, 64, 64), (1, 5, 17, 128, 128, 128), (1, 4, 4, 256, 0, 256), (1, 16, 32, 32, 0, 256),
+                                  (3, 32, 64, 32, 0, 32), (2, 16, 32, 64, 64, 64), (3, 19, 50, 64, 32, 96), (1, 9, 33, 96, 0, 32)])
+def test_x3_bwd_weight(case):
+    """dW and dbias vs autograd on the CPU, at the fp32-MFMA weight-gradient kernel's bars (rtol 2e-4 / atol 2e-5 of the largest
+    sum), with and without accumulation."""
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2).requires_grad_(True)
+    b = _rand(Co, seed=4).requires_grad_(True)
+    g = _rand(B, Co, H, W, seed=5)
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    F.conv2d(xin, w, b, padding=1).backward(g)
+    assert ops.x3_wgrad_supported(H, W, Co, C1, C2)
+    ws = torch.empty(ops.x3_wgrad_workspace_floats(B, H, W, Co, C1 + C2), device='cuda')
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_x3_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW, db, ws)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'x3 wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'x3 bgrad {case}')
+    ops.conv_x3_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW, db, ws, accumulate=1)
+    close(dW, 2 * w.grad, rtol=2e-4, atol=2e-5, what='x3 wgrad accumulate')
+    close(db, 2 * b.grad, rtol=2e-4, atol=4e-5, what='x3 bgrad accumulate')
+    dW2 = torch.full(w.shape, float('nan'), device='cuda')
+    ops.conv_x3_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW2, None, ws)       # no bias gradient asked for
+    close(dW2, w.grad, rtol=2e-4, atol=2e-5, what='x3 wgrad without dbias')

@@ -51,6 +51,7 @@ def main():
         dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
         dW = torch.empty_like(w); db = torch.empty(Co, device=dev)
         ws = torch.empty(ops.wgrad_workspace_floats(B, H, H, Co, C1 + C2, 9), device=dev)
+        ws3 = torch.empty(max(1, ops.x3_wgrad_workspace_floats(B, H, H, Co, C1 + C2)), device=dev) if (a.x3 and C1 % 32 == 0) else None
         flops = 2.0 * B * H * H * Co * (C1 + C2) * 9
         if a.x3:
             jobs = ops.PackJobs()
@@ -60,7 +61,7 @@ def main():
         fns = {'fwd': (lambda: ops.conv_x3_fwd(x1, x2, f3, bias, y, Co, 1)) if a.x3 else (lambda: ops.conv_fwd(x1, x2, f, bias, y, Co, 9, 1)),
                'dgrad': (lambda: ops.conv_x3_bwd_data(g, d3, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)) if (a.x3 and C1 % 32 == 0) else
                         (lambda: ops.conv_bwd_data(g, d, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)),
-               'wgrad': lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws)}
+               'wgrad': (lambda: ops.conv_x3_bwd_weight(g, Co, x1, C1, x2, dW, db, ws3)) if (a.x3 and C1 % 32 == 0) else (lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws))}
         for k in kinds:
             fns[k](); torch.cuda.synchronize()
             ts = []
