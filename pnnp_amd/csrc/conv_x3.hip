@@ -198,13 +198,10 @@ igemm_x3_kernel(const IgemmArgs a) {
 
     // MFMA over the three taps of filter row tr: halo image img, weight stage st.  FILL: the 12 staging slices of the next
     // chunk's halo (into image img ^ 1) are dealt over the 3 * MT * NT groups of six MFMAs.  `requests` (the LDS-DMA / halo
-    // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right AFTER the first group
-    // of MFMAs has been issued -- in front of the first LDS reads it kept the matrix pipe idle at the start of every item.
+    // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right after the first group
+    // of MFMAs has been issued rather than in front of the item's first LDS reads.
     auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto&& requests) {
         constexpr bool FILL = decltype(fill_tag)::value;
-#ifdef X3_REQ_FIRST               // experiment: requests in front of the item's first LDS reads (the previous placement)
-        requests();
-#endif
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
         u32x4 av[2][MT][3], bv[2][NT][3];
@@ -239,13 +236,11 @@ igemm_x3_kernel(const IgemmArgs a) {
 #endif
                     X3_MFMA(0, 2); X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 1); X3_MFMA(1, 0); X3_MFMA(0, 0);
 #undef X3_MFMA
-#ifndef X3_REQ_FIRST
                     if (tp == 0 && i == 0 && j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
                         requests();
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#endif
                     if constexpr (FILL) {
                         constexpr int NGRP = 3 * MT * NT, PER = 12 / NGRP;      // 12 groups: 1 slice each; 6 groups: 2 each
                         const int grp = (tp * MT + i) * NT + j;
