@@ -39,12 +39,16 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
 
 namespace {
 
-constexpr int NTHR = 512, NWAVE = 8, MT = 2;
+#ifndef X3_NWAVE
+#define X3_NWAVE 8                 // waves per workgroup: 8 (two per SIMD, 2 pixel rows each) or 4 (one per SIMD, 4 rows each, 512 registers)
+#endif
+constexpr int NWAVE = X3_NWAVE, NTHR = 64 * NWAVE, MT = 16 / NWAVE;
 constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row tile, 612 halo pixels
 constexpr int XS_F4 = 2 * 3 * NPIX;                                // one halo image in 16-byte words: [k-octet 2][piece 3][pixel]
 constexpr int XS_BYTES = XS_F4 * 16;                               // 58752
 constexpr int WBLK = 3 * 2 * 3 * 32 * 16;                          // one filter row of one 32-channel block: [tap 3][octet 2][piece 3][32][16 B] = 9216
-constexpr int NSLOT = 3;                                           // halo staging slots per thread: 1224 (pixel, octet) pairs / 512
+constexpr int NSLOT = (2 * NPIX + NTHR - 1) / NTHR;                 // halo staging slots per thread: 1224 (pixel, octet) pairs / 512 -> 3
+constexpr int NSLICE = 4 * NSLOT;                                  // staging slices (two floats each) per chunk
 
 template <int BN> struct X3Cfg {
     static constexpr int NT = BN / 32;
@@ -79,7 +83,7 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
 }
 
 template <int BN>
-__global__ void __launch_bounds__(NTHR)
+__global__ void __launch_bounds__(NTHR, 1)
 igemm_x3_kernel(const IgemmArgs a) {
     using Cfg = X3Cfg<BN>;
     constexpr int NT = Cfg::NT;
@@ -242,10 +246,10 @@ igemm_x3_kernel(const IgemmArgs a) {
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (FILL) {
-                        constexpr int NGRP = 3 * MT * NT, PER = 12 / NGRP;      // 12 groups: 1 slice each; 6 groups: 2 each
+                        constexpr int NGRP = 3 * MT * NT;                       // the NSLICE slices are dealt evenly over the groups
                         const int grp = (tp * MT + i) * NT + j;
 #pragma unroll
-                        for (int e = 0; e < PER; ++e) stage_slice(grp * PER + e, img ^ 1);
+                        for (int q = grp * NSLICE / NGRP; q < (grp + 1) * NSLICE / NGRP; ++q) stage_slice(q, img ^ 1);
                         __builtin_amdgcn_sched_barrier(0);                    // keep the slice behind ITS group of MFMAs
                     }
                 }
@@ -350,7 +354,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     load_halo(cur, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
 #pragma unroll
-    for (int q = 0; q < 12; ++q) stage_slice(q, 0);                     // the first chunk's halo: nothing to hide it behind yet
+    for (int q = 0; q < NSLICE; ++q) stage_slice(q, 0);                 // the first chunk's halo: nothing to hide it behind yet
     if constexpr (BN == 64) {
         // two weight stages, one item ahead.  Issue order per chunk:
         //   row 0: [weights row 1][halo of the NEXT chunk]   row 1: [weights row 2]   row 2: [weights of the next chunk's row 0]

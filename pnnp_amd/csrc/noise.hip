@@ -30,42 +30,67 @@ struct Philox {
 };
 
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    // one 64-bit product per multiplier and round (v_mad_u64_u32 runs at the full VALU rate on gfx950: tools/ubench/intmul_rate.hip;
+    // written as __umulhi + * the compiler emitted v_mul_hi_u32 and v_mul_lo_u32 separately: 40 multiplies per call instead of 20)
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0; c1 = (uint32_t)p1; c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1; c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     return make_uint4(c0, c1, c2, c3);
 }
+
+// Hardware transcendentals (v_log_f32, v_exp_f32, v_sqrt_f32, v_rcp_f32: ~1 ulp) where the specification (oracle/pnnp_oracle.c, libm)
+// leaves room: a sample may differ from the oracle's by ~2e-7 relative, a Poisson count only when a uniform falls within ~1e-6 of a
+// CDF / acceptance boundary (tier A of the tests: >= 99.9 % of pixels equal to 1e-5).  cos() stays libm-accurate: its absolute
+// error is scaled by sigma * ratio into the output.  libm's logf / expf / sqrtf / IEEE division were ~60 % of the kernel's instructions.
+__device__ __forceinline__ float fast_log(float x) { return __logf(x); }
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float fast_div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
 
 // 23 random bits + 1/2 ulp: exact in fp32, in [2^-24, 1-2^-24]
 __device__ __forceinline__ float u01(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
 __device__ __forceinline__ float box_muller(uint32_t a, uint32_t b) {
     const float u1 = u01(a), u2 = u01(b);
-    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530717958647692f * u2);
+    return fast_sqrt(-2.0f * fast_log(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
 struct Ctx {
     uint32_t k0, k1, crop, off;
 };
 
+// ln(k!) for integral k >= 0: table below 10, Stirling series above (truncation < 5e-9 at k = 10; libm's lgammaf is several hundred
+// instructions behind branches and sat in the rejection path of nearly every wave).  Same operations as oracle/pnnp_oracle.c.
+__device__ __forceinline__ float log_factorial(float k) {
+    if (k < 10.f) {
+        const float LF[10] = {0.f, 0.f, 0.69314718f, 1.79175947f, 3.17805383f, 4.78749174f, 6.57925121f, 8.52516136f, 10.60460290f, 12.80182748f};
+        float v = 0.f;
+#pragma unroll
+        for (int i = 2; i < 10; ++i) v = (k == (float)i) ? LF[i] : v;
+        return v;
+    }
+    const float x = k + 1.f;
+    const float r = __builtin_amdgcn_rcpf(x);
+    return (x - 0.5f) * fast_log(x) - x + 0.91893853f + 0.083333333f * r - 0.0027777778f * (r * r * r);
+}
+
 __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
     if (!(lam > 0.f)) return 0.f;
     if (lam < 10.f) {
         const float u = u01(r0);
-        float p = expf(-lam), s = p, k = 0.f;
+        float p = fast_exp(-lam), s = p, k = 0.f;
         // the rounded CDF can saturate below the largest uniform (1 - 2^-24): stop when a term no longer moves the sum
-        while (u > s) { k += 1.f; p *= lam / k; const float s2 = s + p; if (s2 == s) break; s = s2; }
+        while (u > s) { k += 1.f; p *= fast_div(lam, k); const float s2 = s + p; if (s2 == s) break; s = s2; }
         return k;
     }
-    const float slam = sqrtf(lam), loglam = logf(lam);
+    const float slam = fast_sqrt(lam), loglam = fast_log(lam);
     const float b = 0.931f + 2.53f * slam;
     const float a = -0.059f + 0.02483f * b;
-    const float inv_alpha = 1.1239f + 1.1328f / (b - 3.4f);
-    const float vr = 0.9277f - 3.6224f / (b - 2.f);
+    const float inv_alpha = 1.1239f + fast_div(1.1328f, b - 3.4f);
+    const float vr = 0.9277f - fast_div(3.6224f, b - 2.f);
     uint32_t x0 = r0, x1 = r1;
     uint4 extra = make_uint4(0, 0, 0, 0);
     for (int it = 0; it < 64; ++it) {
@@ -75,10 +100,10 @@ __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0
         }
         const float U = u01(x0) - 0.5f, V = u01(x1);
         const float us = 0.5f - fabsf(U);
-        const float k = floorf((2.f * a / us + b) * U + lam + 0.43f);
+        const float k = floorf((fast_div(2.f * a, us) + b) * U + lam + 0.43f);
         if (us >= 0.07f && V <= vr) return k;
         if (k < 0.f || (us < 0.013f && V > us)) continue;
-        if (logf(V) + logf(inv_alpha) - logf(a / (us * us) + b) <= -lam + k * loglam - lgammaf(k + 1.f)) return k;
+        if (fast_log(V) + fast_log(inv_alpha) - fast_log(fast_div(a, us * us) + b) <= -lam + k * loglam - log_factorial(k)) return k;
     }
     return floorf(lam + 0.5f);
 }
@@ -160,15 +185,15 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
             const uint32_t elem = e0 + i;
             const uint4 r = philox4x32_10(elem, ctx.crop, 0u, off, k0, k1);
             float yy = __fmul_rn(v[i], span);
-            yy = __fdiv_rn(yy, ratio);
+            yy = fast_div(yy, ratio);
             float shot;
             if (use_p) {
-                const float lam = __fdiv_rn(__fmul_rn(mfm, yy), K);
-                shot = __fdiv_rn(__fmul_rn(poisson_f32(lam, elem, ctx, r.x, r.y), K), mfm);
+                const float lam = fast_div(__fmul_rn(mfm, yy), K);
+                shot = fast_div(__fmul_rn(poisson_f32(lam, elem, ctx, r.x, r.y), K), mfm);
             } else {
                 const float n = box_muller(r.x, r.y);
-                const float s = sqrtf(fmaxf(__fdiv_rn(yy, K), 1e-10f));
-                shot = __fadd_rn(yy, __fdiv_rn(__fmul_rn(__fmul_rn(n, s), K), mfm));
+                const float s = fast_sqrt(fmaxf(fast_div(yy, K), 1e-10f));
+                shot = __fadd_rn(yy, fast_div(__fmul_rn(__fmul_rn(n, s), K), mfm));
             }
             float acc = shot;
             if (!use_b) {
@@ -183,7 +208,7 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
                 }
                 if (use_d) acc = __fadd_rn(acc, bias);
             }
-            float z = __fdiv_rn(acc, span);
+            float z = fast_div(acc, span);
             z = fminf(fmaxf(z, lo), 1.f);
             if (!(flags & PNNP_NOISE_ORI)) z = __fmul_rn(z, ratio);
             // the trainer's clamp of the noisy input (trainer_SID.py:481-485), fused into the store
