@@ -181,6 +181,25 @@ int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgra
                                  int B, int H, int W, void* stream);
 int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int C1,
                                      const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream);
+/* pointwise layers on the bf16 matrix cores (csrc/gemm_x3.hip): ConvTranspose2d k2 s2 (archs/Unet.py:35-47), Conv2d 1x1 (ResidualBlock
+ * shortcuts, archs/modules.py:176-197), Conv2d 3x3 stride 2 (archs/modules.py:130-138); same contracts as pnnp_convt2x2_* /
+ * pnnp_conv_fwd_f32 + pnnp_conv_bwd_data_f32 with taps = 1 / pnnp_conv3x3s2_*; channel counts in multiples of 32; the weights are
+ * kind-3 packs of pnnp_x3mat_bytes(K, N) bytes (stride-2 backward-data: 9 x pnnp_x3mat_bytes(Cout, Cin)). */
+int pnnp_gemm_x3_supported(int K, int N);
+int64_t pnnp_x3mat_bytes(int K, int N);
+int pnnp_pack_jobs_add_x3_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cin, int Cout);
+int pnnp_pack_jobs_add_x3_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cout, int Cin);
+int pnnp_pack_jobs_add_x3_s2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cout, int Cin);
+int pnnp_convt2x2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, void* stream);
+int pnnp_convt2x2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
+                                  int B, int H, int W, void* stream);
+int pnnp_conv1x1_x3_fwd_f32(const float* x1, int C1, const float* x2 /*or null*/, int C2, const void* w_x3, const float* bias, const float* residual,
+                            float* y, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv1x1_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                 float* dx2 /*or null*/, int C2, const float* mask2, int mode2, int accum2, int B, int H, int W, void* stream);
+int pnnp_conv3x3s2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3s2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
+                                   int B, int H, int W, void* stream);
 /* backward-weight of the same layers (csrc/wgrad_x3.hip; pixel-major LDS images read with ds_read_b64_tr_b16): same contract
  * as pnnp_conv_bwd_weight_f32 with taps = 9; channel counts in multiples of 32; workspace from the query. */
 int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2);

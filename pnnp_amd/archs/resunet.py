@@ -84,6 +84,13 @@ class ResUnetEngine(_EngineBase):
             bwd = train and dgrad
             xf, xd = self.policy.use_x3(co, cip, t, c1)
             xd = xd and bwd
+            p1 = t == 1 and self.policy.use_x3_pointwise(ci, co) and self.policy.use_x3_pointwise(co, ci) and (c1 is None or c1 % 32 == 0)
+            if p1:                                                     # 1x1 (ResidualBlock shortcut) on the pointwise bf16x3 kernel
+                x3f = self._buf(name + ':x3f', ops.x3mat_bytes(ci, co), dev, torch.uint8)
+                x3d = self._buf(name + ':x3d', ops.x3mat_bytes(co, ci), dev, torch.uint8) if bwd else None
+                jobs.add_x3_1x1(w, x3f, x3d)
+                W[name] = (None, None); self.WU[name] = (None, None); self.WX[name] = (x3f, x3d if bwd else x3f)
+                return
             wf, wd = self._wino(co, ci, t)
             wf, wd = wf and not xf, wd and bwd and not xd
             df, dd = not (xf or wf), bwd and not (xd or wd)        # what is left for the direct fp32 kernels
@@ -107,9 +114,16 @@ class ResUnetEngine(_EngineBase):
             conv(f'b{i}_0', f'conv{i}.block.0.conv.conv.weight', c1=self.ch[9 - i] if i >= 6 else None)     # decoder: cat([up, skip])
             conv(f'b{i}_1', f'conv{i}.block.1.conv.conv.weight')
             if i >= 6:
-                conv(f'sc{i}', f'conv{i}.short_cut.0.conv.conv.weight')
+                conv(f'sc{i}', f'conv{i}.short_cut.0.conv.conv.weight', c1=self.ch[9 - i])
         for l in range(1, 5):
             w = P[f'pool{l}.conv.weight']
+            co, ci = w.shape[0], w.shape[1]
+            if self.policy.use_x3_pointwise(ci, co) and self.policy.use_x3_pointwise(co, ci):      # stride-2 conv on the pointwise bf16x3 kernel
+                f = self._buf(f'pool{l}:x3f', ops.x3mat_bytes(9 * ci, co), dev, torch.uint8)
+                d = self._buf(f'pool{l}:x3d', 9 * ops.x3mat_bytes(co, ci), dev, torch.uint8) if train else None
+                jobs.add_x3_s2(w, f, d)
+                self.WX[f'pool{l}'] = (f, d if train else f)
+                continue
             f = self._buf(f'pool{l}:f', w.numel(), dev)
             jobs.add_conv(w, f, None)
             d = None
@@ -119,6 +133,13 @@ class ResUnetEngine(_EngineBase):
             W[f'pool{l}'] = (f, d)
         for i in range(6, 10):
             w = P[f'upv{i}.weight']
+            ci, co = w.shape[0], w.shape[1]
+            if self.policy.use_x3_pointwise(ci, 4 * co) and self.policy.use_x3_pointwise(co, ci):
+                f = self._buf(f'upv{i}:x3f', ops.x3mat_bytes(ci, 4 * co), dev, torch.uint8)
+                d = self._buf(f'upv{i}:x3d', ops.x3mat_bytes(4 * co, ci), dev, torch.uint8) if train else None
+                jobs.add_x3_convt(w, f, d)
+                self.WX[f'upv{i}'] = (f, d if train else f)
+                continue
             f = self._buf(f'upv{i}:f', w.numel(), dev)
             d = self._buf(f'upv{i}:d', w.numel(), dev) if train else None
             jobs.add_convt(w, f, d)
@@ -182,18 +203,28 @@ class ResUnetEngine(_EngineBase):
             a[f't{l}'] = self._cf(f'b{l}_0', xin, None, None, g(f't{l}', shp), ch[lv], RELU)
             a[f'c{l}'] = self._cf(f'b{l}_1', a[f't{l}'], None, None, g(f'c{l}', shp), ch[lv], 0, residual=xin)
             if l < 5:
-                a[f'd{l}'] = ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
-                                             g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
+                if f'pool{l}' in self.WX:
+                    a[f'd{l}'] = ops.conv_s2_x3_fwd(a[f'c{l}'], self.WX[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
+                                                    g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
+                else:
+                    a[f'd{l}'] = ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
+                                                 g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
                 xin = a[f'd{l}']
         cur = a['c5']
         for i in range(6, 10):
             lv = 9 - i
             shp = (B, hs[lv], ws[lv], ch[lv])
-            u = ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
+            if f'upv{i}' in self.WX:
+                u = ops.convt_x3_fwd(cur, self.WX[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
+            else:
+                u = ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
             skip = a[f'c{lv + 1}']
             a[f'u{i}'] = u
             a[f't{i}'] = self._cf(f'b{i}_0', u, skip, None, g(f't{i}', shp), ch[lv], RELU)
-            sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
+            if self.WX.get(f'sc{i}', (None, None))[0] is not None:
+                sc = ops.conv1x1_x3_fwd(u, skip, self.WX[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 0)
+            else:
+                sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
             a[f'c{i}'] = self._cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
             cur = a[f'c{i}']
         o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
@@ -243,12 +274,18 @@ class ResUnetEngine(_EngineBase):
             done(f'conv{i}.block.0.conv.conv.weight')
             g_u, g_skip = gb(f'u{i}', u), gb(f'c{lv + 1}', skip)
             self._dg(f'b{i}_0', g_t, g_u, dx2=g_skip)
-            ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
+            if self.WX.get(f'sc{i}', (None, None))[0] is not None:
+                ops.conv1x1_x3_bwd_data(g, self.WX[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1)
+            else:
+                ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
             ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
-            ops.convt_bwd_data(g_u, W[f'upv{i}'][1], g)
+            if f'upv{i}' in self.WX:
+                ops.convt_x3_bwd_data(g_u, self.WX[f'upv{i}'][1], g)
+            else:
+                ops.convt_bwd_data(g_u, W[f'upv{i}'][1], g)
         for l in range(5, 0, -1):                    # encoder blocks, bottom-up; g = dL/d c_l
             lv = l - 1
             t = a[f't{l}']
@@ -273,7 +310,10 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_s2_bwd_weight(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
                 done(f'pool{l - 1}.conv.weight')
                 g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
-                ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
+                if f'pool{l - 1}' in self.WX:
+                    ops.conv_s2_x3_bwd_data(g_x, self.WX[f'pool{l - 1}'][1], g, accum=1)
+                else:
+                    ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
             else:
                 wgrad('conv_in.weight', g_x, ch[0], a['x8'], self.cin, bias='conv_in.bias')
                 done('conv_in.weight')

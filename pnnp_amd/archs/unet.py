@@ -50,6 +50,10 @@ class ConvPolicy:
             return False, False
         return (ops.wino_supported(ci, co) and ci >= self.wino_mink, ops.wino_supported(co, ci) and co >= self.wino_mink)
 
+    def use_x3_pointwise(self, K, N):
+        """a one-tap-per-segment layer (ConvTranspose2d, 1x1, stride-2 3x3) on the pointwise bf16x3 GEMM kernel (csrc/gemm_x3.hip)?"""
+        return self.x3 and ops.gemm_x3_supported(K, N)
+
     def use_x3_wgrad(self, h, w, cout, c1, c2):
         """backward-weight of a 3x3 layer on the bf16x3 kernel (csrc/wgrad_x3.hip)?"""
         return self.x3 and ops.x3_wgrad_supported(h, w, cout, c1, c2)
@@ -216,6 +220,13 @@ class UNetEngine(_EngineBase):
                 jobs.add_wino(w, buf((name, dev, 'uf'), 16 * co * ci) if wf else None, buf((name, dev, 'ud'), 16 * co * ci) if wd else None)
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
+            ci, co = w.shape[0], w.shape[1]
+            if self.policy.use_x3_pointwise(ci, 4 * co) and self.policy.use_x3_pointwise(co, ci):
+                self._x3[name] = (True, True)                      # ConvTranspose2d on the pointwise bf16x3 GEMM kernel
+                jobs.add_x3_convt(w, buf((name, dev, 'x3f'), ops.x3mat_bytes(ci, 4 * co), torch.uint8),
+                                  buf((name, dev, 'x3d'), ops.x3mat_bytes(4 * co, ci), torch.uint8) if need_dgrad else None)
+                continue
+            self._x3[name] = (False, False)
             key = (name, dev)
             if key not in self.packed:
                 self.packed[key] = (torch.empty(w.numel(), dtype=torch.float32, device=dev),
@@ -299,7 +310,10 @@ class UNetEngine(_EngineBase):
         cur = a['c5']
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
             lvl = 9 - i
-            u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
+            if self._x3.get(f'upv{i}', (False, False))[0]:
+                u = ops.convt_x3_fwd(cur, self._wx(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
+            else:
+                u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
             a[f'u{i}'] = u
             a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
@@ -372,7 +386,10 @@ class UNetEngine(_EngineBase):
                                  dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
-            ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
+            if self._x3.get(f'upv{i}', (False, False))[1]:
+                ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
+            else:
+                ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
         dx = None
         for i in range(5, 0, -1):          # encoder, bottom-up
             lvl = i - 1

@@ -4,6 +4,7 @@
 
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s);
 int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);       // csrc/conv_x3.hip (3x3, bf16x3 split)
+int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);        // csrc/gemm_x3.hip (one tap per K segment, bf16x3 split)
 
 namespace {
 
@@ -59,6 +60,52 @@ void bwd_res_args(IgemmArgs& a, const float* g, int Cout, const void* w_dgrad, f
     a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
     a.w = reinterpret_cast<const float*>(w_dgrad); a.Ntot = C1;
     a.dst[0] = dx; a.dst_cs[0] = C1; a.addsrc = addsrc; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+}
+
+void convt_fwd_args(IgemmArgs& a, const float* x, int Cin, const void* w_packed, const float* bias, float* y, int B, int H, int W, int Cout) {
+    base_args(a);
+    a.seg[0] = IgemmSeg{x, Cin, 0, 0, 0};
+    a.nseg = 1;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W;
+    a.OH = 2 * H; a.OW = 2 * W; a.out_mul = 2;
+    a.w = reinterpret_cast<const float*>(w_packed); a.Ntot = 4 * Cout; a.n_sub = Cout;       // the four sub-pixel GEMMs in one launch
+    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias;
+}
+
+void convt_bwd_args(IgemmArgs& a, const float* g, int Cout, const void* w_dgrad, float* dx, int Cin, const float* mask, int mode, int B, int H, int W) {
+    base_args(a);
+    for (int s = 0; s < 4; ++s) a.seg[s] = IgemmSeg{g, Cout, 0, s >> 1, s & 1};
+    a.nseg = 4; a.in_mul = 2;
+    a.IH = 2 * H; a.IW = 2 * W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
+    a.w = reinterpret_cast<const float*>(w_dgrad); a.Ntot = Cin;
+    a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+}
+
+void s2_fwd_args(IgemmArgs& a, const float* x, int Cin, const void* w_packed, const float* bias, float* y, int B, int H, int W, int Cout, int act) {
+    base_args(a);
+    for (int t = 0; t < 9; ++t) a.seg[t] = IgemmSeg{x, Cin, 0, t / 3 - 1, t % 3 - 1};
+    a.nseg = 9; a.in_mul = 2;
+    a.IH = H; a.IW = W; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H / 2; a.OW = W / 2;
+    a.w = reinterpret_cast<const float*>(w_packed); a.Ntot = Cout;
+    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias; a.act = act;
+}
+
+// class cls = (py, px) of the input pixel parity; returns the number of taps (K segments) that reach it
+int s2_bwd_args(IgemmArgs& a, int cls, const float* g, int Cout, float* dx, int Cin, const float* mask, int mode, int accum, int B, int H, int W) {
+    const int py = cls >> 1, px = cls & 1;
+    base_args(a);
+    int ns = 0;
+    for (int iy = 0; iy < (py ? 2 : 1); ++iy)
+        for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
+            const int dy = py ? 2 * iy : 1, dxk = px ? 2 * ix : 1;      // tap (dy, dxk)
+            a.seg[ns++] = IgemmSeg{g, Cout, 0, dy == 0 ? 1 : 0, dxk == 0 ? 1 : 0};
+        }
+    a.nseg = ns;
+    a.IH = H / 2; a.IW = W / 2; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H; a.OW = W;
+    a.out_mul = 2; a.out_yoff = py; a.out_xoff = px;
+    a.Ntot = Cin;
+    a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0; a.accum[0] = accum;
+    return ns;
 }
 
 }  // namespace
@@ -164,19 +211,78 @@ int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_
     return pnnp_igemm_x3_launch(a, Cout, as_stream(stream));
 }
 
+// ---------------------------------------------------------------- pointwise layers on the bf16 matrix cores (csrc/gemm_x3.hip)
+// Same contracts as their fp32-MFMA twins below / above; weights are the x3 packs of pnnp_pack_jobs_add_x3_convt / _1x1 / _s2;
+// channel counts in multiples of 32.
+int pnnp_gemm_x3_supported(int K, int N) { return (K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0) ? 1 : 0; }
+
+int pnnp_convt2x2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, void* stream) {
+    if (!x || !w_x3 || !y || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    convt_fwd_args(a, x, Cin, w_x3, bias, y, B, H, W, Cout);
+    return pnnp_gemm_x3_launch(a, Cin, as_stream(stream));
+}
+
+int pnnp_convt2x2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
+                                  int B, int H, int W, void* stream) {
+    if (!g || !w_x3_dgrad || !dx || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    convt_bwd_args(a, g, Cout, w_x3_dgrad, dx, Cin, mask, mode, B, H, W);
+    return pnnp_gemm_x3_launch(a, Cout, as_stream(stream));
+}
+
+int pnnp_conv1x1_x3_fwd_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias, const float* residual,
+                            float* y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_x3 || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    fwd_args(a, x1, C1, x2, C2, w_x3, bias, residual, y, B, H, W, Cout, act);
+    return pnnp_gemm_x3_launch(a, C1, as_stream(stream));
+}
+
+int pnnp_conv1x1_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx1, int C1, const float* mask1, int mode1, int accum1,
+                                 float* dx2, int C2, const float* mask2, int mode2, int accum2, int B, int H, int W, void* stream) {
+    if (!g || !w_x3_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    bwd_args(a, g, Cout, w_x3_dgrad, dx1, C1, mask1, mode1, accum1, dx2, C2, mask2, mode2, accum2, B, H, W);
+    return pnnp_gemm_x3_launch(a, Cout, as_stream(stream));
+}
+
+int pnnp_conv3x3s2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x || !w_x3 || !y || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    s2_fwd_args(a, x, Cin, w_x3, bias, y, B, H, W, Cout, act);
+    return pnnp_gemm_x3_launch(a, Cin, as_stream(stream));
+}
+
+int pnnp_conv3x3s2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
+                                   int B, int H, int W, void* stream) {
+    if (!g || !w_x3_s2dgrad || !dx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    int slice = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+        IgemmArgs a;
+        const int ns = s2_bwd_args(a, cls, g, Cout, dx, Cin, mask, mode, accum, B, H, W);
+        a.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_x3_s2dgrad) + (int64_t)slice * Cout * Cin * 6);
+        const int rc = pnnp_gemm_x3_launch(a, Cout, as_stream(stream));
+        if (rc != PNNP_OK) return rc;
+        slice += ns;
+    }
+    return PNNP_OK;
+}
+
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47
 //   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  one GEMM with N = 4*Cout (the 4 output sub-pixels).
 int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,
                           int B, int H, int W, int Cout, void* stream) {
     if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    a.seg[0] = IgemmSeg{x, Cin, 0, 0, 0};
-    a.nseg = 1;
-    a.IH = H; a.IW = W; a.B = B; a.DH = H; a.DW = W;
-    a.OH = 2 * H; a.OW = 2 * W; a.out_mul = 2;
-    a.w = w_packed; a.Ntot = 4 * Cout; a.n_sub = Cout;       // the four sub-pixel GEMMs in one launch
-    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias;
+    IgemmArgs a;
+    convt_fwd_args(a, x, Cin, w_packed, bias, y, B, H, W, Cout);
     return pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
 }
 
@@ -185,12 +291,8 @@ int pnnp_convt2x2_bwd_data_f32(const float* g, int Cout, const float* w_dgrad, f
                                const float* mask, int mode, int B, int H, int W, void* stream) {
     if (!g || !w_dgrad || !dx || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    for (int s = 0; s < 4; ++s) a.seg[s] = IgemmSeg{g, Cout, 0, s >> 1, s & 1};
-    a.nseg = 4; a.in_mul = 2;
-    a.IH = 2 * H; a.IW = 2 * W; a.B = B; a.DH = H; a.DW = W; a.OH = H; a.OW = W;
-    a.w = w_dgrad; a.Ntot = Cin;
-    a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0;
+    IgemmArgs a;
+    convt_bwd_args(a, g, Cout, w_dgrad, dx, Cin, mask, mode, B, H, W);
     return pnnp_igemm_launch(a, 1, Cout, as_stream(stream));
 }
 
@@ -202,12 +304,8 @@ int pnnp_conv3x3s2_fwd_f32(const float* x, int Cin, const float* w_packed, const
                            int B, int H, int W, int Cout, int act, void* stream) {
     if (!x || !w_packed || !y || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    IgemmArgs a; base_args(a);
-    for (int t = 0; t < 9; ++t) a.seg[t] = IgemmSeg{x, Cin, 0, t / 3 - 1, t % 3 - 1};
-    a.nseg = 9; a.in_mul = 2;
-    a.IH = H; a.IW = W; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H / 2; a.OW = W / 2;
-    a.w = w_packed; a.Ntot = Cout;
-    a.dst[0] = y; a.dst_cs[0] = Cout; a.bias = bias; a.act = act;
+    IgemmArgs a;
+    s2_fwd_args(a, x, Cin, w_packed, bias, y, B, H, W, Cout, act);
     return pnnp_igemm_launch(a, 1, Cin, as_stream(stream));
 }
 
@@ -231,19 +329,9 @@ int pnnp_conv3x3s2_bwd_data_f32(const float* g, int Cout, const float* w_s2dgrad
     if (B == 0) return PNNP_OK;
     int slice = 0;
     for (int cls = 0; cls < 4; ++cls) {
-        const int py = cls >> 1, px = cls & 1;
-        IgemmArgs a; base_args(a);
-        int ns = 0;
-        for (int iy = 0; iy < (py ? 2 : 1); ++iy)
-            for (int ix = 0; ix < (px ? 2 : 1); ++ix) {
-                const int dy = py ? 2 * iy : 1, dxk = px ? 2 * ix : 1;      // tap (dy, dxk)
-                a.seg[ns++] = IgemmSeg{g, Cout, 0, dy == 0 ? 1 : 0, dxk == 0 ? 1 : 0};
-            }
-        a.nseg = ns;
-        a.IH = H / 2; a.IW = W / 2; a.B = B; a.DH = H / 2; a.DW = W / 2; a.OH = H; a.OW = W;
-        a.out_mul = 2; a.out_yoff = py; a.out_xoff = px;
-        a.w = w_s2dgrad + (int64_t)slice * Cout * Cin; a.Ntot = Cin;
-        a.dst[0] = dx; a.dst_cs[0] = Cin; a.mask[0] = mask; a.mask_mode[0] = mask ? mode : 0; a.accum[0] = accum;
+        IgemmArgs a;
+        const int ns = s2_bwd_args(a, cls, g, Cout, dx, Cin, mask, mode, accum, B, H, W);
+        a.w = w_s2dgrad + (int64_t)slice * Cout * Cin;
         const int rc = pnnp_igemm_launch(a, 1, Cout, as_stream(stream));
         if (rc != PNNP_OK) return rc;
         slice += ns;

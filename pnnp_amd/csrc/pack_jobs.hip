@@ -5,6 +5,7 @@
 //   job kind 0: strided gather  dst[((t*(K/4)+kq)*Ndst + n_off + n)*4 + kr] = src[off + k*sk + n*sn + ts*st]  (k < Kvalid else 0)
 //   job kind 1: Winograd filter transform into the kernel's chunked order (csrc/wino.hip)
 //   job kind 2: 3x3 filters split into three bf16 pieces in the order csrc/conv_x3.hip streams them by LDS-DMA
+//   job kind 3: a strided K x N matrix (1x1 / ConvTranspose / strided-tap weights) split likewise for csrc/gemm_x3.hip
 // The builders below produce exactly the jobs the per-layer entry points used to launch (same formulas, same layouts).
 #include "common.h"
 
@@ -105,6 +106,31 @@ __device__ __forceinline__ void x3_job(const PnnpPackJob& j, int64_t blk, int nb
     }
 }
 
+// bf16x3 pack of a K x N weight matrix for csrc/gemm_x3.hip:  dst (uint16) [Ntot/32][K16tot][octet 2][piece 3][32][8]
+//   this job's sub-matrix: element (k, n), k < K, n < N  =  src[off + k*sk + n*sn], placed at row k_off + k (field `st`), column
+//   n_off + n of the whole matrix (K16tot = field T, Ntot = field Ndst).  Rows / columns no job covers must be zero-filled by the
+//   caller (the builders below cover everything).
+__device__ __forceinline__ void x3mat_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
+    const int K = j.K, N = j.N, K16 = j.T, k_off = (int)j.st;
+    const int64_t total = (int64_t)K * N;
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
+        const int kr = (int)(t & 7);                               // 8 consecutive k of one column: one 16-byte word per piece
+        int64_t r = t >> 3;
+        const int n = (int)(r % N);
+        const int k = (int)(r / N) * 8 + kr;
+        if (k >= K) continue;
+        const float v = w[j.off + (int64_t)k * j.sk + (int64_t)n * j.sn];
+        const unsigned short h = bf16_rne(v);
+        const float r1 = v - __uint_as_float((unsigned)h << 16);
+        const unsigned short m = bf16_rne(r1);
+        const unsigned short l = bf16_rne(r1 - __uint_as_float((unsigned)m << 16));
+        const int kk = k_off + k, nn = j.n_off + n;
+        unsigned short* o = u + ((((int64_t)(nn >> 5) * K16 + (kk >> 4)) * 2 + ((kk >> 3) & 1)) * 3) * 256 + (nn & 31) * 8 + (kk & 7);
+        o[0] = h; o[256] = m; o[512] = l;
+    }
+}
+
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     int j = 0;
     while (j + 1 < tb.n && (int)blockIdx.x >= tb.blk_end[j]) ++j;          // uniform: <= 32 scalar compares
@@ -113,11 +139,12 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     const PnnpPackJob& job = tb.job[j];
     if (job.kind == 1) wino_job(job, (int64_t)blockIdx.x - b0, nblk);
     else if (job.kind == 2) x3_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else if (job.kind == 3) x3mat_job(job, (int64_t)blockIdx.x - b0, nblk);
     else gather_job(job, (int64_t)blockIdx.x - b0, nblk);
 }
 
 int job_blocks(const PnnpPackJob& j) {
-    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -150,7 +177,7 @@ int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
         int blocks = 0;
         for (int i = 0; i < tb.n; ++i) {
             const PnnpPackJob& j = jobs[i0 + i];
-            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15)))) return PNNP_E_INVALID;
+            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0))) return PNNP_E_INVALID;
             tb.job[i] = j;
             blocks += job_blocks(j);
             tb.blk_end[i] = blocks;
@@ -214,6 +241,51 @@ int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, vo
     }
     return ok ? PNNP_OK : PNNP_E_WORKSPACE;
 }
+
+namespace {
+PnnpPackJob x3mat(const float* src, void* dst, int K, int N, int64_t sk, int64_t sn, int64_t off, int Ktot, int k_off, int Ntot, int n_off) {
+    PnnpPackJob j{};
+    j.src = src; j.dst = reinterpret_cast<float*>(dst); j.kind = 3; j.K = K; j.N = N; j.sk = sk; j.sn = sn; j.off = off;
+    j.T = Ktot / 16; j.st = k_off; j.Ndst = Ntot; j.n_off = n_off;
+    return j;
+}
+}  // namespace
+
+// x3 packs for the pointwise GEMM kernel (csrc/gemm_x3.hip); all channel counts in multiples of 32.  Sizes: pnnp_x3mat_bytes(K, N).
+// ConvTranspose2d weight [Cin][Cout][2][2]: fwd = [K = Cin][N = 4*Cout], column s*Cout + co; dgrad = [K = 4*Cout (row s*Cout + co)][N = Cin]
+int pnnp_pack_jobs_add_x3_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cin, int Cout) {
+    if (!jobs || !n || !w || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    bool ok = true;
+    for (int s = 0; s < 4; ++s) {
+        if (fwd) ok = ok && push(jobs, n, cap, x3mat(w, fwd, Cin, Cout, (int64_t)Cout * 4, 4, s, Cin, 0, 4 * Cout, s * Cout));
+        if (dgrad) ok = ok && push(jobs, n, cap, x3mat(w, dgrad, Cout, Cin, 4, (int64_t)Cout * 4, s, 4 * Cout, s * Cout, Cin, 0));
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+// Conv2d 1x1 weight [Cout][Cin]: fwd = [K = Cin][N = Cout], dgrad = [K = Cout][N = Cin]
+int pnnp_pack_jobs_add_x3_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin) {
+    if (!jobs || !n || !w || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    bool ok = true;
+    if (fwd) ok = ok && push(jobs, n, cap, x3mat(w, fwd, Cin, Cout, 1, Cin, 0, Cin, 0, Cout, 0));
+    if (dgrad) ok = ok && push(jobs, n, cap, x3mat(w, dgrad, Cout, Cin, Cin, 1, 0, Cout, 0, Cin, 0));
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+// Conv2d 3x3 stride 2 weight [Cout][Cin][3][3]: fwd = [K = 9*Cin (row t*Cin + ci)][N = Cout]; dgrad = 9 slices [K = Cout][N = Cin], one per
+// tap in the parity-class order of pnnp_pack_conv3x3s2_dgrad_f32, the taps of a class stacked along K (class c at the byte offset of its first slice)
+int pnnp_pack_jobs_add_x3_s2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin) {
+    if (!jobs || !n || !w || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    static const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};          // S2_TAP_ORDER of csrc/conv_api.hip: classes of 1, 2, 2, 4 taps
+    static const int first[9] = {0, 1, 1, 3, 3, 5, 5, 5, 5}, count[9] = {1, 2, 2, 2, 2, 4, 4, 4, 4};
+    bool ok = true;
+    for (int t = 0; t < 9; ++t) {
+        if (fwd) ok = ok && push(jobs, n, cap, x3mat(w, fwd, Cin, Cout, 9, (int64_t)Cin * 9, t, 9 * Cin, t * Cin, Cout, 0));
+        // backward-data: one pack per input-pixel parity class, K = (taps of the class) x Cout, the class's taps stacked along K
+        if (dgrad) ok = ok && push(jobs, n, cap, x3mat(w, reinterpret_cast<char*>(dgrad) + (int64_t)first[t] * Cout * Cin * 6, Cout, Cin, (int64_t)Cin * 9, 9,
+                                                       order[t], count[t] * Cout, (t - first[t]) * Cout, Cin, 0));
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+int64_t pnnp_x3mat_bytes(int K, int N) { return (int64_t)K * N * 6; }
 
 // bytes of one x3 pack: K (reduction channels, rounded up to 16) x N (channels written, rounded up to 32) x 9 taps x 3 pieces x 2 B
 int64_t pnnp_x3_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16 * 16) * ((N + 31) / 32 * 32) * 9 * 6; }

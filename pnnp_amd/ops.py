@@ -39,6 +39,7 @@ def _prep():
         L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3_weight_bytes.restype = C.c_int64
         L.pnnp_x3_wgrad_workspace_floats.restype = C.c_int64
+        L.pnnp_x3mat_bytes.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -87,6 +88,21 @@ class PackJobs:
         co, ci = w.shape[0], w.shape[1]
         check(_prep().pnnp_pack_jobs_add_x3(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci,
                                             cin_pad or (ci + 15) // 16 * 16), 'pack_jobs_add_x3')
+        self.keep += [w, fwd, dgrad]
+
+    def add_x3_convt(self, w, fwd, dgrad):
+        ci, co = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_x3_convt(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), ci, co), 'pack_jobs_add_x3_convt')
+        self.keep += [w, fwd, dgrad]
+
+    def add_x3_1x1(self, w, fwd, dgrad):
+        co, ci = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_x3_1x1(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci), 'pack_jobs_add_x3_1x1')
+        self.keep += [w, fwd, dgrad]
+
+    def add_x3_s2(self, w, fwd, dgrad):
+        co, ci = w.shape[0], w.shape[1]
+        check(_prep().pnnp_pack_jobs_add_x3_s2(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci), 'pack_jobs_add_x3_s2')
         self.keep += [w, fwd, dgrad]
 
     def add_s2_dgrad(self, w, dst):
@@ -159,6 +175,66 @@ def conv_x3_bwd_data_res(g, w_x3_dgrad, dx, addsrc, mask=None, mode=0):
     with _Timed('conv9_dgrad_x3', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
         check(_prep().pnnp_conv3x3_x3_bwd_data_res_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
                                                        B, H, W, stream()), 'conv_x3_bwd_data_res')
+
+
+def gemm_x3_supported(K, N):
+    return bool(_prep().pnnp_gemm_x3_supported(int(K), int(N)))
+
+
+def x3mat_bytes(K, N):
+    return int(_prep().pnnp_x3mat_bytes(int(K), int(N)))
+
+
+def convt_x3_fwd(x, w_x3, bias, y, cout):
+    require_cuda(x, w_x3, y)
+    B, H, W, Cin = x.shape
+    with _Timed('convt_fwd_x3', 8.0 * B * H * W * Cin * cout, 4.0 * B * H * W * (Cin + 4 * cout)):
+        check(_prep().pnnp_convt2x2_x3_fwd_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), B, H, W, cout, stream()), 'convt_x3_fwd')
+    return y
+
+
+def convt_x3_bwd_data(g, w_x3_dgrad, dx, mask=None, mode=0):
+    require_cuda(g, w_x3_dgrad, dx)
+    B, H, W, Cin = dx.shape
+    with _Timed('convt_dgrad_x3', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_x3_bwd_data_f32(ptr(g), g.shape[3], ptr(w_x3_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W, stream()),
+              'convt_x3_bwd_data')
+
+
+def conv1x1_x3_fwd(x1, x2, w_x3, bias, y, cout, act, residual=None):
+    require_cuda(x1, x2, w_x3, y)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv1_fwd_x3', 2.0 * B * H * W * cout * (C1 + C2), 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv1x1_x3_fwd_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_x3), ptr(bias), ptr(residual), ptr(y), B, H, W, cout, act, stream()),
+              'conv1x1_x3_fwd')
+    return y
+
+
+def conv1x1_x3_bwd_data(g, w_x3_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask2=None, mode2=0, accum2=0):
+    require_cuda(g, w_x3_dgrad, dx1)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]
+    C2 = dx2.shape[3] if dx2 is not None else 0
+    with _Timed('conv1_dgrad_x3', 2.0 * B * H * W * Cout * (C1 + C2), 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv1x1_x3_bwd_data_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx1), C1, ptr(mask1), mode1, accum1,
+                                                   ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv1x1_x3_bwd_data')
+
+
+def conv_s2_x3_fwd(x, w_x3, bias, y, cout, act=0):
+    require_cuda(x, w_x3, y)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_fwd_x3', 2.0 * B * (H // 2) * (W // 2) * cout * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_x3_fwd_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), B, H, W, cout, act, stream()), 'conv3x3s2_x3_fwd')
+    return y
+
+
+def conv_s2_x3_bwd_data(g, w_x3_s2dgrad, dx, mask=None, mode=0, accum=0):
+    require_cuda(g, w_x3_s2dgrad, dx)
+    B, H, W, Cin = dx.shape
+    with _Timed('conv9s2_dgrad_x3', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_x3_bwd_data_f32(ptr(g), g.shape[3], ptr(w_x3_s2dgrad), ptr(dx), Cin, ptr(mask), mode, accum,
+                                                     B, H, W, stream()), 'conv3x3s2_x3_bwd_data')
 
 
 def x3_wgrad_supported(H, W, cout, c1, c2=0):

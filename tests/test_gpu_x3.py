@@ -158,3 +158,70 @@ def test_x3_bwd_weight(case):
     dW2 = torch.full(w.shape, float('nan'), device='cuda')
     ops.conv_x3_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW2, None, ws)       # no bias gradient asked for
     close(dW2, w.grad, rtol=2e-4, atol=2e-5, what='x3 wgrad without dbias')
+
+
+@pytest.mark.parametrize('case', [(2, 8, 16, 64, 32), (1, 3, 35, 128, 64), (1, 2, 2, 512, 256), (1, 16, 32, 64, 32), (2, 9, 40, 256, 128), (1, 8, 64, 32, 32)])
+def test_x3_convt(case):
+    """ConvTranspose2d(k2, s2) forward and backward-data on the pointwise bf16x3 GEMM kernel vs F.conv_transpose2d."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = case
+    x = _rand(B, Ci, H, W, seed=1).requires_grad_(True)
+    w = _rand(Ci, Co, 2, 2, seed=2, scale=0.2); b = _rand(Co, seed=3)
+    y = F.conv_transpose2d(x, w, b, stride=2)
+    g = _rand(B, Co, 2 * H, 2 * W, seed=4)
+    y.backward(g)
+    jobs = ops.PackJobs()
+    f = torch.zeros(ops.x3mat_bytes(Ci, 4 * Co), dtype=torch.uint8, device='cuda'); d = torch.zeros(ops.x3mat_bytes(4 * Co, Ci), dtype=torch.uint8, device='cuda')
+    jobs.add_x3_convt(w.cuda(), f, d); jobs.run()
+    yo = torch.full((B, 2 * H, 2 * W, Co), float('nan'), device='cuda')
+    ops.convt_x3_fwd(nhwc(x.detach()).cuda(), f, b.cuda(), yo, Co)
+    close(nchw(yo), y, what=f'x3 convT fwd {case}')
+    m = _rand(B, Ci, H, W, seed=5)
+    dx = torch.full((B, H, W, Ci), float('nan'), device='cuda')
+    ops.convt_x3_bwd_data(nhwc(g).cuda(), d, dx, mask=nhwc(m).cuda(), mode=1)
+    close(nchw(dx), x.grad * torch.where(m > 0, 1.0, 0.2), what=f'x3 convT dgrad {case}')
+
+
+@pytest.mark.parametrize('case', [(2, 8, 32, 32, 32, 64), (1, 12, 40, 64, 64, 64), (1, 5, 17, 128, 128, 128), (1, 16, 33, 64, 0, 128), (2, 9, 20, 32, 0, 32)])
+def test_x3_conv1x1(case):
+    """Conv2d 1x1 (ResidualBlock shortcuts: concat inputs, accumulate into existing gradients) on the pointwise kernel."""
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    w = _rand(Co, C1 + C2, 1, 1, seed=3, scale=0.2); b = _rand(Co, seed=4)
+    xin = (torch.cat([x1, x2], 1) if C2 else x1).requires_grad_(True)
+    y = F.conv2d(xin, w, b)
+    g = _rand(B, Co, H, W, seed=5); y.backward(g)
+    jobs = ops.PackJobs()
+    f = torch.zeros(ops.x3mat_bytes(C1 + C2, Co), dtype=torch.uint8, device='cuda'); d = torch.zeros(ops.x3mat_bytes(Co, C1 + C2), dtype=torch.uint8, device='cuda')
+    jobs.add_x3_1x1(w.cuda(), f, d); jobs.run()
+    yo = torch.full((B, H, W, Co), float('nan'), device='cuda')
+    ops.conv1x1_x3_fwd(nhwc(x1).cuda(), nhwc(x2).cuda() if C2 else None, f, b.cuda(), yo, Co, 2)
+    close(nchw(yo), F.relu(y), what=f'x3 1x1 fwd {case}')
+    base1 = _rand(B, C1, H, W, seed=6); base2 = _rand(B, max(C2, 1), H, W, seed=7)
+    d1 = nhwc(base1).cuda().clone(); d2 = nhwc(base2).cuda().clone() if C2 else None
+    ops.conv1x1_x3_bwd_data(nhwc(g).cuda(), d, d1, accum1=1, dx2=d2, accum2=1)
+    close(nchw(d1), base1 + xin.grad[:, :C1], what='x3 1x1 dgrad accum')
+    if C2:
+        close(nchw(d2), base2 + xin.grad[:, C1:], what='x3 1x1 dgrad2 accum')
+
+
+@pytest.mark.parametrize('case', [(2, 16, 64, 32, 64), (1, 12, 40, 64, 128), (1, 6, 70, 128, 256), (1, 4, 4, 256, 512), (1, 34, 66, 32, 32)])
+def test_x3_conv3x3_stride2(case):
+    """ResUnet's down-sampling conv (archs/modules.py:130-138) forward and backward-data on the pointwise kernel."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = case
+    x = _rand(B, Ci, H, W, seed=1).requires_grad_(True)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=0.2); b = _rand(Co, seed=3)
+    y = F.conv2d(x, w, b, stride=2, padding=1)
+    g = _rand(B, Co, H // 2, W // 2, seed=4); y.backward(g)
+    jobs = ops.PackJobs()
+    f = torch.zeros(ops.x3mat_bytes(9 * Ci, Co), dtype=torch.uint8, device='cuda'); d = torch.zeros(9 * ops.x3mat_bytes(Co, Ci), dtype=torch.uint8, device='cuda')
+    jobs.add_x3_s2(w.cuda(), f, d); jobs.run()
+    yo = torch.full((B, H // 2, W // 2, Co), float('nan'), device='cuda')
+    ops.conv_s2_x3_fwd(nhwc(x.detach()).cuda(), f, b.cuda(), yo, Co)
+    close(nchw(yo), y, what=f'x3 s2 fwd {case}')
+    base = _rand(B, Ci, H, W, seed=6)
+    dx = nhwc(base).cuda().clone()
+    ops.conv_s2_x3_bwd_data(nhwc(g).cuda(), d, dx, accum=1)
+    close(nchw(dx), base + x.grad, what=f'x3 s2 dgrad {case}')
