@@ -179,6 +179,9 @@ igemm_x3_kernel(const IgemmArgs a) {
     // bytes of the pack, as 1 KB pieces dealt over the 8 waves
     const int K16 = nchunks;
     auto dma_weights = [&](const Tile& tl, int g, int tr, int st, bool valid = true) {
+#ifdef X3_SKIP_DMA                // timing experiment only (wrong results): weights are never refreshed
+        if (g + tr > 0) valid = false;
+#endif
 #pragma unroll
         for (int i = 0; i < (Cfg::NDMA + NWAVE - 1) / NWAVE; ++i) {
             // wave-uniform piece; past the end a wave repeats the last piece (same bytes to the same place) instead of branching
