@@ -324,6 +324,11 @@ int pnnp_nf_train_bwd_pair_f32(const float* x, const float* clean /*or null*/, c
                                const float* bn, const float* h1, const float* h2, const float* out3, const float* dz, float dzmul,
                                float cobj, float* dx, float* sums, float* dy2, float* dy1, float* dv23, float* part, int B, int H,
                                int W, void* stream);
+/* batch statistics of a coupling's two BatchNorm layers for training-mode SAMPLING (trainer_LRID.py:34-39,420-427: the proxy is
+ * sampled without .eval()): u [B][4][H][W] feeds the coupling network with its first two planes; ident = device 4x4 identity;
+ * bn [24] as above; h1, h2 scratch [B][4][H][W]; part scratch max(tiles, pblocks) * 8 floats. */
+int pnnp_nf_train_stats_f32(const float* u, const float* ident, const float* prm, float* bn, float* h1, float* h2, float* part,
+                            int B, int H, int W, void* stream);
 
 /* SNA_torch (data_process/process.py:562-588): shot-noise augmentation under a white-balance gain change.
  * gt [C][H][W] -> dn (the extra Poisson noise, / (wp-bl), x ratio unless ori) and dy (the signal change); aug_wb4 is a

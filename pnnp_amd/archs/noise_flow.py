@@ -416,7 +416,9 @@ class NoiseFlow(nn.Module):
 
     def sample(self, **kwargs):
         """noise_flow.py:173-188.  kwargs: clean [B,4,H,W] (CUDA), iso (scalar / 0-dim tensor);
-        optional ``z`` injects the prior draw (else N(0,1) from the counter-based generator)."""
+        optional ``z`` injects the prior draw (else N(0,1) from the counter-based generator).
+        In TRAINING mode (trainer_LRID.py:34-39 never calls .eval() on the proxy it samples from, :420-427) the BatchNorm layers
+        of every coupling use the statistics of the batch being sampled and move their running buffers, as nn.BatchNorm2d does."""
         clean = kwargs['clean'] if 'clean' in kwargs else kwargs['noise']
         _lib.require_cuda(clean)
         clean = clean.contiguous().float()
@@ -432,7 +434,35 @@ class NoiseFlow(nn.Module):
         else:
             z = z.contiguous().float().clone()       # the ping-pong below overwrites its buffers
         cur, nxt = z, torch.empty_like(clean)
-        for vec, winv, g_after, s_after, host in self._tables():
+        train = self.training
+        if train:
+            tiles, pb = L.pnnp_nf_train_tiles(B, H, W), L.pnnp_nf_train_pblocks(B, H, W)
+            f32 = dict(dtype=torch.float32, device=clean.device)
+            ident = torch.eye(4, **f32).reshape(-1).contiguous()
+            h1 = torch.empty((B, 4, H, W), **f32); h2 = torch.empty_like(h1)
+            part = torch.empty(max(tiles, pb) * 8, **f32); bn = torch.empty(24, **f32)
+            n = float(B * H * W)
+        for (vec, winv, g_after, s_after, host), (ac, _cv, _g, _s) in zip(self._tables(), self._plan()):
+            if train:
+                # batch statistics of this coupling's hidden maps for the tensor it is about to transform (its first two planes are
+                # the coupling network's input in both directions), folded into the BatchNorm scale / offset slots of the step table
+                sl = ac._shift_and_log_scale
+                prm = torch.cat([t.detach().reshape(-1) for t in _coupling_params(ac)]).contiguous()
+                _lib.check(L.pnnp_nf_train_stats_f32(_lib.ptr(cur), _lib.ptr(ident), _lib.ptr(prm), _lib.ptr(bn), _lib.ptr(h1), _lib.ptr(h2),
+                                                     _lib.ptr(part), B, H, W, _lib.stream()), 'nf_train_stats')
+                st = bn.cpu().numpy().astype(np.float64)                  # [mean1, rstd1, var1, mean2, rstd2, var2] x 4 (bias-free means)
+                vec = vec.copy()
+                for li, (bnm, conv, so, oo) in enumerate(((sl.net[1], sl.conv2d_1, 76, 80), (sl.net[4], sl.conv2d_2, 104, 108))):
+                    gam = bnm.weight.detach().cpu().numpy().astype(np.float64); bet = bnm.bias.detach().cpu().numpy().astype(np.float64)
+                    cb = conv.bias.detach().cpu().numpy().astype(np.float64)
+                    mean, rstd, var = st[12 * li:12 * li + 4], st[12 * li + 4:12 * li + 8], st[12 * li + 8:12 * li + 12]
+                    sc = gam * rstd
+                    vec[so:so + 4] = sc.astype(np.float32)
+                    vec[oo:oo + 4] = (bet - (mean + cb) * sc).astype(np.float32)     # the step kernel adds the conv bias: cancel it as the batch mean does
+                    with torch.no_grad():                                  # nn.BatchNorm2d buffers: momentum 0.1, unbiased variance
+                        bnm.running_mean.mul_(0.9).add_(torch.from_numpy((0.1 * (mean + cb)).astype(np.float32)).to(bnm.running_mean.device))
+                        bnm.running_var.mul_(0.9).add_(torch.from_numpy((0.1 * var * n / max(n - 1.0, 1.0)).astype(np.float32)).to(bnm.running_var.device))
+                        bnm.num_batches_tracked += 1
             w = winv.copy()
             if g_after is not None:        # gain.py:79-86: x * exp(cam*gain_params) * iso  (scalar: folded into W^-1)
                 w *= np.float32(np.exp(_interp(host['g_cam'], iso) * host['g_gain']) * np.float32(iso))

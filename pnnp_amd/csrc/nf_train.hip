@@ -504,6 +504,26 @@ int pnnp_nf_train_fwd_pair_f32(const float* x, const float* clean, const float* 
     return pnnp_launch_status();
 }
 
+// Batch statistics of a coupling's two BatchNorm layers for a tensor u whose first two planes feed the coupling network directly
+// (training-mode SAMPLING, trainer_LRID.py:34-39,420-427: the proxy is never put in eval mode): h1 = conv2d_1(u[0:2]) -> bn[0:12],
+// h2 = conv2d_2(relu(BN1(h1))) -> bn[12:24].  `ident`: device [16] floats, the 4x4 identity (the Conv2d1x1 of the pair acts AFTER
+// the coupling in this direction).  h1, h2: scratch [B][4][H][W]; part: max(tiles, pblocks) * 8 floats.
+int pnnp_nf_train_stats_f32(const float* u, const float* ident, const float* prm, float* bn, float* h1, float* h2, float* part,
+                            int B, int H, int W, void* stream) {
+    if (bad_shape(B, H, W) || !u || !ident || !prm || !bn || !h1 || !h2 || !part) return PNNP_E_INVALID;
+    hipStream_t st = as_stream(stream);
+    const PairIn p{u, nullptr, nullptr, ident, prm, bn, H, W};
+    const dim3 grid = tile_grid(B, H, W);
+    const int tiles = pnnp_nf_train_tiles(B, H, W), pb = pnnp_nf_train_pblocks(B, H, W);
+    const int64_t plane = (int64_t)H * W, npix = (int64_t)B * plane;
+    const double inv_n = 1.0 / (double)npix;
+    hipLaunchKernelGGL(nf_tr_conv1_kernel, grid, dim3(256), 0, st, p, h1, part);
+    hipLaunchKernelGGL(nf_tr_bnstat_kernel, dim3(1), dim3(1024), 0, st, part, tiles, inv_n, bn);
+    hipLaunchKernelGGL(nf_tr_conv2_kernel, dim3(pb), dim3(256), 0, st, h1, prm, bn, h2, part, plane, npix);
+    hipLaunchKernelGGL(nf_tr_bnstat_kernel, dim3(1), dim3(1024), 0, st, part, pb, inv_n, bn + 12);
+    return pnnp_launch_status();
+}
+
 // Backward of one pair.  dz: gradient of the pair's output (multiplied by dzmul); cobj = dL/d(objective).  Outputs: dx
 // [B][4][H][W]; sums [319] = dW3[180] db3[4] dlogs[4] dscale[1] dBE2[4] dG2[4] | dW2[16] db2[4] dBE1[4] dG1[4] |
 // dW1[72] db1[4] dWm[16] da db.  Scratch: dy [B][4][H][W] x2 (dy2, dy1), dv23 [B][2][H][W], part: max(tiles*197, pblocks*28) floats.

@@ -30,8 +30,10 @@ PROXY_DATASETS = ('NF_Syn_Dataset', 'IMX686_NF_Syn_Dataset')      # trainer_SID.
 def build_proxy(cfg, device='cuda'):
     """`arch_proxy` of a run file -> the NoiseFlow proxy the train step samples from (trainer_SID.py:33-42,
     trainer_LRID.py:33-39): built by name, weights from `<fast_ckpt>/<camera>_NoiseFlow_last_model.pth` when that file exists
-    (by_name as trainer_SID does; the checkpoints are not distributed with the reference, so a missing file leaves the
-    random-initialised flow and says so), then ``.eval()`` as trainer_SID.py:42 does.  Returns None when the run file has no proxy."""
+    (the checkpoints are not distributed with the reference, so a missing file leaves the random-initialised flow and says so).
+    The two trainers differ and both are kept: trainer_SID loads by_name=True and calls ``.eval()`` (:41-42); trainer_LRID loads
+    by_name=False and never calls ``.eval()`` (:37-39), so its proxy samples with BatchNorm on BATCH statistics (NoiseFlow.sample
+    in training mode).  Returns None when the run file has no proxy."""
     proxy = cfg.get('arch_proxy')
     if not proxy or cfg.get('mode', 'train') != 'train':
         return None
@@ -41,11 +43,13 @@ def build_proxy(cfg, device='cuda'):
     net = cls(proxy)
     dst = cfg.get('dst_train', cfg.get('dst'))
     path = os.path.join(str(cfg.get('fast_ckpt', '')), f"{dst['camera_type']}_NoiseFlow_last_model.pth")
+    lrid = dst.get('dataset') == 'IMX686_NF_Syn_Dataset'
     if os.path.exists(path):
-        net = load_weights(net, torch.load(path, map_location='cpu'), by_name=True)
+        net = load_weights(net, torch.load(path, map_location='cpu'), by_name=not lrid)
     else:
         print(f'No checkpoint file!!!  ({path}: the {proxy["name"]} proxy keeps its initial weights)', flush=True)
-    return net.to(device).eval()
+    net = net.to(device)
+    return net.train() if lrid else net.eval()
 
 
 def load(path):

@@ -462,6 +462,26 @@ def gen_noiseflow():
         for k, v in net.state_dict().items():
             if 'running_' in k or 'num_batches' in k:
                 out[f'tr_buf_iso{iso}:' + k] = v.numpy().copy()
+    # training-mode SAMPLING: trainer_LRID.py:34-39 builds the proxy and never calls .eval() on it, so `proxy_net.sample` (:420-427)
+    # runs its BatchNorm layers on BATCH statistics (and moves the running buffers).  Same injected prior draw mechanism.
+    z3 = torch.randn(3, 4, 32, 32, generator=g)
+    out['ts_z'] = z3.numpy()
+    def fixed3(mean, logsd):
+        o = orig(mean, logsd)
+        o.eps = z3
+        o.sample = mean + torch.exp(logsd) * z3
+        return o
+    NFm.gaussian_diag = fixed3
+    for iso in (1600, 3000):
+        net.load_state_dict({k: torch.from_numpy(out['sd:' + k]) for k in out['keys']})
+        net.train()
+        with torch.no_grad():
+            x = net.sample(clean=clean3, iso=torch.tensor(float(iso)))
+        out[f'ts_out_iso{iso}'] = x.numpy()
+        for k, v in net.state_dict().items():
+            if 'running_' in k or 'num_batches' in k:
+                out[f'ts_buf_iso{iso}:' + k] = v.numpy().copy()
+    NFm.gaussian_diag = orig
     net.eval()
     np.savez_compressed(os.path.join(HERE, 'noiseflow.npz'), **out)
 

@@ -251,3 +251,24 @@ def test_train_pair_c_abi_rejects_bad_arguments():
     bad = L.pnnp_nf_train_fwd_pair_f32(p, nul, nul, p, p, p, p, p, p, p, _lib.ptr(z), p, 1, 32, 32, _lib.stream())   # z aliases x
     assert bad != 0
     assert L.pnnp_nf_train_tiles(3, 33, 64) == 3 * 2 * 2 and L.pnnp_nf_train_pblocks(1, 32, 33) == 2
+
+
+def test_train_mode_sampling_uses_batch_statistics_like_the_lrid_trainer(golden_dir):
+    """trainer_LRID.py:34-39 never calls .eval() on the proxy it samples from (:420-427): every BatchNorm of the couplings
+    normalises with the statistics of the batch being sampled and moves its running buffers.  Golden: the reference in
+    train() mode with an injected prior draw (2 ISOs): sample within the chained-coupling bar, buffers rtol 2e-5."""
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    clean = torch.from_numpy(g['tr_clean']).cuda(); z = torch.from_numpy(g['ts_z']).cuda()
+    for iso in (1600, 3000):
+        net = _net(g).train()
+        x = net.sample(clean=clean, iso=float(iso), z=z)
+        _close_chain(x.cpu().numpy(), g[f'ts_out_iso{iso}'])
+        sd = net.state_dict()
+        for k in sd:
+            if 'running_' in k:
+                np.testing.assert_allclose(sd[k].cpu().numpy(), g[f'ts_buf_iso{iso}:' + k], rtol=2e-5, atol=1e-7, err_msg=k)
+            elif 'num_batches' in k:
+                assert int(sd[k]) == int(g[f'ts_buf_iso{iso}:' + k]), k
+        # and it is not the eval-mode result
+        xe = _net(g).sample(clean=clean, iso=float(iso), z=z)
+        assert float((xe - x).abs().max()) > 1e-3 * float(x.abs().max())

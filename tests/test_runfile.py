@@ -68,7 +68,9 @@ def test_arch_proxy_runfile_trains_on_noiseflow_samples(capsys, monkeypatch):
     cfg = runfile.load(rf)
     np.random.seed(0); torch.manual_seed(0)
     net, step, lr_of, sh = runfile.build(cfg)
-    assert isinstance(step.proxy_net, archs.NoiseFlow) and not step.proxy_net.training          # .eval() (trainer_SID.py:42)
+    assert isinstance(step.proxy_net, archs.NoiseFlow) and step.proxy_net.training             # trainer_LRID.py:37-39 never calls .eval()
+    cfg_sid = runfile.load(rf); cfg_sid['dst_train']['dataset'] = 'NF_Syn_Dataset'
+    assert not runfile.build_proxy(cfg_sid).training                                           # trainer_SID.py:42 does
     assert step.proxy_ratio_choices == (1, 2, 4, 8, 16)
     calls = []
     real = step.proxy_net.sample

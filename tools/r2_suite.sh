@@ -1,14 +1,17 @@
 #!/bin/bash
 # Round-2 GPU suite (run on the GPU box from the repo root):  bash tools/r2_suite.sh <tag> <commit>
-# tests, bench line, rocprofv3 kernel stats of the same command, PMC traffic passes, config-5 line + stats, RCCL overlap trace.
+# tests, bench line, rocprofv3 kernel stats of the same command, PMC traffic passes, config-5 line + stats, fp32-MFMA family line,
+# HBM-bound kernel table, eval forward.
 TAG=${1:-a}; COMMIT=${2:-unknown}
 OUT=/root/repo/gpurun_out/r2$TAG; mkdir -p $OUT
 cd /root/repo
 python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
 if [ -z "$SKIP_TESTS" ]; then
-timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -25 > $OUT/pytest.log
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $OUT/pytest.log
+timeout 300 python -m pytest tests/test_gpu_x3.py tests/test_gpu_fullsize.py -q -m gpu -s -k "accurate or golden" 2>&1 | grep -i "relative L2\|worst HIP" > $OUT/accuracy.log
 fi
 timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --family wino --no-cpu-baseline > $OUT/bench_family_wino.json 2> /dev/null
 export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/rp_*
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_b -o b --output-format csv -- python3 /root/repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_bench.err
 cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
@@ -18,11 +21,15 @@ timeout 600 python bench.py --arch resunet --noise noiseflow --batch 12 --steps 
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_c5 -o c --output-format csv -- python3 /root/repo/bench.py --arch resunet --noise noiseflow --batch 12 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_config5_under_rocprof.json 2> /dev/null
 cp $(find /tmp/rp_c5 -name "*kernel_stats.csv" | head -1) $OUT/bench_config5_kernel_stats.csv
-# RCCL kernels on the side stream vs the backward pass (1-rank group, forced reducer)
-timeout 600 rocprofv3 --kernel-trace -d /tmp/rp_r -o r --output-format csv -- python3 /root/repo/bench.py --force-reducer --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > $OUT/bench_force_reducer.json 2> $OUT/rocprof_reducer.err
+# HBM-bound kernels under rocprofv3, eval forward
 cd /root/repo
-python tools/overlap_from_trace.py $(find /tmp/rp_r -name "*kernel_trace.csv" | head -1) $OUT/rccl_overlap.json > $OUT/rccl_overlap.txt 2>&1
+timeout 900 bash tools/aux_prof.sh > $OUT/aux.log 2>&1
+cp gpurun_out/aux_kernels.json gpurun_out/aux_kernel_stats.csv $OUT/ 2>/dev/null
+timeout 300 python tools/eval_bench.py > $OUT/eval_bench.txt 2>&1
 # HBM traffic of the conv kernels (two --pmc passes)
 timeout 900 bash tools/pmc_traffic.sh $COMMIT > $OUT/pmc.log 2>&1
 cp gpurun_out/traffic.json gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv $OUT/ 2>/dev/null
+# matrix-pipe utilisation per layer (PMC)
+timeout 600 bash tools/pmc_layers.sh util 'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY' --x3 --only fwd,dgrad,wgrad --reps 2 > /dev/null 2>&1
+cp gpurun_out/pmc_layers_util.csv $OUT/ 2>/dev/null
 ls -la $OUT
