@@ -261,6 +261,26 @@ int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int
 int pnnp_maxpool2_fwd_codes_f32(const float* x, float* y, unsigned char* codes /*[B][H/2][W/2][C]*/, int B, int H, int W, int C, void* stream);
 int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
                                 int accumulate, void* stream);
+/* ---------------------------------------------------------------- the thin ends of the networks (csrc/thin.hip)
+ * The 1x1 head conv10_1 (archs/Unet.py:80,93: nf -> out_nc, no activation) and the first 3x3 convolution's weight gradient
+ * (archs/Unet.py:31 conv1_1, in_nc -> nf).  With 4 channels on one side these are HBM streams over the full-resolution
+ * nf-channel map, done in float32 on the vector ALUs; weights are read in the torch layout (no packed copy).
+ *   head forward:  out NCHW [B][cout][H][W] = bias + x W^T (+ residual NCHW)   -- replaces the 1x1 GEMM + pnnp_nhwc_to_nchw_f32
+ *   head backward: gx = (g W) * act'(x) [mode 0 none / 1 LeakyReLU(0.2) / 2 ReLU; x is the activation output],
+ *                  dW [cout][cin] and dbias [cout] (+)= in the same pass over x and g (g: first cout of gcs >= 4 channels)
+ *   first backward-weight: dW [cout][cin][3][3], dbias (+)=; x [B][H][W][xcs] must be ZERO in channels cin .. 3.
+ * *_supported() say whether these kernels take the layer (else use pnnp_conv_* with taps 1 / 9); ws >= *_workspace_floats(). */
+int pnnp_head_supported(int cin, int cout, int64_t npix);
+int64_t pnnp_head_bwd_workspace_floats(int cin);
+int pnnp_head_fwd_f32(const float* x, int xcs, int cin, const float* w /*[cout][cin]*/, const float* bias, const float* residual /*or null*/,
+                      float* out, int B, int H, int W, int cout, void* stream);
+int pnnp_head_bwd_f32(const float* g, int gcs, const float* x, int xcs, int cin, const float* w, float* gx, int gxcs, int mode,
+                      float* dW, float* dbias /*or null*/, int B, int H, int W, int cout, int accumulate, float* ws, int64_t ws_floats,
+                      void* stream);
+int pnnp_first_wgrad_supported(int cin, int cout, int H, int W);
+int64_t pnnp_first_wgrad_workspace_floats(int cout);
+int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x, int xcs, int cin, float* dW, float* dbias /*or null*/,
+                              int B, int H, int W, int accumulate, float* ws, int64_t ws_floats, void* stream);
 /* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);
  * the NCHW result can add a residual (arch 'res' flag, archs/Unet.py:95-98). */
 int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);

@@ -227,9 +227,12 @@ class ResUnetEngine(_EngineBase):
                 sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
             a[f'c{i}'] = self._cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
             cur = a[f'c{i}']
-        o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
-        ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
+        if self.policy.use_thin_head(ch[0], self.cout, B * H * Wd):
+            ops.head_fwd(a['c9'], P['conv10.weight'], P['conv10.bias'], out, residual=x if self.m.res else None)
+        else:
+            o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
+            ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
             self.saved = (a, (B, H, Wd, dev), gen)
         return out
@@ -259,10 +262,13 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
 
         # head
-        wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
-        done('conv10.weight')
         g = gb('c9', a['c9'])
-        ops.conv_bwd_data(g_out8, W['conv10'][1], g, taps=1)
+        if self.policy.use_thin_head(ch[0], self.cout, B * H * Wd):
+            ops.head_bwd(g_out8, a['c9'], P['conv10.weight'], g, G('conv10.weight'), G('conv10.bias'), wsf, mode=0, accumulate=acc)
+        else:
+            wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
+            ops.conv_bwd_data(g_out8, W['conv10'][1], g, taps=1)
+        done('conv10.weight')
         for i in range(9, 5, -1):                    # decoder blocks, top-down
             lv = 9 - i
             u, skip, t = a[f'u{i}'], a[f'c{lv + 1}'], a[f't{i}']
@@ -315,7 +321,10 @@ class ResUnetEngine(_EngineBase):
                 else:
                     ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
             else:
-                wgrad('conv_in.weight', g_x, ch[0], a['x8'], self.cin, bias='conv_in.bias')
+                if self.policy.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
+                    ops.first_bwd_weight(g_x, ch[0], a['x8'], self.cin, G('conv_in.weight'), G('conv_in.bias'), wsf, accumulate=acc)
+                else:
+                    wgrad('conv_in.weight', g_x, ch[0], a['x8'], self.cin, bias='conv_in.bias')
                 done('conv_in.weight')
         if need_dx:
             raise PnnpError('gradient w.r.t. the network input is not implemented on the HIP path')
@@ -333,6 +342,7 @@ class ResUnetEngine(_EngineBase):
             if lv < 4:
                 need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 4),
                            ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 18))
+        need = max(need, ops.head_bwd_workspace_floats(ch[0]), ops.first_wgrad_workspace_floats(ch[0]))
         return max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
 
 

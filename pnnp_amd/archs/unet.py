@@ -27,14 +27,21 @@ class ConvPolicy:
     ``wino``: Winograd F(2x2,3x3) on the fp32 matrix cores for forward / backward-data where x3 is off and the layer
     qualifies (channels written % 64 == 0, reduction >= ``wino_mink`` channels), ``wino_wgrad``: the Winograd
     backward-weight kernel likewise; everything else (and everything when all are off) uses the direct fp32 implicit-GEMM
-    kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
+    kernels.  ``thin``: the 4-channel ends -- the 1x1 head and the first layer's backward-weight -- on the streaming vector-ALU
+    kernels of csrc/thin.hip instead of the channel-padded GEMM kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
     families against each other at full size)."""
 
-    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True):
-        self.wino, self.wino_wgrad, self.wino_mink, self.x3 = bool(wino), bool(wino_wgrad), int(wino_mink), bool(x3)
+    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True, thin=True):
+        self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin = bool(wino), bool(wino_wgrad), int(wino_mink), bool(x3), bool(thin)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin)
+
+    def use_thin_head(self, cin, cout, npix):
+        return self.thin and ops.head_supported(cin, cout, npix)
+
+    def use_thin_first(self, cin, cout, h, w, x_cs):
+        return self.thin and x_cs >= 4 and ops.first_wgrad_supported(cin, cout, h, w)
 
     def use_x3(self, co, ci, taps=9, c1=None):
         """(forward, backward-data) of a 3x3 Conv2d(ci -> co) on the bf16x3 kernel?  ``c1``: channels of the first of two
@@ -80,7 +87,8 @@ class _EngineBase:
     def set_policy(self, policy=None, **kw):
         """``set_policy(x3=False)`` etc.: fields not named keep their current value."""
         if policy is None:
-            cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3)
+            cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
+                       thin=self.policy.thin)
             cur.update(kw)
             policy = ConvPolicy(**cur)
         self.policy = policy
@@ -318,9 +326,12 @@ class UNetEngine(_EngineBase):
             a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             cur = a[f'c{i}']
-        o = conv('conv10_1', a['c9'], None, H, W, self.cout, act=0, taps=1, out=g('o', (B, H, W, self.cout)))
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=dev)
-        ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
+        if self.policy.use_thin_head(ch[0], self.cout, B * H * W):
+            ops.head_fwd(a['c9'], P['conv10_1.weight'], P['conv10_1.bias'], out, residual=x if self.m.res else None)
+        else:
+            o = conv('conv10_1', a['c9'], None, H, W, self.cout, act=0, taps=1, out=g('o', (B, H, W, self.cout)))
+            ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
             self.saved = (a, (B, H, W, dev), gen)
         return out
@@ -368,9 +379,14 @@ class UNetEngine(_EngineBase):
             done(name)
 
         # conv10_1 (1x1, no activation); its input c9 is a LeakyReLU output
-        wgrad('conv10_1', g_out8, self.cout, a['c9'], ch[0], taps=1)
         g_cur = gb('c9', a['c9'].shape)
-        ops.conv_bwd_data(g_out8, self._w('conv10_1')[1], g_cur, mask1=a['c9'], mode1=LRELU, taps=1)
+        if self.policy.use_thin_head(ch[0], self.cout, B * H * W):
+            ops.head_bwd(g_out8, a['c9'], P['conv10_1.weight'], g_cur, G('conv10_1.weight', P['conv10_1.weight'].shape),
+                         G('conv10_1.bias', (self.cout,)), wsf, mode=LRELU, accumulate=acc)
+            done('conv10_1')
+        else:
+            wgrad('conv10_1', g_out8, self.cout, a['c9'], ch[0], taps=1)
+            ops.conv_bwd_data(g_out8, self._w('conv10_1')[1], g_cur, mask1=a['c9'], mode1=LRELU, taps=1)
         for i in range(9, 5, -1):          # decoder, top-down
             lvl = 9 - i
             wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
@@ -404,7 +420,12 @@ class UNetEngine(_EngineBase):
                 g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
                 ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1, codes=a.get(f'pc{i - 1}'))
             else:
-                wgrad('conv1_1', g_a, ch[0], a['x8'], self.cin)
+                if self.policy.use_thin_first(self.cin, ch[0], H, W, a['x8'].shape[3]):
+                    ops.first_bwd_weight(g_a, ch[0], a['x8'], self.cin, G('conv1_1.weight', P['conv1_1.weight'].shape),
+                                         G('conv1_1.bias', (ch[0],)), wsf, accumulate=acc)
+                    done('conv1_1')
+                else:
+                    wgrad('conv1_1', g_a, ch[0], a['x8'], self.cin)
                 if need_dx:
                     raise PnnpError('gradient w.r.t. the network input is not implemented on the HIP path')
         return dx
@@ -424,6 +445,7 @@ class UNetEngine(_EngineBase):
             if lvl < 4:
                 need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lvl + 1], c, 4))
         need = max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
+        need = max(need, ops.head_bwd_workspace_floats(ch[0]), ops.first_wgrad_workspace_floats(ch[0]))
         return need
 
 

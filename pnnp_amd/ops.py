@@ -40,6 +40,8 @@ def _prep():
         L.pnnp_x3_weight_bytes.restype = C.c_int64
         L.pnnp_x3_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3mat_bytes.restype = C.c_int64
+        L.pnnp_head_bwd_workspace_floats.restype = C.c_int64
+        L.pnnp_first_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
     return L
 
@@ -393,6 +395,53 @@ def conv_s2_bwd_weight(g, x, dW, dbias, ws, accumulate=0):
     with _Timed('conv9s2_wgrad', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
         check(_prep().pnnp_conv3x3s2_bwd_weight_f32(ptr(g), g.shape[3], ptr(x), Cin, ptr(dW), ptr(dbias), B, H, W, accumulate,
                                                     ptr(ws), _i64(ws.numel()), stream()), 'conv3x3s2_bwd_weight')
+
+
+# ---- the thin ends of the networks (csrc/thin.hip): the 1x1 head and the first layer's backward-weight
+def head_supported(cin, cout, npix):
+    return bool(_prep().pnnp_head_supported(int(cin), int(cout), _i64(npix)))
+
+
+def head_bwd_workspace_floats(cin):
+    return int(_prep().pnnp_head_bwd_workspace_floats(int(cin)))
+
+
+def head_fwd(x, weight, bias, out, residual=None):
+    """out NCHW [B,cout,H,W] = conv1x1(x NHWC [B,H,W,>=cin]; weight [cout,cin,1,1], bias) (+ residual NCHW)."""
+    require_cuda(x, weight, bias, out)
+    B, H, W, xcs = x.shape
+    cout, cin = weight.shape[0], weight.shape[1]
+    with _Timed('head_fwd', 2.0 * B * H * W * cin * cout, 4.0 * B * H * W * (cin + cout)):
+        check(_prep().pnnp_head_fwd_f32(ptr(x), xcs, cin, ptr(weight), ptr(bias), ptr(residual), ptr(out), B, H, W, cout, stream()), 'head_fwd')
+    return out
+
+
+def head_bwd(g, x, weight, gx, dW, dbias, ws, mode=0, accumulate=0):
+    """Backward of the 1x1 head in one pass: gx [B,H,W,>=cin] = (g W) * act'(x), dW [cout,cin,1,1] and dbias (+)=.
+    g [B,H,W,gcs>=4] (first cout channels), x [B,H,W,>=cin] the head's input (an activation output when mode != 0)."""
+    require_cuda(g, x, weight, gx, dW, ws)
+    B, H, W, gcs = g.shape
+    cout, cin = weight.shape[0], weight.shape[1]
+    with _Timed('head_bwd', 4.0 * B * H * W * cin * cout, 4.0 * B * H * W * (2 * cin + cout)):
+        check(_prep().pnnp_head_bwd_f32(ptr(g), gcs, ptr(x), x.shape[3], cin, ptr(weight), ptr(gx), gx.shape[3], mode, ptr(dW), ptr(dbias),
+                                        B, H, W, cout, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'head_bwd')
+
+
+def first_wgrad_supported(cin, cout, H, W):
+    return bool(_prep().pnnp_first_wgrad_supported(int(cin), int(cout), int(H), int(W)))
+
+
+def first_wgrad_workspace_floats(cout):
+    return int(_prep().pnnp_first_wgrad_workspace_floats(int(cout)))
+
+
+def first_bwd_weight(g, cout, x, cin, dW, dbias, ws, accumulate=0):
+    """dW [cout,cin,3,3], dbias (+)= for the first 3x3 convolution: x [B,H,W,xcs>=4] zero in channels cin..3, g [B,H,W,>=cout]."""
+    require_cuda(g, x, dW, ws)
+    B, H, W, gcs = g.shape
+    with _Timed('first_wgrad', 2.0 * B * H * W * cout * cin * 9, 4.0 * B * H * W * (cin + cout)):
+        check(_prep().pnnp_first_bwd_weight_f32(ptr(g), gcs, cout, ptr(x), x.shape[3], cin, ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                ptr(ws), _i64(ws.numel()), stream()), 'first_bwd_weight')
 
 
 def maxpool_fwd(x, y, codes=None):

@@ -37,9 +37,10 @@ def _he_net(arch, seed=11):
     return net.cuda(), sd
 
 
-FAMILIES = {'x3': dict(x3=True, wino=True), 'wino': dict(x3=False, wino=True), 'direct': dict(x3=False, wino=False)}
+FAMILIES = {'x3': dict(x3=True, wino=True, thin=True), 'wino': dict(x3=False, wino=True, thin=True), 'direct': dict(x3=False, wino=False, thin=False)}
 # x3: 3x3 forward / backward-data on the bf16 matrix cores (float32 operands split in three), Winograd backward-weight;
-# wino: Winograd F(2x2,3x3) on the fp32 matrix cores where it applies; direct: fp32 implicit GEMM everywhere
+# wino: Winograd F(2x2,3x3) on the fp32 matrix cores where it applies; direct: fp32 implicit GEMM everywhere, the 4-channel ends included
+# (thin=False; the other two run them on the streaming kernels of csrc/thin.hip)
 
 
 def _fwd(net, x, family):
