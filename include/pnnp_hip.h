@@ -175,6 +175,10 @@ int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, vo
                           int Cout, int Cin, int Cin_pad);
 int pnnp_conv3x3_x3_fwd_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias,
                             const float* residual, float* y, int B, int H, int W, int Cout, int act, void* stream);
+/* the same layer with the MaxPool2d(2) behind it (archs/Unet.py:35,41,47,53) fused into its epilogue: y as above, pooled
+ * [B][H/2][W/2][Cout] and codes exactly as pnnp_maxpool2_fwd_codes_f32 would produce from y (H, W even). */
+int pnnp_conv3x3_x3_fwd_pool_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias, float* y,
+                                 float* pooled, unsigned char* codes, int B, int H, int W, int Cout, int act, void* stream);
 int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad,
                                  float* dx1, int C1, const float* mask1, int mode1, int accum1,
                                  float* dx2 /*or null*/, int C2, const float* mask2, int mode2, int accum2,

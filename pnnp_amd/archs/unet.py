@@ -31,11 +31,12 @@ class ConvPolicy:
     kernels of csrc/thin.hip instead of the channel-padded GEMM kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
     families against each other at full size)."""
 
-    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True, thin=True):
+    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True, thin=True, pool_fused=True):
         self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin = bool(wino), bool(wino_wgrad), int(wino_mink), bool(x3), bool(thin)
+        self.pool_fused = bool(pool_fused)         # training forward: MaxPool2d(2) in the epilogue of the bf16x3 conv in front of it
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -88,7 +89,7 @@ class _EngineBase:
         """``set_policy(x3=False)`` etc.: fields not named keep their current value."""
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
-                       thin=self.policy.thin)
+                       thin=self.policy.thin, pool_fused=self.policy.pool_fused)
             cur.update(kw)
             policy = ConvPolicy(**cur)
         self.policy = policy
@@ -304,17 +305,27 @@ class UNetEngine(_EngineBase):
         for lvl in range(5):               # encoder: conv{l}_1, conv{l}_2, pool
             i = lvl + 1
             a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
-            a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
-            if lvl < 4:
-                codes = None
-                if train:                          # argmax + sign codes: the backward pass then does not re-read the full-resolution map
-                    codes = bufs.t.get(f'pc{i}')
-                    shp = (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])
-                    if codes is None or tuple(codes.shape) != shp or codes.device != dev:
-                        codes = bufs.t[f'pc{i}'] = torch.empty(shp, dtype=torch.uint8, device=dev)
-                    a[f'pc{i}'] = codes
-                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])), codes=codes)
-                cur = a[f'p{i}']
+            if lvl == 4:
+                a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
+                continue
+            codes = None
+            fused = self.policy.pool_fused and self._x3.get(f'conv{i}_2', (False, False))[0]
+            if train or fused:                     # argmax + sign codes: the backward pass then does not re-read the full-resolution map
+                codes = bufs.t.get(f'pc{i}')
+                shp = (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])
+                if codes is None or tuple(codes.shape) != shp or codes.device != dev:
+                    codes = bufs.t[f'pc{i}'] = torch.empty(shp, dtype=torch.uint8, device=dev)
+                a[f'pc{i}'] = codes
+            pooled = g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl]))
+            if fused:
+                # conv{i}_2 writes the pooled map and the codes from its own epilogue (csrc/conv_x3.hip)
+                a[f'c{i}'] = ops.conv_x3_fwd_pool(a[f'c{i}a'], None, self._wx(f'conv{i}_2')[0], P[f'conv{i}_2.bias'],
+                                                  g(f'conv{i}_2', (B, hs[lvl], ws[lvl], ch[lvl])), pooled, codes, ch[lvl], LRELU)
+                a[f'p{i}'] = pooled
+            else:
+                a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
+                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], pooled, codes=codes)
+            cur = a[f'p{i}']
         cur = a['c5']
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
             lvl = 9 - i

@@ -191,6 +191,18 @@ int pnnp_conv3x3_x3_fwd_f32(const float* x1, int C1, const float* x2, int C2, co
     return pnnp_igemm_x3_launch(a, C1, as_stream(stream));
 }
 
+// pnnp_conv3x3_x3_fwd_f32 + MaxPool2d(2) of its (activated) output in the same kernel: y as before, pooled [B][H/2][W/2][Cout]
+// and the codes of pnnp_maxpool2_fwd_codes_f32 (bit-identical to running that kernel on y).  H, W even; no residual.
+int pnnp_conv3x3_x3_fwd_pool_f32(const float* x1, int C1, const float* x2, int C2, const void* w_x3, const float* bias, float* y,
+                                 float* pooled, unsigned char* codes, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_x3 || !y || !pooled || !codes || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1) || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    IgemmArgs a;
+    fwd_args(a, x1, C1, x2, C2, w_x3, bias, nullptr, y, B, H, W, Cout, act);
+    a.pool_dst = pooled; a.pool_codes = codes; a.pool_cs = Cout;
+    return pnnp_igemm_x3_launch(a, C1, as_stream(stream));
+}
+
 int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad,
                                  float* dx1, int C1, const float* mask1, int mode1, int accum1,
                                  float* dx2, int C2, const float* mask2, int mode2, int accum2,

@@ -82,7 +82,7 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int BN>
+template <int BN, bool POOL>
 __global__ void __launch_bounds__(NTHR, 1)
 igemm_x3_kernel(const IgemmArgs a) {
     using Cfg = X3Cfg<BN>;
@@ -266,6 +266,70 @@ igemm_x3_kernel(const IgemmArgs a) {
         const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
         float* eb = epi + wave * 512;
         const int q4 = (lane & 7) * 4, pr = lane >> 3;
+        if constexpr (POOL) {
+            // Forward layer in front of MaxPool2d(2) (archs/Unet.py:35,41,47,53): single destination, bias + activation only.
+            // A wave owns the two rows 2j, 2j+1 of its 32 columns; a lane takes the pixel PAIR (2 pr, 2 pr + 1) of a 16-pixel
+            // half from the patch, so after both rows it holds a whole 2x2 window of 4 channels: it writes the pooled float4
+            // and the four codes (bits 0-1 first maximum in the order (0,0) (0,1) (1,0) (1,1), bits 2-5 the signs) of
+            // csrc/misc.hip maxpool_fwd_codes_kernel -- the pool kernel and its re-read of the full-resolution map go away.
+            const int cs2 = a.dst_cs[0];
+            const int64_t imgo = (int64_t)b * a.OH * a.OW * cs2;
+            const int ibytes = a.OH * a.OW * cs2 * 4;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst[0] + imgo), 0, ibytes, 0x00020000);
+            const int ph = a.OH >> 1, pw = a.OW >> 1;
+            const int64_t pimg = (int64_t)b * ph * pw * a.pool_cs;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool_dst + pimg), 0, ph * pw * a.pool_cs * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool_codes + pimg), 0, ph * pw * a.pool_cs, 0x00020000);
+            const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
+            const int py0 = y0 + wave * MT;
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
+                const bool n_ok = nwv + q4 < a.Ntot;
+                f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+                if (a.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nwv + q4);
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    f32x4 win[2][2];
+                    const int px = x0 + 16 * h2 + 2 * pr;
+                    const bool ok2 = py0 < a.DH && px < a.DW && n_ok;            // even sizes: the whole window is inside or outside
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                        for (int r = 0; r < 8; ++r) {
+                            eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][8 * h2 + r];
+                            acc[i][k][8 * h2 + r] = 0.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            f32x4 o = *reinterpret_cast<const f32x4*>(eb + (2 * pr + e) * 32 + q4) + bias4;
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+                            win[i][e] = o;
+                            const unsigned vo = ok2 ? (unsigned)((((py0 + i) * a.OW + px + e) * cs2 + nwv + q4) * 4) : OOB;
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo, 0, 0);
+                        }
+                    }
+                    f32x4 mx;
+                    unsigned code = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float w0 = win[0][0][c], w1 = win[0][1][c], w2 = win[1][0][c], w3 = win[1][1][c];
+                        unsigned arg = 0; float best = w0;
+                        if (w1 > best) { best = w1; arg = 1; }                  // first maximum wins
+                        if (w2 > best) { best = w2; arg = 2; }
+                        if (w3 > best) { best = w3; arg = 3; }
+                        const unsigned cj = arg | (w0 > 0.f ? 4u : 0u) | (w1 > 0.f ? 8u : 0u) | (w2 > 0.f ? 16u : 0u) | (w3 > 0.f ? 32u : 0u);
+                        mx[c] = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
+                        code |= cj << (8 * c);
+                    }
+                    const unsigned po = (unsigned)(((py0 >> 1) * pw + (px >> 1)) * a.pool_cs + nwv + q4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mx), rp, ok2 ? po * 4u : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(code, rc, ok2 ? po : OOB, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
@@ -442,10 +506,10 @@ igemm_x3_kernel(const IgemmArgs a) {
     }
 }
 
-template <int BN>
+template <int BN, bool POOL>
 int launch_x3(const IgemmArgs& a, hipStream_t s) {
     using Cfg = X3Cfg<BN>;
-    auto kern = igemm_x3_kernel<BN>;
+    auto kern = igemm_x3_kernel<BN, POOL>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
     const int per_cu = 1;                                           // ~150 KB of LDS: one 8-wave workgroup per CU
@@ -482,5 +546,13 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     b.seg_channels = chan_per_seg;
     const int64_t wbytes = (int64_t)((a.Ntot + 31) / 32) * b.nseg * b.chunks_per_seg * 27648;
     if (wbytes >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
-    return a.Ntot >= 64 ? launch_x3<64>(b, s) : launch_x3<32>(b, s);
+    if (a.pool_dst || a.pool_codes) {
+        // fused MaxPool2d(2): plain forward layers only (one destination, no mask / residual / accumulate), even sizes
+        if (!a.pool_dst || !a.pool_codes || a.dst[1] || a.mask_mode[0] || a.accum[0] || a.addsrc || (a.OH & 1) || (a.OW & 1) || a.OH != a.DH ||
+            a.OW != a.DW || (a.pool_cs & 3) || a.pool_cs < a.Ntot || ((uintptr_t)a.pool_dst & 15) || ((uintptr_t)a.pool_codes & 3))
+            return PNNP_E_UNSUPPORTED;
+        if ((int64_t)(a.OH / 2) * (a.OW / 2) * a.pool_cs * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+        return a.Ntot >= 64 ? launch_x3<64, true>(b, s) : launch_x3<32, true>(b, s);
+    }
+    return a.Ntot >= 64 ? launch_x3<64, false>(b, s) : launch_x3<32, false>(b, s);
 }

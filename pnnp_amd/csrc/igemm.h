@@ -50,4 +50,9 @@ struct IgemmArgs {
     int mask_mode[2];              // 0 none, 1 x lrelu'(mask), 2 x relu'(mask)
     int accum[2];                  // dst += result
     const float* addsrc;           // optional residual tensor with dst[0] geometry, added before act (or null)
+    // (csrc/conv_x3.hip, forward only) MaxPool2d(2) of the activated output fused into the epilogue: the pooled map
+    // [B][OH/2][OW/2][pool_cs] and the one-byte argmax + sign codes of pnnp_maxpool2_fwd_codes_f32 (or both null)
+    float* pool_dst;
+    unsigned char* pool_codes;
+    int pool_cs;
 };

@@ -160,6 +160,17 @@ def conv_x3_fwd(x1, x2, w_x3, bias, y, cout, act, residual=None):
     return y
 
 
+def conv_x3_fwd_pool(x1, x2, w_x3, bias, y, pooled, codes, cout, act):
+    """conv_x3_fwd + MaxPool2d(2) of the activated output in the same kernel (pooled [B,H/2,W/2,cout], codes as maxpool_fwd)."""
+    require_cuda(x1, x2, w_x3, y, pooled, codes)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_x3', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv3x3_x3_fwd_pool_f32(ptr(x1), C1, ptr(x2), C2, ptr(w_x3), ptr(bias), ptr(y), ptr(pooled), ptr(codes),
+                                                   B, H, W, cout, act, stream()), 'conv_x3_fwd_pool')
+    return y
+
+
 def conv_x3_bwd_data(g, w_x3_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=None, mask2=None, mode2=0, accum2=0):
     require_cuda(g, w_x3_dgrad, dx1)
     B, H, W, Cout = g.shape

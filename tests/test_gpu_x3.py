@@ -225,3 +225,27 @@ def test_x3_conv3x3_stride2(case):
     dx = nhwc(base).cuda().clone()
     ops.conv_s2_x3_bwd_data(nhwc(g).cuda(), d, dx, accum=1)
     close(nchw(dx), base + x.grad, what=f'x3 s2 dgrad {case}')
+
+
+@pytest.mark.parametrize('cin,cout,shape', [(32, 32, (2, 32, 64)), (32, 64, (1, 48, 96)), (64, 64, (2, 16, 32)), (16, 128, (1, 32, 32))])
+def test_fused_maxpool_equals_conv_then_pool_kernel(cin, cout, shape):
+    """conv3x3 + LeakyReLU + MaxPool2d(2) in one kernel (archs/Unet.py:33-35): y, the pooled map and the argmax/sign codes are
+    bit-identical to the un-fused conv followed by the pool kernel (same accumulation, same first-maximum rule)."""
+    from pnnp_amd import ops
+    B, H, W = shape
+    g = torch.Generator(device='cuda').manual_seed(cin + cout)
+    x = torch.randn(B, H, W, cin, device='cuda', generator=g)
+    x[0, :4, :8] = 0.0                                                  # ties: equal values inside windows (first maximum must win)
+    w = torch.randn(cout, cin, 3, 3, device='cuda', generator=g) * 0.1
+    b = torch.randn(cout, device='cuda', generator=g) * 0.1
+    b[: cout // 2] = 0.0
+    wx = torch.empty(ops.x3_weight_bytes(cin, cout), dtype=torch.uint8, device='cuda')
+    jobs = ops.PackJobs(); jobs.add_x3(w, wx, None, cin_pad=(cin + 15) // 16 * 16); jobs.run()
+    y0 = torch.empty(B, H, W, cout, device='cuda'); p0 = torch.empty(B, H // 2, W // 2, cout, device='cuda')
+    c0 = torch.empty(B, H // 2, W // 2, cout, dtype=torch.uint8, device='cuda')
+    ops.conv_x3_fwd(x, None, wx, b, y0, cout, 1)
+    ops.maxpool_fwd(y0, p0, codes=c0)
+    y1 = torch.full_like(y0, float('nan')); p1 = torch.full_like(p0, float('nan')); c1 = torch.full_like(c0, 255)
+    ops.conv_x3_fwd_pool(x, None, wx, b, y1, p1, c1, cout, 1)
+    assert torch.equal(y1, y0) and torch.equal(p1, p0) and torch.equal(c1, c0)
+    assert int((c0 & 3 != 0).sum()) > 0 and int((c0 >> 2 == 0).sum()) > 0      # the case has non-trivial argmax and all-negative windows
