@@ -23,8 +23,12 @@ namespace {
 
 constexpr int NWAVE = 8, NTHR = 512, TH = 8, NPIX = TH * 32;        // 256 pixels per tile
 constexpr int KI = 32;                                              // channels per work item (two 16-channel k-steps)
-constexpr int XS_F4 = 2 * 2 * 3 * NPIX;                             // one image in 16-byte words: [k-step 2][octet 2][piece 3][pixel]
-constexpr int XS_BYTES = XS_F4 * 16;                                // 49152
+// one image in 16-byte words: [k-step 2][octet 2] slots of [piece 3][pixel], each slot padded by 64 bytes: the staging writes of 8
+// consecutive lanes go to 2 pixels x 4 slots, and with an unpadded slot stride (a multiple of 256 bytes) the four slots fell on the
+// same banks -- a 4-way conflict on every ds_write_b128 that made the kernel LDS-bound
+constexpr int SLOT_F4 = 3 * NPIX + 4;
+constexpr int XS_F4 = 2 * 2 * SLOT_F4;
+constexpr int XS_BYTES = XS_F4 * 16;                                // 49408
 constexpr int WBLK = 2 * 3 * 32 * 16;                               // one k-step of one 32-column block: [octet 2][piece 3][32][16 B] = 3072
 constexpr unsigned OOB = 0x80000000u;
 
@@ -81,7 +85,7 @@ gemm_x3_kernel(const IgemmArgs a) {
     for (int k = 0; k < 2; ++k) {
         const int pix = (tid + NTHR * k) >> 2;
         prow[k] = pix >> 5; pcol[k] = pix & 31;
-        xdst[k] = ((oc >> 1) * 2 + (oc & 1)) * 3 * NPIX + pix;      // + piece * NPIX (+ image * XS_F4)
+        xdst[k] = ((oc >> 1) * 2 + (oc & 1)) * SLOT_F4 + pix;      // + piece * NPIX (+ image * XS_F4)
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
@@ -119,18 +123,38 @@ gemm_x3_kernel(const IgemmArgs a) {
             ra[set][k][1] = bload(rs, vo, soff + 16);
         }
     };
-    // one of the two staging slices of an item: split slot k of register set `set` into image `img`
-    auto stage_slot = [&](int k, int set, int img) {
-        u32x4 H, M, L;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
+    // one of the two staging slots of an item, in quarters: quarter p splits one float pair of slot k of register set `set`;
+    // after the fourth the three 16-byte words go to image `img`
+    u32x4 sH, sM, sL;
+    float qa0[2], qa1[2];                                           // a quarter in flight (up to two per MFMA group)
+    // step 0..4 of splitting float pair p of slot k: five dependent pieces of 1-4 VALU instructions, one per MFMA gap
+    auto stage_piece = [&](int k, int set, int p, int q, int step) {
+        if (step == 0) {
             const f32x4 v = ra[set][k][p >> 1];
-            unsigned h, m, l;
-            split2(v[(p & 1) * 2], v[(p & 1) * 2 + 1], h, m, l);
-            H[p] = h; M[p] = m; L[p] = l;
+            qa0[q] = v[(p & 1) * 2]; qa1[q] = v[(p & 1) * 2 + 1];
+            sH[p] = cvt_pk_bf16(qa0[q], qa1[q]);
+        } else if (step == 1) {
+            qa0[q] -= __uint_as_float(sH[p] << 16); qa1[q] -= __uint_as_float(sH[p] & 0xffff0000u);
+        } else if (step == 2) {
+            sM[p] = cvt_pk_bf16(qa0[q], qa1[q]);
+        } else if (step == 3) {
+            qa0[q] -= __uint_as_float(sM[p] << 16); qa1[q] -= __uint_as_float(sM[p] & 0xffff0000u);
+        } else if (step == 4) {
+            sL[p] = cvt_pk_bf16(qa0[q], qa1[q]);
         }
+    };
+    auto stage_quarter = [&](int k, int set, int p) {
+#pragma unroll
+        for (int st = 0; st < 5; ++st) stage_piece(k, set, p, 0, st);
+    };
+    auto stage_write = [&](int k, int img) {
         u32x4* d = xs + img * XS_F4 + xdst[k];
-        d[0] = H; d[NPIX] = M; d[2 * NPIX] = L;
+        d[0] = sH; d[NPIX] = sM; d[2 * NPIX] = sL;
+    };
+    auto stage_slot = [&](int k, int set, int img) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) stage_quarter(k, set, p);
+        stage_write(k, img);
     };
     // LDS-DMA of the weights of item g (tile columns n0 ..): per 32-column block two consecutive k-step blocks of the pack
     auto dma_weights = [&](const Tile& tl, int g, int st, bool valid = true) {
@@ -139,7 +163,11 @@ gemm_x3_kernel(const IgemmArgs a) {
             const int ins = min(wave + NWAVE * i, Cfg::NDMA - 1);   // 1 KB pieces: [block j][6 pieces of its 6144 bytes]
             const int j = ins / 6, r = ins - 6 * j;
             const int nb = (tl.n0 >> 5) + j;
+#ifdef GX_SKIP_DMA
+            const bool ok = false;
+#else
             const bool ok = valid && nb * 32 < a.Ntot;
+#endif
             const int soff = ok ? ((nb * K16 + 2 * g) * WBLK + r * 1024) : 0;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + ins * 1024),
                                                      16, ok ? (unsigned)lane * 16u : OOB, soff, 0, 0);
@@ -152,34 +180,51 @@ gemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-    // the two k-steps of an item; the staging slot `fill_k` of register set `set` is split between them into image img ^ 1
+    // the two k-steps of an item; the staging slot ks of register set `set` is split behind each k-step into image img ^ 1.
+    // Operand reads run one 32-column block ahead of the MFMAs (two rotating B register sets; the next k-step's A with the last
+    // block): only the first six reads of an item are exposed.  (All 15 reads of a k-step in front of its 24 MFMAs cost a full
+    // LDS round trip per k-step: 35 % of the kernel's time.)
     auto mfma_item = [&](int st, int img, int set, auto&& requests) {
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
+        u32x4 av[2][3], bv[2][3];
+        auto load_a = [&](int ks, u32x4 (&d)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[p] = xim[(ks * 2 + half) * SLOT_F4 + p * NPIX + wave * 32 + l31];
+        };
+        auto load_b = [&](int ks, int j, u32x4 (&d)[3]) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) d[p] = *reinterpret_cast<const u32x4*>(wst + (j * 2 + ks) * WBLK + ((half * 3 + p) * 32 + l31) * 16);
+        };
+        load_a(0, av[0]);
+        load_b(0, 0, bv[0]);
+        constexpr int QG = 4 / NT;                                  // staging quarters per 6-MFMA group
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            u32x4 av[3], bv[NT][3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) av[p] = xim[((ks * 2 + half) * 3 + p) * NPIX + wave * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-                    bv[j][p] = *reinterpret_cast<const u32x4*>(wst + (j * 2 + ks) * WBLK + ((half * 3 + p) * 32 + l31) * 16);
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
-#define GX_MFMA(PA, PB) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[PA]), __builtin_bit_cast(bf16x8, bv[j][PB]), acc[j], 0, 0, 0)
-                GX_MFMA(0, 2); GX_MFMA(2, 0); GX_MFMA(1, 1); GX_MFMA(0, 1); GX_MFMA(1, 0); GX_MFMA(0, 0);
+                const int cur = (ks * NT + j) & 1;
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < NT) load_b(ks, j + 1, bv[cur ^ 1]);
+                else if (ks == 0) { load_b(1, 0, bv[cur ^ 1]); load_a(1, av[1]); }
+                // The split of one staging slot is spread over the k-step's MFMAs: QG quarters per group, and inside the group one
+                // dependent piece (1-4 VALU instructions) goes BETWEEN each two MFMAs, fenced so that it stays there.  The six MFMAs
+                // of a group depend on each other through the accumulator: each leaves 32 cycles of issue slots, which a lump of
+                // VALU work behind the group does not use (a wave alone on its SIMD then runs MFMAs and VALU back to back).
+#define GX_MFMA(PA, PB) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks][PA]), __builtin_bit_cast(bf16x8, bv[cur][PB]), acc[j], 0, 0, 0)
+#define GX_GAP(STEP) { _Pragma("unroll") for (int q = 0; q < QG; ++q) stage_piece(ks, set, j * QG + q, q, STEP); __builtin_amdgcn_sched_barrier(0); }
+                GX_MFMA(0, 2); GX_GAP(0)
+                GX_MFMA(2, 0); GX_GAP(1)
+                GX_MFMA(1, 1); GX_GAP(2)
+                GX_MFMA(0, 1); GX_GAP(3)
+                GX_MFMA(1, 0); GX_GAP(4)
+                GX_MFMA(0, 0);
+#undef GX_GAP
 #undef GX_MFMA
+                if (j == NT - 1) stage_write(ks, img ^ 1);
+                __builtin_amdgcn_sched_barrier(0);
                 if (ks == 0 && j == 0) {
-                    __builtin_amdgcn_sched_barrier(0);
                     requests();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                if (j == NT - 1) {                                  // one staging slot behind each k-step's MFMAs
-                    __builtin_amdgcn_sched_barrier(0);
-                    stage_slot(ks, set, img ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -288,14 +333,30 @@ gemm_x3_kernel(const IgemmArgs a) {
         load_item(n1.tile, n1.g, 1);
     }
     int it = 0;
+#ifdef GX_STAMPS                  // debug build: where does an item's time go?  (cycle sums per wave, dumped into dst[0] at the end)
+    long long tw = 0, tb = 0, tm = 0, te = 0, to = 0, tall = clock64(), tlast_ = clock64();
+#define GX_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
+#else
+#define GX_T(v)
+#endif
     for (;;) {
         const int st = it & 1, img = it & 1;
         const Ck n1 = item_at(1), n2 = item_at(2);
-        // outstanding: [weights it (issued during it-1)] [activations it+1 (set (it+1)&1)]: both needed now / during this item
+        GX_T(to)
+        // outstanding, in issue order: [weights it] [activations it+1], both requested during item it-1.  The weights are needed now;
+        // the activations only when the first staging slot is split (after the first k-step's MFMAs: the compiler's own count
+        // waits there), so they get another third of an item of flight time
+#ifdef GX_WAIT_ALL
         __builtin_amdgcn_s_waitcnt(0x0f70);
+#else
+        __builtin_amdgcn_s_waitcnt(0x0f70 | AL);
+#endif
+        GX_T(tw)
         __syncthreads();
+        GX_T(tb)
         if (it & 1) mfma_item(st, img, 0, [&] { dma_weights(n1.tile, n1.g, st ^ 1, n1.ok); load_item(n2.tile, n2.g, 1); });
         else        mfma_item(st, img, 1, [&] { dma_weights(n1.tile, n1.g, st ^ 1, n1.ok); load_item(n2.tile, n2.g, 0); });
+        GX_T(tm)
         if (g == nitems - 1) {
             if constexpr (Cfg::EPI_ALIAS) {
                 __syncthreads();
@@ -304,10 +365,18 @@ gemm_x3_kernel(const IgemmArgs a) {
                 epilogue(cur, epi_sep);
             }
         }
+        GX_T(te)
         if (!n1.ok) break;
         if (g == nitems - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
         ++it;
     }
+#ifdef GX_STAMPS
+    if (lane == 0) {
+        __syncthreads();
+        float* d = a.dst[0] + ((int64_t)blockIdx.x * NWAVE + wave) * 8;
+        d[0] = (float)tw; d[1] = (float)tb; d[2] = (float)tm; d[3] = (float)te; d[4] = (float)to; d[5] = (float)(clock64() - tall); d[6] = (float)(it + 1);
+    }
+#endif
     (void)D; (void)AL;
 }
 
