@@ -175,6 +175,27 @@ igemm_x3_kernel(const IgemmArgs a) {
             d[0] = sh[k]; d[NPIX] = sm[k]; d[2 * NPIX] = sl[k];
         }
     };
+    // the same slice as five dependent pieces of 1-4 VALU instructions (step 0 .. 4) + the stores (step 5), one piece per MFMA gap
+    float pa0[2], pa1[2];
+    auto stage_piece = [&](int q, int u, int step, int img) {
+        const int k = q >> 2, p = q & 3;
+        if (step == 0) {
+            const f32x4 v = ra[k][p >> 1];
+            pa0[u] = v[(p & 1) * 2]; pa1[u] = v[(p & 1) * 2 + 1];
+            sh[k][p] = cvt_pk_bf16(pa0[u], pa1[u]);
+        } else if (step == 1) {
+            pa0[u] -= __uint_as_float(sh[k][p] << 16); pa1[u] -= __uint_as_float(sh[k][p] & 0xffff0000u);
+        } else if (step == 2) {
+            sm[k][p] = cvt_pk_bf16(pa0[u], pa1[u]);
+        } else if (step == 3) {
+            pa0[u] -= __uint_as_float(sm[k][p] << 16); pa1[u] -= __uint_as_float(sm[k][p] & 0xffff0000u);
+        } else if (step == 4) {
+            sl[k][p] = cvt_pk_bf16(pa0[u], pa1[u]);
+        } else if (p == 3) {
+            u32x4* d = xs + img * XS_F4 + xdst[k];
+            d[0] = sh[k]; d[NPIX] = sm[k]; d[2 * NPIX] = sl[k];
+        }
+    };
     // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: per 32-channel block 9216 contiguous
     // bytes of the pack, as 1 KB pieces dealt over the 8 waves
     const int K16 = nchunks;
@@ -225,6 +246,54 @@ igemm_x3_kernel(const IgemmArgs a) {
                     bx[j][p] = *reinterpret_cast<const u32x4*>(wst + j * WBLK + (((tp * 2 + half) * 3 + p) * 32 + l31) * 16);
         };
         lds_load(0, av[0], bv[0]);
+#ifndef X3_LUMPS
+        // Everything that is not an MFMA is cut into pieces of one LDS read or 1-4 VALU instructions and placed BETWEEN the MFMAs,
+        // fenced so that it stays there: the six MFMAs of a group depend on each other through the accumulator, each leaves 32 cycles
+        // of issue slots.  When the older wave of the SIMD has finished its item and waits at the barrier, the younger one runs alone:
+        // whatever stands between its MFMA groups as a lump (12 operand reads in front of a tap, a staging slice behind a group) is
+        // then matrix-pipe idle time.
+        auto next_read = [&](int tp, int m, u32x4 (&ax)[MT][3], u32x4 (&bx)[NT][3]) {      // operand read m of tap tp (0 .. 3 (MT + NT) - 1)
+            if (m < 3 * MT) {
+                const int i = m / 3, pc = m % 3;
+                ax[i][pc] = xim[(half * 3 + pc) * NPIX + (wave * MT + i + tr) * HC + tp + l31];
+            } else {
+                const int j = (m - 3 * MT) / 3, pc = (m - 3 * MT) % 3;
+                bx[j][pc] = *reinterpret_cast<const u32x4*>(wst + j * WBLK + (((tp * 2 + half) * 3 + pc) * 32 + l31) * 16);
+            }
+        };
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp) {
+            const u32x4 (&ax)[MT][3] = av[tp & 1];
+            const u32x4 (&bx)[NT][3] = bv[tp & 1];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    constexpr int NGRP = 3 * MT * NT, SPG = NSLICE / NGRP;   // staging slices per group (1 or 2)
+                    static_assert(NSLICE % NGRP == 0, "slices per group");
+                    const int gi = i * NT + j, grp = tp * MT * NT + gi;
+#define X3_MFMA(PA, PB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[i][PA]), __builtin_bit_cast(bf16x8, bx[j][PB]), acc[i][j], 0, 0, 0)
+#define X3_GAP(STEP) { const int m = gi * 6 + STEP;                                                                                  \
+                       if (tp + 1 < 3 && m < 3 * (MT + NT)) next_read(tp + 1, m, av[(tp + 1) & 1], bv[(tp + 1) & 1]);                \
+                       if constexpr (FILL) { _Pragma("unroll") for (int u = 0; u < SPG; ++u) stage_piece(grp * SPG + u, u, STEP, img ^ 1); } \
+                       __builtin_amdgcn_sched_barrier(0); }
+                    // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+                    X3_MFMA(0, 2); X3_GAP(0)
+                    X3_MFMA(2, 0); X3_GAP(1)
+                    X3_MFMA(1, 1); X3_GAP(2)
+                    X3_MFMA(0, 1); X3_GAP(3)
+                    X3_MFMA(1, 0); X3_GAP(4)
+                    X3_MFMA(0, 0); X3_GAP(5)
+#undef X3_GAP
+#undef X3_MFMA
+                    if (tp == 0 && i == 0 && j == 0) {
+                        requests();
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+        }
+#else
 #pragma unroll
         for (int tp = 0; tp < 3; ++tp) {
             if (tp + 1 < 3) lds_load(tp + 1, av[(tp + 1) & 1], bv[(tp + 1) & 1]);
@@ -236,11 +305,7 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
-#ifdef X3_SKIP_MFMA               // timing experiment only: staging without the matrix work
-#define X3_MFMA(PA, PB) acc[i][j][0] += __uint_as_float(ax[i][PA][0] ^ bx[j][PB][0])
-#else
 #define X3_MFMA(PA, PB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[i][PA]), __builtin_bit_cast(bf16x8, bx[j][PB]), acc[i][j], 0, 0, 0)
-#endif
                     X3_MFMA(0, 2); X3_MFMA(2, 0); X3_MFMA(1, 1); X3_MFMA(0, 1); X3_MFMA(1, 0); X3_MFMA(0, 0);
 #undef X3_MFMA
                     if (tp == 0 && i == 0 && j == 0) {
@@ -258,6 +323,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
     };
 
     // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
