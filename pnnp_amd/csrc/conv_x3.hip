@@ -620,5 +620,11 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
         if ((int64_t)(a.OH / 2) * (a.OW / 2) * a.pool_cs * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
         return a.Ntot >= 64 ? launch_x3<64, true>(b, s) : launch_x3<32, true>(b, s);
     }
-    return a.Ntot >= 64 ? launch_x3<64, false>(b, s) : launch_x3<32, false>(b, s);
+    // 64-column tiles unless they leave CUs idle: a layer with fewer (16 x 32 px x 64 ch) tiles than CUs (conv5_1 backward-data at
+    // B = 16: 128; everything in a single-crop forward) runs on 32-column tiles, twice as many
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int64_t tiles64 = (int64_t)((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + 63) / 64);
+    const bool wide = a.Ntot >= 64 && tiles64 * 4 >= (int64_t)cus * 3;
+    return wide ? launch_x3<64, false>(b, s) : launch_x3<32, false>(b, s);
 }

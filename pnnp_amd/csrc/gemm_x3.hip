@@ -416,5 +416,9 @@ int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     b.seg_channels = chan_per_seg;
     const int64_t wbytes = (int64_t)(a.Ntot / 32) * b.nseg * b.chunks_per_seg * 2 * WBLK;
     if (wbytes >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
-    return a.Ntot % 128 == 0 ? launch_gx<4>(b, s) : launch_gx<2>(b, s);
+    // 128-column tiles unless they leave CUs idle (single-crop forwards): then 64-column tiles, twice as many
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int64_t tiles128 = (int64_t)((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * (a.Ntot / 128);
+    return (a.Ntot % 128 == 0 && tiles128 * 4 >= (int64_t)cus * 3) ? launch_gx<4>(b, s) : launch_gx<2>(b, s);
 }
