@@ -310,6 +310,13 @@ def main():
         out["step_tflops_per_gpu"] = step_tflops
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(S, S)
+        # RCCL prints its version banner through C stdio (block-buffered when piped): push that out first so that the JSON line is the
+        # last line on stdout, then keep the communicator alive until after the print (its teardown prints nothing)
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
