@@ -85,6 +85,10 @@ static float unit(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.192092895507
 static float gauss(uint32_t a, uint32_t b) {
     return sqrtf(-2.0f * logf(unit(a))) * cosf(6.28318530717958647692f * unit(b));
 }
+/* the second normal of the same Box-Muller pair (sin instead of cos): a pixel pair shares the two uniforms */
+static float gauss2(uint32_t a, uint32_t b) {
+    return sqrtf(-2.0f * logf(unit(a))) * sinf(6.28318530717958647692f * unit(b));
+}
 
 typedef struct { uint32_t k0, k1, crop, off; } ctx_t;
 
@@ -118,7 +122,7 @@ static float poisson(float lam, uint32_t elem, const ctx_t* c, uint32_t r0, uint
     u4 extra = {{0, 0, 0, 0}};
     for (int it = 0; it < 64; ++it) {
         if (it > 0) {
-            if (it & 1) { extra = philox(elem, c->crop, 1u + ((it + 1) >> 1), c->off, c->k0, c->k1); x0 = extra.v[0]; x1 = extra.v[1]; }
+            if (it & 1) { extra = philox(elem, c->crop, 8u + ((it + 1) >> 1), c->off, c->k0, c->k1); x0 = extra.v[0]; x1 = extra.v[1]; }
             else { x0 = extra.v[2]; x1 = extra.v[3]; }
         }
         const float U = unit(x0) - 0.5f, V = unit(x1);
@@ -186,31 +190,41 @@ void pnnp_oracle_noise_sample(const float* y, float* out, int B, int C, int H, i
                     const u4 r = philox((uint32_t)(c * H + h), cx.crop, 0x40000000u, off, k0, k1);
                     row = gauss(r.v[0], r.v[1]) * P[P_SIGR] / mfm;
                 }
+                /* Draws of a pixel QUAD (4 consecutive pixels of a row, the last quad of a row may be short) come from blocks keyed by
+                   the quad's first element: slot 0 -> the shot uniforms U of pixels 0..3 (no 'p': two Box-Muller pairs, cos / sin),
+                   slot 1 -> read noise (two Box-Muller pairs: (x,y) cos -> pixel 0, sin -> pixel 1; (z,w) -> pixels 2, 3; Tukey: one
+                   uniform each), slot 2 -> the second uniform V of the first PTRS round, slot 3 -> quantisation.  Later PTRS rounds
+                   of a pixel take blocks keyed by the pixel's own element, slots 9.. (poisson()). */
+                u4 b0 = {{0, 0, 0, 0}}, b1 = {{0, 0, 0, 0}}, b2 = {{0, 0, 0, 0}}, b3 = {{0, 0, 0, 0}};
                 for (int w = 0; w < W; ++w) {
                     const long i = (((long)b * C + c) * H + h) * W + w;
                     const uint32_t elem = (uint32_t)((c * H + h) * (long)W + w);
-                    const u4 r = philox(elem, cx.crop, 0u, off, k0, k1);
+                    const int j = w & 3;
+                    if (j == 0) {
+                        b0 = philox(elem, cx.crop, 0u, off, k0, k1); b1 = philox(elem, cx.crop, 1u, off, k0, k1);
+                        b2 = philox(elem, cx.crop, 2u, off, k0, k1); b3 = philox(elem, cx.crop, 3u, off, k0, k1);
+                    }
                     float yy = y[i] * span;
                     yy = yy / ratio;
                     float shot;
                     if (up) {
                         const float lam = mfm * yy / K;
-                        shot = poisson(lam, elem, &cx, r.v[0], r.v[1]) * K / mfm;
+                        shot = poisson(lam, elem, &cx, b0.v[j], b2.v[j]) * K / mfm;
                     } else {
-                        const float n = gauss(r.v[0], r.v[1]);
+                        const float n = (j & 1) ? gauss2(b0.v[j & 2], b0.v[(j & 2) + 1]) : gauss(b0.v[j & 2], b0.v[(j & 2) + 1]);
                         float s = yy / K; s = sqrtf(s > 1e-10f ? s : 1e-10f);
                         shot = yy + n * s * K / mfm;
                     }
                     float acc = shot;
                     if (!ub) {
-                        const float rd = ug ? tukey(unit(r.v[2]), P[P_LAM]) : gauss(r.v[2], r.v[3]);
+                        const float rd = ug ? tukey(unit(b1.v[j]), P[P_LAM])
+                                            : ((j & 1) ? gauss2(b1.v[j & 2], b1.v[(j & 2) + 1]) : gauss(b1.v[j & 2], b1.v[(j & 2) + 1]));
                         acc = acc + rd * sig_read;
                     }
                     if (extras) {
                         if (ur) acc = acc + row;
                         if (uq) {
-                            const u4 rq = philox(elem, cx.crop, 1u, off, k0, k1);
-                            acc = acc + (unit(rq.v[0]) - 0.5f) * qscale;
+                            acc = acc + (unit(b3.v[j]) - 0.5f) * qscale;
                         }
                         if (ud) acc = acc + P[P_BIAS0 + (c & 3)];
                     }

@@ -10,11 +10,14 @@
 //   quant = U(-.5,.5) DN (OBS)  or  (U(0,1)-.5)*q*(wp-bl) (TORCH)
 //
 // RNG: Philox4x32-10, key = (seed_lo, seed_hi ^ offset_hi),
-//      counter = (element-in-crop, crop_base+b, slot, offset_lo).  Slot 0 feeds the first
-//      Poisson attempt (lanes x,y) and the read-noise Box-Muller pair (lanes z,w); slot 1
-//      the quantisation uniform; slots 2.. further PTRS rejection rounds; slot 0x40000000
-//      with element = c*H+h is the row draw.  The sample therefore depends only on
-//      (seed, offset, global crop index, element) -- not on batch size, grid or GPU count.
+//      counter = (element-in-crop, crop_base+b, slot, offset_lo).  A QUAD of 4 consecutive pixels of a row
+//      (= one thread) shares blocks keyed by its first element: slot 0 = the four shot uniforms, slot 1 = the
+//      read noise (two Box-Muller pairs, cos -> even pixel, sin -> odd pixel; Tukey-lambda: one uniform each),
+//      slot 2 = the second uniform of the first PTRS round (only computed when a pixel of the thread has
+//      lam >= 10), slot 3 = quantisation.  Later PTRS rounds of a pixel: blocks keyed by the pixel's own
+//      element, slots 9..; slot 0x40000000 with element = c*H+h is the row draw.  (Round 1 drew one block per
+//      pixel and a second one for 'q': twice the Philox work and twice the log / sqrt / cos.)  The sample
+//      depends only on (seed, offset, global crop index, element) -- not on batch size, grid or GPU count.
 // Poisson: lam < 10 sequential inversion; lam >= 10 Hoermann's PTRS transformed rejection
 // (exact, no Gaussian approximation).  Specification: oracle/pnnp_oracle.c.
 //
@@ -58,6 +61,29 @@ __device__ __forceinline__ float box_muller(uint32_t a, uint32_t b) {
     return fast_sqrt(-2.0f * fast_log(u1)) * cosf(6.28318530717958647692f * u2);
 }
 
+// cos(2 pi u) and sin(2 pi u) for u in (0, 1), absolute error < 1.5e-7 (the oracle's cosf / sinf of the ROUNDED product
+// 6.2831853f * u are no closer to the true values: that rounding alone moves the angle by up to 3.7e-7 rad).  Octant reduction on u
+// itself -- exact, u is a 23-bit fraction -- then the Taylor polynomials on [-pi/4, pi/4]: ~22 VALU for both.
+__device__ __forceinline__ void sincos_2pi(float u, float& sn, float& cs) {
+    const float t = u * 4.f;                                   // quarter turns
+    const float q = rintf(t);                                  // nearest quarter turn, 0 .. 4
+    const float r = (t - q) * 1.57079632679489661923f;         // |r| <= pi/4 (t - q is exact)
+    const float r2 = r * r;
+    const float c = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.4801587e-5f, -1.3888889e-3f), 4.1666668e-2f), -0.5f), 1.f);
+    const float s = r * fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.7557319e-6f, -1.9841270e-4f), 8.3333338e-3f), -1.6666667e-1f), 1.f);
+    const int qi = (int)q & 3;                                 // angle = qi * pi/2 + r
+    const float cq = (qi & 1) ? s : c, sq = (qi & 1) ? c : s;  // qi=0: (c, s)  1: (-s, c)  2: (-c, -s)  3: (s, -c)
+    cs = (qi == 1 || qi == 2) ? -cq : cq;
+    sn = (qi >= 2) ? -sq : sq;
+}
+// the two normals of one Box-Muller pair: n0 = r cos, n1 = r sin
+__device__ __forceinline__ void box_muller2(uint32_t a, uint32_t b, float& n0, float& n1) {
+    const float r = fast_sqrt(-2.0f * fast_log(u01(a)));
+    float sn, cs;
+    sincos_2pi(u01(b), sn, cs);
+    n0 = r * cs; n1 = r * sn;
+}
+
 struct Ctx {
     uint32_t k0, k1, crop, off;
 };
@@ -77,15 +103,44 @@ __device__ __forceinline__ float log_factorial(float k) {
     return (x - 0.5f) * fast_log(x) - x + 0.91893853f + 0.083333333f * r - 0.0027777778f * (r * r * r);
 }
 
-__device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
-    if (!(lam > 0.f)) return 0.f;
-    if (lam < 10.f) {
-        const float u = u01(r0);
-        float p = fast_exp(-lam), s = p, k = 0.f;
-        // the rounded CDF can saturate below the largest uniform (1 - 2^-24): stop when a term no longer moves the sum
-        while (u > s) { k += 1.f; p *= fast_div(lam, k); const float s2 = s + p; if (s2 == s) break; s = s2; }
-        return k;
+// Sequential inversion for lam < 10 (lanes with `take` false idle along): the oracle's loop
+//     while (u > s) { k += 1; p *= lam / k; s2 = s + p; if (s2 == s) break; s = s2; }
+// with the step counter WAVE-UNIFORM -- every lane that is still searching is at the same k.  The first 24 steps are unrolled, so
+// 1/k is a literal (a per-lane v_rcp_f32 is a quarter-rate instruction: 4 of the loop's 11 issue slots) and a step is 6 VALU
+// instructions + one ballot on the scalar unit; beyond 24 (P < 5e-5 per pixel at lam = 10) a plain loop takes over.  The dark
+// regime spends most of its time here: a wave iterates to the largest count among its 64 lanes, for each of its 4 pixels.
+__device__ __forceinline__ float poisson_small(float lam, float u_in, bool take) {
+    float p = fast_exp(-lam), s = p, k = 0.f;
+    float u = take ? u_in : -1.f;                                  // a lane is searching while u > s; done / idle lanes carry u = -1
+#define PS_STEP(FJ, RJ) {                                                                                        \
+        k = (u > s) ? (FJ) : k;                                                                                   \
+        p *= lam * (RJ);                                                                                          \
+        const float s2 = s + p;                                                                                   \
+        /* the rounded CDF can saturate below the largest uniform (1 - 2^-24): stop when a term no longer moves the sum */ \
+        u = (s2 == s) ? -1.f : u;                                                                                 \
+        s = s2; }
+    bool more = true;
+#pragma unroll
+    for (int j = 1; j <= 24; ++j) {
+        if (more) {
+            more = __builtin_amdgcn_ballot_w64(u > s) != 0;
+            if (more) PS_STEP((float)j, 1.0f / (float)j)
+        }
     }
+    if (more)
+        for (int j = 25; j < 64; ++j) {
+            if (__builtin_amdgcn_ballot_w64(u > s) == 0) break;
+            PS_STEP((float)j, __builtin_amdgcn_rcpf((float)j))
+        }
+#undef PS_STEP
+    return k;
+}
+
+__device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
+    const bool small = lam > 0.f && lam < 10.f;
+    const float ks = poisson_small(lam, u01(r0), small);          // (convergent: every lane of the wave comes through here)
+    if (!(lam > 0.f)) return 0.f;
+    if (small) return ks;
     const float slam = fast_sqrt(lam), loglam = fast_log(lam);
     const float b = 0.931f + 2.53f * slam;
     const float a = -0.059f + 0.02483f * b;
@@ -95,7 +150,7 @@ __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0
     uint4 extra = make_uint4(0, 0, 0, 0);
     for (int it = 0; it < 64; ++it) {
         if (it > 0) {
-            if (it & 1) { extra = philox4x32_10(elem, c.crop, 1u + ((it + 1) >> 1), c.off, c.k0, c.k1); x0 = extra.x; x1 = extra.y; }
+            if (it & 1) { extra = philox4x32_10(elem, c.crop, 8u + ((it + 1) >> 1), c.off, c.k0, c.k1); x0 = extra.x; x1 = extra.y; }
             else { x0 = extra.z; x1 = extra.w; }
         }
         const float U = u01(x0) - 0.5f, V = u01(x1);
@@ -179,33 +234,54 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
         const float bias = (use_d && extras) ? P[PNNP_P_BIAS0 + (c & 3)] : 0.f;
         const float lo = (flags & PNNP_NOISE_CLIP) ? 0.f : -__fdiv_rn(bl, wp);
         const uint32_t e0 = (uint32_t)((c * H + h) * (int64_t)W + 4 * xq);
-        float o[4];
+        float o[4], yv[4], lam[4], rdn[4] = {0.f, 0.f, 0.f, 0.f}, shn[4] = {0.f, 0.f, 0.f, 0.f};
+        // the quad's blocks (see the header): shot uniforms, read noise, first-round PTRS V (lazily), quantisation
+        const uint4 b0 = philox4x32_10(e0, ctx.crop, 0u, off, k0, k1);
+        const uint32_t U[4] = {b0.x, b0.y, b0.z, b0.w};
+        bool big = false;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            yv[i] = fast_div(__fmul_rn(v[i], span), ratio);
+            lam[i] = fast_div(__fmul_rn(mfm, yv[i]), K);
+            big |= lam[i] >= 10.f;
+        }
+        uint32_t V[4] = {0u, 0u, 0u, 0u};
+        if (use_p && big) {
+            const uint4 b2 = philox4x32_10(e0, ctx.crop, 2u, off, k0, k1);
+            V[0] = b2.x; V[1] = b2.y; V[2] = b2.z; V[3] = b2.w;
+        }
+        if (!use_p) { box_muller2(b0.x, b0.y, shn[0], shn[1]); box_muller2(b0.z, b0.w, shn[2], shn[3]); }
+        if (!use_b) {
+            const uint4 b1 = philox4x32_10(e0, ctx.crop, 1u, off, k0, k1);
+            if (use_g) {
+                const float lt = P[PNNP_P_LAM];
+                rdn[0] = tukey_lambda(u01(b1.x), lt); rdn[1] = tukey_lambda(u01(b1.y), lt);
+                rdn[2] = tukey_lambda(u01(b1.z), lt); rdn[3] = tukey_lambda(u01(b1.w), lt);
+            } else {
+                box_muller2(b1.x, b1.y, rdn[0], rdn[1]); box_muller2(b1.z, b1.w, rdn[2], rdn[3]);
+            }
+        }
+        uint32_t Q[4] = {0u, 0u, 0u, 0u};
+        if (extras && use_q) {
+            const uint4 b3 = philox4x32_10(e0, ctx.crop, 3u, off, k0, k1);
+            Q[0] = b3.x; Q[1] = b3.y; Q[2] = b3.z; Q[3] = b3.w;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const uint32_t elem = e0 + i;
-            const uint4 r = philox4x32_10(elem, ctx.crop, 0u, off, k0, k1);
-            float yy = __fmul_rn(v[i], span);
-            yy = fast_div(yy, ratio);
+            const float yy = yv[i];
             float shot;
             if (use_p) {
-                const float lam = fast_div(__fmul_rn(mfm, yy), K);
-                shot = fast_div(__fmul_rn(poisson_f32(lam, elem, ctx, r.x, r.y), K), mfm);
+                shot = fast_div(__fmul_rn(poisson_f32(lam[i], elem, ctx, U[i], V[i]), K), mfm);
             } else {
-                const float n = box_muller(r.x, r.y);
                 const float s = fast_sqrt(fmaxf(fast_div(yy, K), 1e-10f));
-                shot = __fadd_rn(yy, fast_div(__fmul_rn(__fmul_rn(n, s), K), mfm));
+                shot = __fadd_rn(yy, fast_div(__fmul_rn(__fmul_rn(shn[i], s), K), mfm));
             }
             float acc = shot;
-            if (!use_b) {
-                const float rd = use_g ? tukey_lambda(u01(r.z), P[PNNP_P_LAM]) : box_muller(r.z, r.w);
-                acc = __fadd_rn(acc, __fmul_rn(rd, sig_read));
-            }
+            if (!use_b) acc = __fadd_rn(acc, __fmul_rn(rdn[i], sig_read));
             if (extras) {
                 if (use_r) acc = __fadd_rn(acc, row_noise);
-                if (use_q) {
-                    const uint4 rq = philox4x32_10(elem, ctx.crop, 1u, off, k0, k1);
-                    acc = __fadd_rn(acc, __fmul_rn(u01(rq.x) - 0.5f, qscale));
-                }
+                if (use_q) acc = __fadd_rn(acc, __fmul_rn(u01(Q[i]) - 0.5f, qscale));
                 if (use_d) acc = __fadd_rn(acc, bias);
             }
             float z = fast_div(acc, span);
@@ -322,7 +398,10 @@ extern "C" int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, i
     const int64_t total = (int64_t)B * C * H * ((W + 3) / 4);
     if (total == 0) return PNNP_OK;
     int64_t blocks = (total + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+#ifndef NS_BLOCKS_PER_CU
+#define NS_BLOCKS_PER_CU 64      // short blocks, scheduled dynamically: a wave's time varies with its pixels' Poisson paths (measured 5 .. 64: 358 -> 196 us)
+#endif
+    if (blocks > pnnp_device_cus() * NS_BLOCKS_PER_CU) blocks = pnnp_device_cus() * NS_BLOCKS_PER_CU;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
     hipLaunchKernelGGL(noise_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
                        y, out, B, C, H, W, params, flags, mfm, k0, k1, (uint32_t)offset, crop_base);

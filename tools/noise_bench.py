@@ -17,6 +17,7 @@ def timeit(fn, reps=30):
 
 
 def main():
+    only = sys.argv[sys.argv.index('--only') + 1] if '--only' in sys.argv else None      # e.g. pr:dark
     g = torch.Generator(device='cuda').manual_seed(0)
     base = torch.rand(16, 4, 512, 512, device='cuda', generator=g)
     np.random.seed(1); plist = [process.sample_params_max('SonyA7S2') for _ in range(16)]
@@ -24,6 +25,8 @@ def main():
     out = torch.empty_like(base)
     for code in ('pr', 'prq', 'pgrq'):
         for name, scale in (('bright', 1.0), ('mid', 0.1), ('dark', 0.01)):
+            if only and only != f'{code}:{name}':
+                continue
             hr = base * scale
             fl = process.noise_flags(code, ori=False, clip=True, torch_mode=True)
             if 'g' in code and 'p' in code: fl |= process.F_TORCH_TUKEY
