@@ -52,6 +52,9 @@ struct Wx3Cfg {
     // staging slots (one float4 = 4 channels of a pixel): a 32-channel block of G / X is staged by the waves with wave % WM == block
     static constexpr int G_THR = NTHR / WM, X_THR = NTHR / WN;
     static constexpr int NG = (GPIX * 8 + G_THR - 1) / G_THR, NX = (XPIX * 8 + X_THR - 1) / X_THR;
+    // the 32 x 32 output tile (one k-step of 9 groups per tile, six staging slices) measured 5 % faster with its staging slices as lumps
+    // behind the MFMA groups than with everything placed between the individual MFMAs; the larger tiles 4-8 % slower
+    static constexpr bool LUMPS = WM * WN == 1;
     static_assert(WM * WN * WK == NWAVE && KS >= 1 && KS * WK == TH * 2, "wave layout");
     static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NWAVE * 16 * 64 * 4, "LDS budget (images; reduction scratch aliases them)");
 };
@@ -167,6 +170,30 @@ wgrad_x3_kernel(const Wx3Args a) {
         }
     };
     static_assert((GPIX * 8) % Cfg::G_THR == 0, "G slots must divide evenly (bias sums count every pixel once)");
+    // the same slice as dependent pieces of 2-4 VALU instructions (step 0 .. 9) and the stores (step 10, 11): one or two per MFMA gap
+    f32x4 pv; unsigned ph[2], pm[2], pl[2];
+    float bmul = 1.f;                                             // 0 while there is no next tile: the pieces then run on stale registers, branch-free
+    auto stage_piece = [&](int sl, int step, int img) {
+        const bool isg = sl < NG;
+        switch (step) {
+        case 0: pv = isg ? rg[isg ? sl : 0] : rx[isg ? 0 : sl - NG]; ph[0] = cvt_pk_bf16(pv.x, pv.y); ph[1] = cvt_pk_bf16(pv.z, pv.w); break;
+        case 1: if (isg) { bsum[0] = fmaf(pv.x, bmul, bsum[0]); bsum[1] = fmaf(pv.y, bmul, bsum[1]); bsum[2] = fmaf(pv.z, bmul, bsum[2]); bsum[3] = fmaf(pv.w, bmul, bsum[3]); } break;
+        case 2: pv.x -= __uint_as_float(ph[0] << 16); pv.y -= __uint_as_float(ph[0] & 0xffff0000u); break;
+        case 3: pv.z -= __uint_as_float(ph[1] << 16); pv.w -= __uint_as_float(ph[1] & 0xffff0000u); break;
+        case 4: pm[0] = cvt_pk_bf16(pv.x, pv.y); pm[1] = cvt_pk_bf16(pv.z, pv.w); break;
+        case 5: pv.x -= __uint_as_float(pm[0] << 16); pv.y -= __uint_as_float(pm[0] & 0xffff0000u); break;
+        case 6: pv.z -= __uint_as_float(pm[1] << 16); pv.w -= __uint_as_float(pm[1] & 0xffff0000u); break;
+        case 7: pl[0] = cvt_pk_bf16(pv.x, pv.y); pl[1] = cvt_pk_bf16(pv.z, pv.w); break;
+        default: {
+            char* ib = smem + img * Cfg::IMG_BYTES;
+            const int dst = isg ? g_dst[isg ? sl : 0] : x_dst[isg ? 0 : sl - NG];
+            const int pstride = (isg ? GPIX : XPIX) * 64;
+            if (step == 8) *reinterpret_cast<u32x2*>(ib + dst) = u32x2{ph[0], ph[1]};
+            if (step == 9) *reinterpret_cast<u32x2*>(ib + dst + pstride) = u32x2{pm[0], pm[1]};
+            if (step == 10) *reinterpret_cast<u32x2*>(ib + dst + 2 * pstride) = u32x2{pl[0], pl[1]};
+        } break;
+        }
+    };
 
     f32x16 acc[9];
 #pragma unroll
@@ -201,11 +228,72 @@ wgrad_x3_kernel(const Wx3Args a) {
     for (int s = 0; s < NSL; ++s) stage_slice(s, 0);
     if (z + a.Z < ntile) load_tile(z + a.Z);
     int img = 0;
+#ifdef WX3_STAMPS                 // debug build: cycle sums per wave (barrier wait / MFMA phase / tail), dumped into the slab at the end
+    long long tb = 0, tm = 0, tw = 0, tall = clock64(), tlast_ = clock64(); int ntl = 0;
+    long long gstamp[NGRP + 1] = {}, gt0 = 0;
+#define WX3_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
+#else
+#define WX3_T(v)
+#endif
     for (int tile = z; tile < ntile; tile += a.Z) {
+        WX3_T(tm)
         __syncthreads();                                            // image `img` is complete; every wave is done with the other one
+        WX3_T(tb)
+#ifdef WX3_STAMPS
+        if (ntl == 5) gt0 = clock64();
+        if (ntl == 6) gstamp[NGRP] = clock64();
+#endif
         const char* gimg = smem + img * Cfg::IMG_BYTES;
         const char* ximg = gimg + Cfg::G_BYTES;
         const bool have_next = tile + a.Z < ntile, have_next2 = tile + 2 * a.Z < ntile;
+        if constexpr (!Cfg::LUMPS) {
+        // Operand reads and the staging pieces sit BETWEEN the individual MFMAs (fenced).  The SIMD's vector issue is the shared
+        // resource: an MFMA holds it for 8 of its 32 cycles, a VALU instruction for 4-5, and DEPENDENT VALU instructions back to back
+        // wait for each other -- a staging slice as one lump behind its group of MFMAs (30 dependent VALU + 3 stores) took ~300 cycles
+        // during which the wave issued no MFMA (cycle stamps: 280 cycles per 6-MFMA group without a slice, 500-530 with one).
+        auto g_addr = [&](int ks) {
+            const int kk = wk * KS + ks;
+            return gimg + ((wmo * 3) * GPIX + (kk >> 1) * 32 + (kk & 1) * 16) * 64 + tr_lane;
+        };
+        auto x_addr = [&](int ks, int t) {
+            const int kk = wk * KS + ks, dy = t / 3, dx = t - 3 * dy;
+            return ximg + ((wno * 3) * XPIX + ((kk >> 1) + dy) * XC + (kk & 1) * 16 + dx) * 64 + tr_lane;
+        };
+        bmul = have_next ? 1.f : 0.f;                                // (without a next tile the staging below rewrites the idle image from stale registers: harmless)
+        u32x4 av[2][3], bv[2][3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) { av[0][p] = tr_read(g_addr(0) + p * GPIX * 64); bv[0][p] = tr_read(x_addr(0, 0) + p * XPIX * 64); }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int grp = ks * 9 + t, cur = grp & 1;
+                const bool more = grp + 1 < NGRP;                     // another (k-step, tap) follows in this tile
+                const int nks = t + 1 < 9 ? ks : ks + 1, nt = t + 1 < 9 ? t + 1 : 0;
+                const bool fill = grp >= SL0 && grp < SL0 + NSL;
+#ifdef WX3_STAMPS
+                if (ntl == 5) gstamp[grp] = clock64();
+#endif
+                if (grp == SL0) __builtin_amdgcn_s_waitcnt(0x0f70);        // the next tile's loads were issued a full tile ago
+                __builtin_amdgcn_sched_barrier(0);
+#define WX3_MFMA(PA, PB) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av[ks & 1][PA]), __builtin_bit_cast(bf16x8, bv[cur][PB]), acc[t], 0, 0, 0)
+#define WX3_GAP(G) { if (more && G < 3) bv[cur ^ 1][G] = tr_read(x_addr(nks, nt) + G * XPIX * 64);                                          \
+                     if (more && t == 8 && G >= 3) av[(ks + 1) & 1][G - 3] = tr_read(g_addr(ks + 1) + (G - 3) * GPIX * 64);                \
+                     if (fill) { stage_piece(grp - SL0, 2 * G, img ^ 1); if (2 * G + 1 < 11) stage_piece(grp - SL0, 2 * G + 1, img ^ 1); } \
+                     __builtin_amdgcn_sched_barrier(0); }
+                // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
+                WX3_MFMA(0, 2); WX3_GAP(0)
+                WX3_MFMA(2, 0); WX3_GAP(1)
+                WX3_MFMA(1, 1); WX3_GAP(2)
+                WX3_MFMA(0, 1); WX3_GAP(3)
+                WX3_MFMA(1, 0); WX3_GAP(4)
+                WX3_MFMA(0, 0); WX3_GAP(5)
+#undef WX3_GAP
+#undef WX3_MFMA
+                if (grp == NGRP - 1 && have_next2) load_tile(tile + 2 * a.Z);   // registers are free again: the tile after next
+            }
+        }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const int kk = wk * KS + ks;                            // k-step of the tile: pixel row kk >> 1, pixels 16 (kk & 1) ..
@@ -233,16 +321,35 @@ wgrad_x3_kernel(const Wx3Args a) {
 #undef WX3_MFMA
                 __builtin_amdgcn_sched_barrier(0);
                 const int grp = ks * 9 + t;
+#ifdef WX3_STAMPS
+                if (ntl == 5) gstamp[grp] = clock64();
+#endif
                 if (grp >= SL0 && grp < SL0 + NSL) {                // the late groups carry the next tile's staging, one slice each
-                    if (grp == SL0) __builtin_amdgcn_s_waitcnt(0x0f70);        // its loads were issued a full tile ago
+                    if (grp == SL0) {
+#ifdef WX3_STAMPS
+                        WX3_T(tm)
+#endif
+                        __builtin_amdgcn_s_waitcnt(0x0f70);                 // its loads were issued a full tile ago
+#ifdef WX3_STAMPS
+                        WX3_T(tw)
+#endif
+                    }
                     if (have_next) stage_slice(grp - SL0, img ^ 1);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (grp == NGRP - 1 && have_next2) load_tile(tile + 2 * a.Z);   // registers are free again: the tile after next
             }
         }
+        }
         img ^= 1;
+#ifdef WX3_STAMPS
+        ++ntl;
+#endif
     }
+#ifdef WX3_STAMPS
+    WX3_T(tm)
+    const long long tloop = clock64() - tall;
+#endif
 
     // ---- reduce the WK pixel-split waves through LDS (the images are dead now), then write the slab [z][tap][m][n]
     __syncthreads();
@@ -292,6 +399,14 @@ wgrad_x3_kernel(const Wx3Args a) {
             a.bias_slab[(int64_t)z * a.M + m0 + blk * 32 + ch] = s;
         }
     }
+#ifdef WX3_STAMPS
+    __syncthreads();
+    if (lane == 0) {
+        float* d = a.slab + ((int64_t)blockIdx.x * NWAVE + wave) * 8;
+        d[0] = (float)tb; d[1] = (float)tm; d[2] = (float)tloop; d[3] = (float)(clock64() - tall); d[4] = (float)ntl; d[5] = (float)tw;
+        if (blockIdx.x == 0) { float* e = a.slab + 256 * NWAVE * 8 + wave * 32; for (int i = 0; i <= NGRP; ++i) e[i] = (float)(gstamp[i] - gt0); }
+    }
+#endif
 }
 
 // out[o(i)] (+)= sum_z slab[z][i]; i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t  (the parameter's own layout)
