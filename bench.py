@@ -291,6 +291,11 @@ def main():
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
                                "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
+            if fam == 'x3':
+                # informational: what a bare loop of the same MFMA sustains on this chip (tools/ubench/mfma_shape.hip, 8 waves per CU, operands
+                # re-read from LDS): 1790 TFLOP/s on random operands (power-limited clock), 2250 on zero operands; `peak` stays the 2.4 GHz figure
+                out["roofline"]["sustained_bare_mfma_loop"] = {"random_operands": 1790.0, "zero_operands": 2250.0, "unit": "TFLOP/s",
+                                                               "source": "tools/ubench/mfma_shape.hip (DESIGN 5)"}
             # per-class table: from the un-timed pass with events around every launch (extra_steps steps)
             call = {}
             for kind, fl2, by2, e0, e1 in (prof_all or []):

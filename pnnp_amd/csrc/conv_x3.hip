@@ -137,27 +137,31 @@ igemm_x3_kernel(const IgemmArgs a) {
     f32x4 ra[NSLOT][2];                                             // halo registers of the NEXT chunk (8 channels per slot)
     u32x4 sh[NSLOT], sm[NSLOT], sl[NSLOT];                          // their hi / mid / lo words while the split is in progress
 
-    // global loads of the halo tile of (tile, chunk g) -> ra (no wait)
-    auto load_halo = [&](const Tile& tl, int g) {
+    // global loads of the halo tile of (tile, chunk g) -> ra (no wait): the scalar part, then one piece per staging slot
+    __amdgpu_buffer_rsrc_t h_rs; int h_soff, h_rlo, h_rhi, h_qlo, h_qhi, h_cvalid; unsigned h_cs4;
+    auto halo_prep = [&](const Tile& tl, int g) {
         const int si = g / a.chunks_per_seg, cc = g - si * a.chunks_per_seg;
         const IgemmSeg sg = a.seg[si];
         const int c0 = sg.coff + cc * 16;
-        const int rlo = -tl.y0, rhi = a.IH - tl.y0, qlo = -tl.x0, qhi = a.IW - tl.x0;
+        h_rlo = -tl.y0; h_rhi = a.IH - tl.y0; h_qlo = -tl.x0; h_qhi = a.IW - tl.x0;
         const int shift = (2 * a.IW + 2) * sg.cstride;             // the resource starts before the image: the scalar offset below stays >= 0
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            (void*)(sg.ptr + ((int64_t)tl.b * a.IH * a.IW * sg.cstride - shift)), 0, 0x7fffffff, 0x00020000);
-        const int soff = (((tl.y0 - 1) * a.IW + tl.x0 - 1) * sg.cstride + c0 + shift) * 4;
-        const unsigned cs4 = (unsigned)sg.cstride * 4u;
+        h_rs = __builtin_amdgcn_make_buffer_rsrc((void*)(sg.ptr + ((int64_t)tl.b * a.IH * a.IW * sg.cstride - shift)), 0, 0x7fffffff, 0x00020000);
+        h_soff = (((tl.y0 - 1) * a.IW + tl.x0 - 1) * sg.cstride + c0 + shift) * 4;
+        h_cs4 = (unsigned)sg.cstride * 4u;
+        h_cvalid = a.seg_channels - cc * 16 - oct * 8;             // > 0: this thread's octet exists (the last chunk of a segment may be half empty)
+    };
+    auto halo_slot = [&](int k) {
         // validity as ONE bitwise expression (a short-circuit && chain becomes per-lane branches around the loads, and the
         // register allocator then serialises the staging with vmcnt(0) waits)
-        const int cvalid = a.seg_channels - cc * 16 - oct * 8;     // > 0: this thread's octet exists (the last chunk of a segment may be half empty)
+        const int bad = (rk[k] - h_rlo) | (h_rhi - 1 - rk[k]) | (qk[k] - h_qlo) | (h_qhi - 1 - qk[k]) | (h_cvalid - 1);     // sign bit set <=> outside
+        const unsigned vo = bad < 0 ? OOB : __umul24(pixk[k], h_cs4) + oct * 32;
+        ra[k][0] = bload(h_rs, vo, h_soff);
+        ra[k][1] = bload(h_rs, vo, h_soff + 16);
+    };
+    auto load_halo = [&](const Tile& tl, int g) {
+        halo_prep(tl, g);
 #pragma unroll
-        for (int k = 0; k < NSLOT; ++k) {
-            const int bad = (rk[k] - rlo) | (rhi - 1 - rk[k]) | (qk[k] - qlo) | (qhi - 1 - qk[k]) | (cvalid - 1);     // sign bit set <=> outside
-            const unsigned vo = bad < 0 ? OOB : __umul24(pixk[k], cs4) + oct * 32;
-            ra[k][0] = bload(rs, vo, soff);
-            ra[k][1] = bload(rs, vo, soff + 16);
-        }
+        for (int k = 0; k < NSLOT; ++k) halo_slot(k);
     };
     // One of the 12 slices of the halo staging: split two floats of slot q/4 (pair q%4); after a slot's fourth pair its three
     // 16-byte words go to halo image `img`.  Sliced so that it can sit between MFMA groups (~12 VALU + at most 3 LDS stores each).
@@ -199,12 +203,11 @@ igemm_x3_kernel(const IgemmArgs a) {
     // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: per 32-channel block 9216 contiguous
     // bytes of the pack, as 1 KB pieces dealt over the 8 waves
     const int K16 = nchunks;
-    auto dma_weights = [&](const Tile& tl, int g, int tr, int st, bool valid = true) {
+    auto dma_piece = [&](const Tile& tl, int g, int tr, int st, bool valid, int i) {
 #ifdef X3_SKIP_DMA                // timing experiment only (wrong results): weights are never refreshed
         if (g + tr > 0) valid = false;
 #endif
-#pragma unroll
-        for (int i = 0; i < (Cfg::NDMA + NWAVE - 1) / NWAVE; ++i) {
+        {
             // wave-uniform piece; past the end a wave repeats the last piece (same bytes to the same place) instead of branching
             const int ins = min(wave + NWAVE * i, Cfg::NDMA - 1);
             const int j = ins / 9, r = ins - 9 * j;
@@ -214,6 +217,10 @@ igemm_x3_kernel(const IgemmArgs a) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + ins * 1024),
                                                      16, ok ? (unsigned)lane * 16u : OOB, soff, 0, 0);
         }
+    };
+    auto dma_weights = [&](const Tile& tl, int g, int tr, int st, bool valid = true) {
+#pragma unroll
+        for (int i = 0; i < Cfg::DPW; ++i) dma_piece(tl, g, tr, st, valid, i);
     };
 
     f32x16 acc[MT][NT];
@@ -228,7 +235,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     // chunk's halo (into image img ^ 1) are dealt over the 3 * MT * NT groups of six MFMAs.  `requests` (the LDS-DMA / halo
     // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right after the first group
     // of MFMAs has been issued rather than in front of the item's first LDS reads.
-    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto&& requests) {
+    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests) {
         constexpr bool FILL = decltype(fill_tag)::value;
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
@@ -271,12 +278,24 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     constexpr int NGRP = 3 * MT * NT, SPG = NSLICE / NGRP;   // staging slices per group (1 or 2)
+                    constexpr int NRD = 3 * (MT + NT), NGAP = 6 * MT * NT;     // operand reads of a tap; MFMA gaps of a tap
+                    constexpr int NHP = decltype(halo_tag)::value ? NSLOT + 1 : 0;     // halo pieces: the scalar part + one per slot
+                    constexpr int RSTEP = (NGAP - NRD) / (Cfg::DPW > NHP ? Cfg::DPW : NHP) > 0 ? (NGAP - NRD) / (Cfg::DPW > NHP ? Cfg::DPW : NHP) : 1;
+                    static_assert(NRD + RSTEP * ((Cfg::DPW > NHP ? Cfg::DPW : NHP) - 1) < NGAP, "request pieces must fit behind the reads");
                     static_assert(NSLICE % NGRP == 0, "slices per group");
                     const int gi = i * NT + j, grp = tp * MT * NT + gi;
 #define X3_MFMA(PA, PB) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[i][PA]), __builtin_bit_cast(bf16x8, bx[j][PB]), acc[i][j], 0, 0, 0)
+                    // the item's requests, one piece per gap, in the gaps behind the ones that carry the next tap's operand reads (an
+                    // LDS-DMA instruction issued among 12 ds_read_b128 costs 100-185 cycles of issue, in a read-free gap 25-60):
+                    // tap 0: the DPW weight pieces from gap NRD on, every RSTEP-th gap; tap 1: the halo pieces likewise
 #define X3_GAP(STEP) { const int m = gi * 6 + STEP;                                                                                  \
-                       if (tp + 1 < 3 && m < 3 * (MT + NT)) next_read(tp + 1, m, av[(tp + 1) & 1], bv[(tp + 1) & 1]);                \
+                       if (tp + 1 < 3 && m < NRD) next_read(tp + 1, m, av[(tp + 1) & 1], bv[(tp + 1) & 1]);                          \
                        if constexpr (FILL) { _Pragma("unroll") for (int u = 0; u < SPG; ++u) stage_piece(grp * SPG + u, u, STEP, img ^ 1); } \
+                       if (m >= NRD && (m - NRD) % RSTEP == 0) {                                                                     \
+                           const int rp = (m - NRD) / RSTEP;                                                                         \
+                           if (tp == 0 && rp < Cfg::DPW) requests(rp);                                                              \
+                           if (tp == 1 && rp < NHP) requests(Cfg::DPW + rp);                                                        \
+                       }                                                                                                             \
                        __builtin_amdgcn_sched_barrier(0); }
                     // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
                     X3_MFMA(0, 2); X3_GAP(0)
@@ -287,10 +306,6 @@ igemm_x3_kernel(const IgemmArgs a) {
                     X3_MFMA(0, 0); X3_GAP(5)
 #undef X3_GAP
 #undef X3_MFMA
-                    if (tp == 0 && i == 0 && j == 0) {
-                        requests();
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
         }
 #else
@@ -310,7 +325,8 @@ igemm_x3_kernel(const IgemmArgs a) {
 #undef X3_MFMA
                     if (tp == 0 && i == 0 && j == 0) {
                         __builtin_amdgcn_sched_barrier(0);
-                        requests();
+#pragma unroll
+                        for (int rp = 0; rp < Cfg::DPW + (decltype(halo_tag)::value ? NSLOT + 1 : 0); ++rp) requests(rp);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                     if constexpr (FILL) {
@@ -535,21 +551,22 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_T(tw)
             __syncthreads();
             X3_T(tb)
-            mfma_row(0, st, img, std::false_type{}, [&] { dma_weights(cur, g, 1, st ^ 1); load_halo(n1.tile, n1.g); });
+            mfma_row(0, st, img, std::false_type{}, std::true_type{}, [&](int rp) {
+                if (rp < D) dma_piece(cur, g, 1, st ^ 1, true, rp); else if (rp == D) halo_prep(n1.tile, n1.g); else halo_slot(rp - D - 1); });
             X3_T(tm)
             // ---- filter row 1
             __builtin_amdgcn_s_waitcnt(0x0f70 | HL);                    // the weights of row 1; the halo loads stay in flight
             X3_T(tw)
             __syncthreads();
             X3_T(tb)
-            mfma_row(1, st ^ 1, img, std::false_type{}, [&] { dma_weights(cur, g, 2, st); });
+            mfma_row(1, st ^ 1, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, st, true, rp); });
             X3_T(tm)
             // ---- filter row 2 (+ the next chunk's halo: registers -> split -> image img^1, between the MFMAs)
             __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: wait for all
             X3_T(tw)
             __syncthreads();
             X3_T(tb)
-            mfma_row(2, st, img, std::true_type{}, [&] { dma_weights(n1.tile, n1.g, 0, st ^ 1, n1.ok); });
+            mfma_row(2, st, img, std::true_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); });
             X3_T(tm)
             if (g == nchunks - 1) {
                 __syncthreads();                                        // every wave has finished reading stage st: it holds the epilogue patches now
@@ -582,15 +599,15 @@ igemm_x3_kernel(const IgemmArgs a) {
             // ---- row 0: outstanding [w row 0][w row 1][halo next]
             __builtin_amdgcn_s_waitcnt(0x0f70 | (D + HL));
             __syncthreads();
-            mfma_row(0, 0, img, std::false_type{}, [&] { dma_weights(cur, g, 2, 2); });
+            mfma_row(0, 0, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); });
             // ---- row 1: outstanding [w row 1][halo next][w row 2]
             __builtin_amdgcn_s_waitcnt(0x0f70 | (HL + D));
             __syncthreads();
-            mfma_row(1, 1, img, std::false_type{}, [&] { dma_weights(n1.tile, n1.g, 0, 0, n1.ok); });
+            mfma_row(1, 1, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); });
             // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
             __builtin_amdgcn_s_waitcnt(0x0f70 | D);
             __syncthreads();
-            mfma_row(2, 2, img, std::true_type{}, [&] { dma_weights(n1.tile, n1.g, 1, 1, n1.ok); });
+            mfma_row(2, 2, img, std::true_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); });
             load_halo(n2.tile, n2.g);
             if (g == nchunks - 1) epilogue(cur, epi_sep);
             if (!n1.ok) break;

@@ -40,14 +40,15 @@ def main():
     kinds = a.only.split(',')
     res = {}
     for name, H, C1, C2, Co in layers:
-        x1 = torch.randn(B, H, H, C1, device=dev)
-        x2 = torch.randn(B, H, H, C2, device=dev) if C2 else None
-        w = torch.randn(Co, C1 + C2, 3, 3, device=dev) * 0.05
+        zs = 0.0 if os.environ.get('LB_ZEROS') else 1.0      # LB_ZEROS=1: all-zero operands (same instructions, less switching power: the clock effect)
+        x1 = torch.randn(B, H, H, C1, device=dev) * zs
+        x2 = torch.randn(B, H, H, C2, device=dev) * zs if C2 else None
+        w = torch.randn(Co, C1 + C2, 3, 3, device=dev) * 0.05 * zs
         bias = torch.randn(Co, device=dev)
         f = torch.empty(w.numel(), device=dev); d = torch.empty(w.numel(), device=dev)
         ops.pack_conv_weight(w, f, d)
         y = torch.empty(B, H, H, Co, device=dev)
-        g = torch.randn(B, H, H, Co, device=dev)
+        g = torch.randn(B, H, H, Co, device=dev) * zs
         dx1 = torch.empty_like(x1); dx2 = torch.empty_like(x2) if C2 else None
         dW = torch.empty_like(w); db = torch.empty(Co, device=dev)
         ws = torch.empty(ops.wgrad_workspace_floats(B, H, H, Co, C1 + C2, 9), device=dev)
