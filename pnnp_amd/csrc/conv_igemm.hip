@@ -231,7 +231,6 @@ igemm_kernel(const IgemmArgs a) {
                 const int cs = a.dst_cs[d], mmode = a.mask_mode[d], accum = a.accum[d];
                 float4 bias = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (a.bias && n_ok) bias = *reinterpret_cast<const float4*>(a.bias + nn);
-                const float* addsrc = (d == 0) ? a.addsrc : nullptr;
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const int py = y0 + wm * MT + i;

@@ -27,7 +27,7 @@
 namespace {
 
 constexpr int TS = 32, HS = TS + 2;            // output tile, tile + halo 1
-constexpr int P_W1 = 0, P_B1 = 72, P_G1 = 76, P_BE1 = 80, P_W2 = 84, P_B2 = 100, P_G2 = 104, P_BE2 = 108, P_W3 = 112, P_B3 = 292,
+[[maybe_unused]] constexpr int P_W1 = 0, P_B1 = 72, P_G1 = 76, P_BE1 = 80, P_W2 = 84, P_B2 = 100, P_G2 = 104, P_BE2 = 108, P_W3 = 112, P_B3 = 292,
               P_LOGS = 296, P_SCALE = 300;
 constexpr float BN_EPS = 1e-5f;
 
