@@ -272,6 +272,7 @@ int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, flo
  *   head forward:  out NCHW [B][cout][H][W] = bias + x W^T (+ residual NCHW)   -- replaces the 1x1 GEMM + pnnp_nhwc_to_nchw_f32
  *   head backward: gx = (g W) * act'(x) [mode 0 none / 1 LeakyReLU(0.2) / 2 ReLU; x is the activation output],
  *                  dW [cout][cin] and dbias [cout] (+)= in the same pass over x and g (g: first cout of gcs >= 4 channels)
+ *   first forward: y [B][H][W][ycs] = act(conv3x3(x) + bias), the 4 input channels NOT padded to a GEMM chunk
  *   first backward-weight: dW [cout][cin][3][3], dbias (+)=; x [B][H][W][xcs] must be ZERO in channels cin .. 3.
  * *_supported() say whether these kernels take the layer (else use pnnp_conv_* with taps 1 / 9); ws >= *_workspace_floats(). */
 int pnnp_head_supported(int cin, int cout, int64_t npix);
@@ -283,6 +284,8 @@ int pnnp_head_bwd_f32(const float* g, int gcs, const float* x, int xcs, int cin,
                       void* stream);
 int pnnp_first_wgrad_supported(int cin, int cout, int H, int W);
 int64_t pnnp_first_wgrad_workspace_floats(int cout);
+int pnnp_first_fwd_f32(const float* x, int xcs, int cin, const float* w /*[cout][cin][3][3]*/, const float* bias /*or null*/, float* y, int ycs,
+                       int B, int H, int W, int cout, int act /*0 none, 1 LeakyReLU(0.2), 2 ReLU*/, void* stream);
 int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x, int xcs, int cin, float* dW, float* dbias /*or null*/,
                               int B, int H, int W, int accumulate, float* ws, int64_t ws_floats, void* stream);
 /* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);

@@ -195,7 +195,10 @@ class ResUnetEngine(_EngineBase):
         hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
         a = {}
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad)
-        a['t0'] = self._cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
+        if self.policy.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
+            a['t0'] = ops.first_fwd(a['x8'], P['conv_in.weight'], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), RELU)
+        else:
+            a['t0'] = self._cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
         xin = a['t0']
         for l in range(1, 6):
             lv = l - 1

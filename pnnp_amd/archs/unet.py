@@ -304,7 +304,11 @@ class UNetEngine(_EngineBase):
         cur = a['x8']
         for lvl in range(5):               # encoder: conv{l}_1, conv{l}_2, pool
             i = lvl + 1
-            a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
+            if lvl == 0 and self.policy.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
+                # conv1_1 on the streaming kernel: its 4 input channels are not worth a (padded) GEMM chunk
+                a['c1a'] = ops.first_fwd(cur, P['conv1_1.weight'], P['conv1_1.bias'], g('conv1_1', (B, H, W, ch[0])), LRELU)
+            else:
+                a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
             if lvl == 4:
                 a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
                 continue

@@ -284,6 +284,88 @@ first_wgrad_kernel(FirstW a) {
     }
 }
 
+// First layer FORWARD: y[pix][co] = act(bias[co] + sum_{tap, ci} x[pix + tap][ci] * w[co][ci][tap]).  Same tile, LDS image and sliding
+// 4-row x 3-column window as the backward-weight kernel above; lane = output channel with its 36 weights in registers (as (ci0, ci1) /
+// (ci2, ci3) pairs per tap), 18 packed FMAs per pixel into one pair of partial sums.  A pixel's CO outputs are one or two whole cache
+// lines.  On the bf16x3 GEMM kernel the 4 input channels were padded to a 16-channel chunk: 4x the matrix work for this layer.
+struct FirstF {
+    const float* x; const float* w; const float* bias; float* y;
+    int B, H, W, xcs, ycs, cin, act, tiles_w, ntiles;
+};
+
+template <int CO>
+__global__ void __launch_bounds__(256)
+first_fwd_kernel(FirstF a) {
+    constexpr int NS = 256 / CO, TR = 2 * NS;
+    constexpr int NX = (TR + 2) * FW_LW, NLD = (NX + 255) / 256;
+    __shared__ f32x4 xt[NX];
+    const int co = threadIdx.x % CO, st = threadIdx.x / CO;
+    f32x2 wq[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int c0 = 2 * h, c1 = 2 * h + 1;
+            wq[t][h] = f32x2{c0 < a.cin ? a.w[(co * a.cin + c0) * 9 + t] : 0.f, c1 < a.cin ? a.w[(co * a.cin + c1) * 9 + t] : 0.f};
+        }
+    const float bs = a.bias ? a.bias[co] : 0.f;
+    const float slope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
+    const int tiles_h = a.H / TR;
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % tiles_h, b = tile / (a.tiles_w * tiles_h);
+        const int h0 = th * TR, w0 = tw * FW_TW;
+        const int nw = min(FW_TW, a.W - w0);
+        f32x4 stage[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            const int r = i / FW_LW, c = i % FW_LW;
+            const int h = h0 - 1 + r, w = w0 - 1 + c;
+            stage[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (i < NX && h >= 0 && h < a.H && w >= 0 && w < a.W)
+                stage[k] = *reinterpret_cast<const f32x4*>(a.x + (((int64_t)b * a.H + h) * a.W + w) * a.xcs);
+        }
+        __syncthreads();                        // the previous tile's readers are done
+#pragma unroll
+        for (int k = 0; k < NLD; ++k)
+            if (threadIdx.x + 256 * k < NX) xt[threadIdx.x + 256 * k] = stage[k];
+        __syncthreads();
+        float* y0 = a.y + (((int64_t)b * a.H + h0 + 2 * st) * a.W + w0) * a.ycs + co;
+        float* y1 = y0 + (int64_t)a.W * a.ycs;
+        const f32x4* xr = xt + 2 * st * FW_LW;
+        f32x4 s0[4], s1[4], s2[4];               // window columns; slot = (tile column + 1) % 3
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { s2[r] = xr[r * FW_LW + 0]; s0[r] = xr[r * FW_LW + 1]; s1[r] = xr[r * FW_LW + 2]; }
+        auto pixels = [&](const f32x4 (&l)[4], const f32x4 (&c)[4], const f32x4 (&r)[4], int col) {
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const f32x4 xl = l[row + kh], xc = c[row + kh], xg = r[row + kh];
+                    acc += f32x2{xl[0], xl[1]} * wq[kh * 3 + 0][0]; acc += f32x2{xl[2], xl[3]} * wq[kh * 3 + 0][1];
+                    acc += f32x2{xc[0], xc[1]} * wq[kh * 3 + 1][0]; acc += f32x2{xc[2], xc[3]} * wq[kh * 3 + 1][1];
+                    acc += f32x2{xg[0], xg[1]} * wq[kh * 3 + 2][0]; acc += f32x2{xg[2], xg[3]} * wq[kh * 3 + 2][1];
+                }
+                float v = (acc[0] + acc[1]) + bs;
+                v = fmaxf(v, slope * v);
+                if (col < nw) (row ? y1 : y0)[(int64_t)col * a.ycs] = v;
+            }
+        };
+        for (int w = 0; w < FW_TW; w += 3) {
+            pixels(s2, s0, s1, w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s2[r] = xr[r * FW_LW + w + 3];
+            pixels(s0, s1, s2, w + 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s0[r] = xr[r * FW_LW + w + 4];
+            pixels(s1, s2, s0, w + 2);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1[r] = xr[r * FW_LW + w + 5];
+        }
+    }
+}
+
 // Sum of the per-workgroup partials in a fixed order, scattered to the torch layouts.
 //   kind 0 (head):  o < 4*cin: dW[co][ci] with co = o / cin;  then db[o - 4*cin]                    (rows co >= cout dropped)
 //   kind 1 (first): o = k * CO + co, k = tap * 4 + ci < 36: dW[co][ci][tap] (ci >= cin dropped);  k = 36: db[co]
@@ -398,6 +480,23 @@ int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x,
     if (cout == 32) hipLaunchKernelGGL(first_wgrad_kernel<32>, grid, blk, 0, as_stream(stream), a);
     else hipLaunchKernelGGL(first_wgrad_kernel<64>, grid, blk, 0, as_stream(stream), a);
     hipLaunchKernelGGL(thin_reduce_kernel, dim3(ceil_div(np, 64)), dim3(1024), 0, as_stream(stream), ws, blocks, np, 1, cin, cout, dW, dbias, accumulate);
+    return pnnp_launch_status();
+}
+
+// y [B][H][W][ycs] (first cout channels) = act(conv3x3(x; w [cout][cin][3][3]) + bias): the first layer's forward (archs/Unet.py:31-33).
+// x [B][H][W][xcs] with channels cin .. 3 of every pixel ZERO; act 0 none / 1 LeakyReLU(0.2) / 2 ReLU.  pnnp_first_wgrad_supported()
+// says whether the layer qualifies.
+int pnnp_first_fwd_f32(const float* x, int xcs, int cin, const float* w, const float* bias, float* y, int ycs, int B, int H, int W, int cout,
+                       int act, void* stream) {
+    if (!x || !w || !y || B < 0 || H <= 0 || W <= 0 || (xcs & 3) || xcs < 4 || ycs < cout || act < 0 || act > 2) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    if (!pnnp_first_wgrad_supported(cin, cout, H, W)) return PNNP_E_UNSUPPORTED;
+    const int tr = 512 / cout;
+    FirstF a{x, w, bias, y, B, H, W, xcs, ycs, cin, act, ceil_div(W, FW_TW), 0};
+    a.ntiles = B * (H / tr) * a.tiles_w;
+    const dim3 grid(thin_blocks(a.ntiles, FW_PER_CU)), blk(256);
+    if (cout == 32) hipLaunchKernelGGL(first_fwd_kernel<32>, grid, blk, 0, as_stream(stream), a);
+    else hipLaunchKernelGGL(first_fwd_kernel<64>, grid, blk, 0, as_stream(stream), a);
     return pnnp_launch_status();
 }
 

@@ -446,6 +446,16 @@ def first_wgrad_workspace_floats(cout):
     return int(_prep().pnnp_first_wgrad_workspace_floats(int(cout)))
 
 
+def first_fwd(x, weight, bias, y, act):
+    """y [B,H,W,>=cout] = act(conv3x3(x [B,H,W,xcs>=4], zero in channels cin..3; weight [cout,cin,3,3]) + bias) on the streaming kernel."""
+    require_cuda(x, weight, y)
+    B, H, W, xcs = x.shape
+    cout, cin = weight.shape[0], weight.shape[1]
+    with _Timed('first_fwd', 2.0 * B * H * W * cout * cin * 9, 4.0 * B * H * W * (cin + cout)):
+        check(_prep().pnnp_first_fwd_f32(ptr(x), xcs, cin, ptr(weight), ptr(bias), ptr(y), y.shape[3], B, H, W, cout, act, stream()), 'first_fwd')
+    return y
+
+
 def first_bwd_weight(g, cout, x, cin, dW, dbias, ws, accumulate=0):
     """dW [cout,cin,3,3], dbias (+)= for the first 3x3 convolution: x [B,H,W,xcs>=4] zero in channels cin..3, g [B,H,W,>=cout]."""
     require_cuda(g, x, dW, ws)

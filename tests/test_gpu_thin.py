@@ -90,3 +90,21 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
     x = torch.zeros(1, 16, 16, 24, device='cuda'); w = torch.zeros(4, 24, 1, 1, device='cuda')
     with pytest.raises(PnnpError):
         ops.head_fwd(x, w, torch.zeros(4, device='cuda'), torch.zeros(1, 4, 16, 16, device='cuda'))
+
+
+@pytest.mark.parametrize('cin,cout,act', [(4, 32, 1), (3, 32, 2), (4, 64, 0), (1, 32, 1)])
+@pytest.mark.parametrize('shape', [(1, 16, 16), (3, 64, 112), (2, 32, 48)])
+def test_first_layer_forward(cin, cout, act, shape):
+    from pnnp_amd import ops
+    B, H, W = shape
+    gen = torch.Generator(device='cuda').manual_seed(cin * 10 + cout + act)
+    x8 = torch.zeros(B, H, W, 8, device='cuda')
+    x8[..., :cin] = torch.randn(B, H, W, cin, device='cuda', generator=gen)
+    w = torch.randn(cout, cin, 3, 3, device='cuda', generator=gen) * 0.3
+    b = torch.randn(cout, device='cuda', generator=gen)
+    y = torch.full((B, H, W, cout + 4), float('nan'), device='cuda')         # channel stride > cout: the tail stays untouched
+    ops.first_fwd(x8, w, b, y, act)
+    ref = F.conv2d(x8[..., :cin].permute(0, 3, 1, 2).double(), w.double(), b.double(), padding=1)
+    ref = {0: ref, 1: F.leaky_relu(ref, 0.2), 2: F.relu(ref)}[act].permute(0, 2, 3, 1)
+    assert _rel(y[..., :cout], ref) < 2e-6
+    assert torch.isnan(y[..., cout:]).all()
