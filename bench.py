@@ -43,31 +43,71 @@ FAMILY = {
 }
 
 
-def cpu_baseline(H, W):
+def physical_cores():
+    """Physical cores of this host (unique (package, core) pairs of /proc/cpuinfo; psutil as a second opinion)."""
+    try:
+        pairs, phys, core = set(), None, None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                phys = line.split(':')[1].strip()
+            elif line.startswith('core id'):
+                core = line.split(':')[1].strip()
+            elif not line.strip():
+                if phys is not None and core is not None:
+                    pairs.add((phys, core))
+                phys = core = None
+        if pairs:
+            return len(pairs)
+    except OSError:
+        pass
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return n
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def cpu_baseline(H, W, budget_s=90.0):
     """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py + oracle/noise_np.py), timed on this
-    box's host cores as BASELINE.md section 3 plans it, bounded to ~30 s: per crop `sample_params_max('SonyA7S2')` ->
-    `generate_noisy_torch('pr', clip=2)` -> clamp -> UNetSeeInDark nf=32 forward -> L1(clamp) -> backward -> Adam,
-    `np.random.seed(1997 + step)`, one warm-up step + two timed steps per leg:
-      * all cores (torch.set_num_threads(min(cpu_count, 32))) on B = 4 crops of 4 x H x W   -> `value`
-      * one thread (the reference exports OMP_NUM_THREADS=1, utils/utils.py:2) on B = 1 crop -> `one_thread`
+    box's host cores by the protocol of BASELINE.md section 3: per crop `sample_params_max('SonyA7S2')` ->
+    `generate_noisy_torch('pr', clip=2)` -> clamp -> UNetSeeInDark nf=32 forward -> L1(clamp) -> backward -> Adam(lr 1e-4),
+    `np.random.seed(1997 + step)`, `torch.manual_seed(1997)`, 2 warm-up + 5 timed steps per leg:
+      * all PHYSICAL cores (torch.set_num_threads(physical_cores())) on B = 16 crops of 4 x H x W   -> `value`
+      * one thread (the reference exports OMP_NUM_THREADS=1, utils/utils.py:2) on B = 1 crop        -> `one_thread`
     with the four buckets the reference's tqdm line shows (trainer_SID.py:81-123): dataloader (here: synthetic clean crops),
-    preprocess (parameters + sampler + clamp), net (forward), bp (loss + backward + Adam)."""
+    preprocess (parameters + sampler + clamp), net (forward), bp (loss + backward + Adam).
+    Bounded by `budget_s` seconds (--cpu-baseline-seconds; 3/4 for the all-cores leg, 1/4 for the one-thread leg): a leg that
+    runs out of budget stops after the step in progress -- warm-ups first, at least one timed step -- and the record says how
+    many warm-up / timed steps it actually did (`protocol_complete` false), instead of silently shrinking the sample."""
     import numpy as np
     import torch
     from oracle import net_torch as O, noise_np as N
     from pnnp_amd import process as P                      # host-side parameter tables / draws (no device code)
     ncpu = os.cpu_count() or 1
-    all_cores = min(ncpu, 32)                              # more threads than this slow torch-CPU convs down on big hosts
+    all_cores = physical_cores()
 
-    def leg(threads, batch, warm, timed):
+    def leg(threads, batch, warm, timed, budget):
         torch.set_num_threads(threads)
         torch.manual_seed(1997)
         sd = O.init_state(O.unet_param_shapes(nf=32), seed=0)
         m = {k: torch.zeros_like(v) for k, v in sd.items()}
         v = {k: torch.zeros_like(vv) for k, vv in sd.items()}
         buckets = dict(dataloader=0.0, preprocess=0.0, net=0.0, bp=0.0)
-        total = 0.0
-        for step in range(1, warm + timed + 1):
+        total, done_warm, done_timed = 0.0, 0, 0
+        t_leg = time.perf_counter()
+        step = 0
+        while True:
+            left = budget - (time.perf_counter() - t_leg)
+            if done_warm < warm and (left > 0 or done_warm == 0):
+                is_warm = True                              # warm-ups first; at least one even when the budget is tiny
+            elif done_timed < timed and (left > 0 or done_timed == 0):
+                is_warm = False                             # then timed steps while the budget lasts; at least one
+            else:
+                break
+            step += 1
             np.random.seed(1997 + step)
             t = [time.perf_counter()]
             hr = torch.rand(batch, 4, H, W)
@@ -88,14 +128,18 @@ def cpu_baseline(H, W):
             with torch.no_grad():
                 O.adam_step(sd, {k: w.grad for k, w in leaves.items()}, m, v, step, lr=1e-4)
             t.append(time.perf_counter())
-            if step > warm:
-                for k, a, b in (('dataloader', 0, 1), ('preprocess', 1, 2), ('net', 2, 3), ('bp', 3, 4)):
-                    buckets[k] += t[b] - t[a]
-                total += t[4] - t[0]
-        return batch * timed / total, total, {k: round(val / timed, 3) for k, val in buckets.items()}
+            if is_warm:
+                done_warm += 1
+                continue
+            done_timed += 1
+            for k, a, b in (('dataloader', 0, 1), ('preprocess', 1, 2), ('net', 2, 3), ('bp', 3, 4)):
+                buckets[k] += t[b] - t[a]
+            total += t[4] - t[0]
+        return dict(value=batch * done_timed / total, timed_s=total, warmup_steps=done_warm, timed_steps=done_timed, batch=batch, threads=threads,
+                    split={k: round(val / done_timed, 3) for k, val in buckets.items()})
 
-    v_all, t_all, split_all = leg(all_cores, 4, 1, 2)
-    v_one, t_one, split_one = leg(1, 1, 1, 2)
+    A = leg(all_cores, 16, 2, 5, 0.75 * budget_s)
+    O1 = leg(1, 1, 2, 5, 0.25 * budget_s)
     torch.set_num_threads(all_cores)
     # the dataloader-side sampler (generate_noisy_obs: numpy, one core, as a DataLoader worker runs it), one crop per code
     obs = {}
@@ -108,12 +152,18 @@ def cpu_baseline(H, W):
         t0 = time.perf_counter()
         N.generate_noisy_obs(y, param=pn, noise_code=code, ori=False, clip=False)
         obs[code] = round(time.perf_counter() - t0, 3)
-    return {"value": v_all, "unit": "crops/s", "cores": all_cores, "kind": "port",
-            "sample": (f"UNet nf=32 train step (sample_params_max + generate_noisy_torch 'pr' clip=2 + fwd/L1/bwd/Adam), 1 warm-up + 2 timed steps: "
-                       f"{all_cores} threads on 4 crops of 4x{H}x{W} ({t_all:.1f} s timed) and 1 thread on 1 crop ({t_one:.1f} s timed), "
-                       f"torch {torch.__version__} CPU fp32, host has {ncpu} logical CPUs"),
-            "split_s_per_step": split_all,
-            "one_thread": {"value": v_one, "unit": "crops/s", "cores": 1, "split_s_per_step": split_one},
+    complete = (A['warmup_steps'], A['timed_steps'], O1['warmup_steps'], O1['timed_steps']) == (2, 5, 2, 5)
+    return {"value": A['value'], "unit": "crops/s", "cores": all_cores, "kind": "port",
+            "sample": (f"UNet nf=32 train step (sample_params_max + generate_noisy_torch 'pr' clip=2 + fwd/L1/bwd/Adam), BASELINE.md section 3 protocol "
+                       f"(2 warm-up + 5 timed steps) under a {budget_s:.0f} s budget: {all_cores} threads (all physical cores) on 16 crops of 4x{H}x{W}: "
+                       f"{A['warmup_steps']} warm-up + {A['timed_steps']} timed steps, {A['timed_s']:.1f} s timed; 1 thread on 1 crop: "
+                       f"{O1['warmup_steps']} + {O1['timed_steps']} steps, {O1['timed_s']:.1f} s timed; "
+                       f"torch {torch.__version__} CPU fp32, host has {ncpu} logical CPUs / {all_cores} physical cores"),
+            "protocol_complete": complete, "budget_s": budget_s,
+            "warmup_steps": A['warmup_steps'], "timed_steps": A['timed_steps'], "batch": 16,
+            "split_s_per_step": A['split'],
+            "one_thread": {"value": O1['value'], "unit": "crops/s", "cores": 1, "batch": 1, "warmup_steps": O1['warmup_steps'],
+                           "timed_steps": O1['timed_steps'], "split_s_per_step": O1['split']},
             "generate_noisy_obs_1crop_1core_s": obs}
 
 
@@ -142,6 +192,9 @@ def main():
     ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
                     help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=90.0,
+                    help='time budget of the CPU baseline legs (BASELINE.md section 3 protocol: B=16, 2 warm-up + 5 timed steps, all physical cores + 1 thread); '
+                         'a leg that runs out stops early and says so')
     ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '
                     '(for rocprofv3 traces of the collective kernels on the side stream overlapping the backward pass)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline becomes whole-step)')
@@ -192,13 +245,18 @@ def main():
         proxy = proxy.to(dev).eval()
     net = net.to(dev)
     net.engine.set_policy(x3=args.family == 'x3', wino=args.family != 'direct')
-    ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
-                      rank=rank, world=world, force_reducer=(world == 1 and args.force_reducer))
     B, S = args.batch, args.size
-    if args.strong:
-        if B % world:
-            raise SystemExit(f'--strong: global batch {B} is not divisible by {world} ranks')
-        B //= world
+    global_batch = B * world
+    if args.strong:                             # one global batch split by shard_crops (remainders to the low ranks)
+        from pnnp_amd.trainer import shard_crops
+        global_batch = B
+        lo, hi = shard_crops(global_batch, rank, world)
+        B = hi - lo
+        if global_batch < world:
+            raise SystemExit(f'--strong: global batch {global_batch} is smaller than {world} ranks')
+    ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
+                      rank=rank, world=world, force_reducer=(world == 1 and args.force_reducer),
+                      global_batch=global_batch if args.strong else None)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     hr = torch.rand(B, 4, S, S, device=dev, generator=g)          # synthetic clean crops, resident in HBM
     hr_nf = hr * 0.01                                             # dark crops for the NoiseFlow proxy (clean/gain scale)
@@ -217,6 +275,7 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    ts._state(dev)                              # (with --warmup 0: the reducer exists before the timed region asks for its wait times)
     barrier()
     # HIP events on the launching stream: in the TIMED region only around the dominant kernel's launches (the `roofline` object);
     # the per-class table comes from a short un-timed pass afterwards, so that the headline number is not taxed by ~200 event
@@ -226,11 +285,18 @@ def main():
     dom_kinds = set(FAMILY[fam0][2])
     if not args.no_kernel_events:
         ops.PROFILE, ops.PROFILE_KINDS = [], dom_kinds
+    if ts.reducer is not None:
+        ts.reducer.time_waits = True            # one event pair per step around reducer.finish(): is the all-reduce hidden?
     t0 = time.perf_counter()
     for i in range(args.steps):
         loss = one_step(args.warmup + i)
+    torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0           # this rank's own time to finish its K steps (before the barrier)
     barrier()
     dt = time.perf_counter() - t0
+    waits = ts.reducer.wait_ms() if ts.reducer is not None else []
+    if ts.reducer is not None:
+        ts.reducer.time_waits = False
     prof, ops.PROFILE, ops.PROFILE_KINDS = ops.PROFILE, None, None
     prof_all, extra_steps = None, 3
     if not args.no_kernel_events:
@@ -240,26 +306,43 @@ def main():
         torch.cuda.synchronize()
         prof_all, ops.PROFILE = ops.PROFILE, None
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        # per-rank view for the scaling record: own ms/step and the compute stream's wait for the gradient all-reduce
+        mine = torch.tensor([1e3 * dt_own / args.steps, (sum(waits) / len(waits)) if waits else 0.0, max(waits) if waits else 0.0],
+                            dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu()
+    elif waits:
+        per_rank = torch.tensor([[1e3 * dt_own / args.steps, sum(waits) / len(waits), max(waits)]], dtype=torch.float64)
     dt = float(tmax.item())
     loss_val = float(loss[0])
     spread = ts.replica_checksum() if world > 1 else None      # 0.0: every rank holds bit-identical weights after the run
 
     if rank == 0:
-        crops = B * world * args.steps
+        crops = global_batch * args.steps
         value = crops / dt
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)" if pol.x3 else "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else "NoiseFlow.sample proxy (iso 6400, ratio in {1,2,4,8,16})") +
-                                   (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": B * world,
+                                   (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
             "final_loss": loss_val,
         }
         if spread is not None:
             out["replica_checksum_spread"] = spread
+        if per_rank is not None:
+            # is the gradient all-reduce hidden behind backward?  allreduce_wait = time the compute stream stood still in
+            # reducer.finish() (event pair on the compute stream), per step; ~0 when RCCL overlaps the remaining backward kernels
+            out["per_rank_ms_per_step"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()),
+                                           "all": [round(float(v), 4) for v in per_rank[:, 0]]}
+            out["allreduce_wait_ms_per_step"] = {"mean_min_over_ranks": float(per_rank[:, 1].min()), "mean_max_over_ranks": float(per_rank[:, 1].max()),
+                                                 "worst_step_any_rank": float(per_rank[:, 2].max()),
+                                                 "bucket_bytes": ts.bucket_bytes, "grad_bytes": int(net.engine.params.grad.numel() * 4)}
         step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
         classes = {}
         if prof:
@@ -314,7 +397,7 @@ def main():
                                "kernel": "not measured (--no-kernel-events)", "step_algorithmic_tflops": step_tflops}
         out["step_tflops_per_gpu"] = step_tflops
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(S, S)
+            out["cpu_baseline"] = cpu_baseline(S, S, args.cpu_baseline_seconds)
         # RCCL prints its version banner through C stdio (block-buffered when piped): push that out first so that the JSON line is the
         # last line on stdout, then keep the communicator alive until after the print (its teardown prints nothing)
         import ctypes

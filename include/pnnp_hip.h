@@ -170,6 +170,15 @@ int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const
  * pnnp_conv_bwd_data_res_f32 with taps = 9 (archs/Unet.py:16-52,54-92; archs/modules.py:176-197); the weights are x3 packs:
  * kind-2 jobs of the pack table, pnnp_x3_weight_bytes(K, N) bytes each (K = channels reduced over, N = channels written). */
 int pnnp_x3_supported(int K, int N);
+/* size limit of the bf16x3 forward / backward-data / pointwise kernels: one image [H][W][cstride] of every map they touch must
+ * fit a 32-bit byte offset ((H + 4) W cstride 4 < 2^31); beyond it the launchers return PNNP_E_UNSUPPORTED -- ask first and run the
+ * layer on the fp32-MFMA families (pnnp_conv_* / pnnp_conv3x3_wino_*), which the Python engines do.
+ * bf16x3 dynamic range: a piece is a bf16, which has float32's exponent range, so for 2^-110 (7.7e-34) <= |a| <= float32 max all
+ * three pieces are normal numbers and hi + mid + lo == a exactly; below that the lo (then mid) piece becomes a bf16 subnormal and
+ * may be flushed by the matrix core: accuracy degrades gracefully to 16 (8) significand bits, never to garbage
+ * (tests/test_gpu_x3.py::test_x3_dynamic_range, ::test_x3_below_the_supported_range_degrades_gracefully).  Products and sums are
+ * float32 and obey float32's own range. */
+int pnnp_x3_image_fits(int H, int W, int cstride);
 int64_t pnnp_x3_weight_bytes(int K, int N);
 int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/,
                           int Cout, int Cin, int Cin_pad);
@@ -207,6 +216,8 @@ int pnnp_conv3x3s2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_s2
 /* backward-weight of the same layers (csrc/wgrad_x3.hip; pixel-major LDS images read with ds_read_b64_tr_b16): same contract
  * as pnnp_conv_bwd_weight_f32 with taps = 9; channel counts in multiples of 32; workspace from the query. */
 int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2);
+/* its size limit: the WHOLE batch of a map [B][H][W][cstride] must fit a 32-bit byte offset ((B H + 2) W cstride 4 < 2^31) */
+int pnnp_x3_wgrad_fits(int B, int H, int W, int cstride);
 int64_t pnnp_x3_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
 int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
                                    const float* x2 /*or null*/, int x2_cs, int C2, float* dW, float* dbias /*or null*/,

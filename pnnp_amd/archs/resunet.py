@@ -67,7 +67,7 @@ class ResUnetEngine(_EngineBase):
         and runs in a few launches per step (ops.PackJobs)."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
-        key = (dev, train, self.policy.key(), tuple(p.data_ptr() for p in P.values()))
+        key = (dev, train, self._pol.key(), tuple(p.data_ptr() for p in P.values()))
         if self._jobs_key != key:
             self._jobs, self._jobs_key = self._build_pack_jobs(train, dev, P), key
         self._jobs.run()
@@ -82,9 +82,9 @@ class ResUnetEngine(_EngineBase):
             t = kh * kw
             cip = cin_pad or ci
             bwd = train and dgrad
-            xf, xd = self.policy.use_x3(co, cip, t, c1)
+            xf, xd = self._pol.use_x3(co, cip, t, c1)
             xd = xd and bwd
-            p1 = t == 1 and self.policy.use_x3_pointwise(ci, co) and self.policy.use_x3_pointwise(co, ci) and (c1 is None or c1 % 32 == 0)
+            p1 = t == 1 and self._pol.use_x3_pointwise(ci, co) and self._pol.use_x3_pointwise(co, ci) and (c1 is None or c1 % 32 == 0)
             if p1:                                                     # 1x1 (ResidualBlock shortcut) on the pointwise bf16x3 kernel
                 x3f = self._buf(name + ':x3f', ops.x3mat_bytes(ci, co), dev, torch.uint8)
                 x3d = self._buf(name + ':x3d', ops.x3mat_bytes(co, ci), dev, torch.uint8) if bwd else None
@@ -118,7 +118,7 @@ class ResUnetEngine(_EngineBase):
         for l in range(1, 5):
             w = P[f'pool{l}.conv.weight']
             co, ci = w.shape[0], w.shape[1]
-            if self.policy.use_x3_pointwise(ci, co) and self.policy.use_x3_pointwise(co, ci):      # stride-2 conv on the pointwise bf16x3 kernel
+            if self._pol.use_x3_pointwise(ci, co) and self._pol.use_x3_pointwise(co, ci):      # stride-2 conv on the pointwise bf16x3 kernel
                 f = self._buf(f'pool{l}:x3f', ops.x3mat_bytes(9 * ci, co), dev, torch.uint8)
                 d = self._buf(f'pool{l}:x3d', 9 * ops.x3mat_bytes(co, ci), dev, torch.uint8) if train else None
                 jobs.add_x3_s2(w, f, d)
@@ -134,7 +134,7 @@ class ResUnetEngine(_EngineBase):
         for i in range(6, 10):
             w = P[f'upv{i}.weight']
             ci, co = w.shape[0], w.shape[1]
-            if self.policy.use_x3_pointwise(ci, 4 * co) and self.policy.use_x3_pointwise(co, ci):
+            if self._pol.use_x3_pointwise(ci, 4 * co) and self._pol.use_x3_pointwise(co, ci):
                 f = self._buf(f'upv{i}:x3f', ops.x3mat_bytes(ci, 4 * co), dev, torch.uint8)
                 d = self._buf(f'upv{i}:x3d', ops.x3mat_bytes(4 * co, ci), dev, torch.uint8) if train else None
                 jobs.add_x3_convt(w, f, d)
@@ -150,7 +150,7 @@ class ResUnetEngine(_EngineBase):
 
     def _wino(self, co, ci, taps=9):
         """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  Same rule as the UNet engine (self.policy)."""
-        return self.policy.use_wino(co, ci, taps)
+        return self._pol.use_wino(co, ci, taps)
 
     def _cf(self, name, src, src2, bias, out, cout, act, residual=None):
         """3x3 forward: bf16x3 / Winograd kernel where packed for it, else the direct implicit GEMM."""
@@ -183,7 +183,8 @@ class ResUnetEngine(_EngineBase):
         self.params.ensure(dev)
         # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
         # tensor._version, the fused Adam kernel goes through mark_dirty()
-        key = (train, dev, self._dirty_epoch) + tuple(p._version for p in self.m.parameters())
+        self._pol = self.effective_policy(H, Wd, max(self.ch[0], self.cin_pad, self.cout_pad))
+        key = (train, dev, self._dirty_epoch, self._pol.key()) + tuple(p._version for p in self.m.parameters())
         if key != self._pack_key:
             self.pack_weights(train)
             self._pack_key = key
@@ -195,7 +196,7 @@ class ResUnetEngine(_EngineBase):
         hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
         a = {}
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad)
-        if self.policy.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
+        if self._pol.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
             a['t0'] = ops.first_fwd(a['x8'], P['conv_in.weight'], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), RELU)
         else:
             a['t0'] = self._cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
@@ -231,18 +232,20 @@ class ResUnetEngine(_EngineBase):
             a[f'c{i}'] = self._cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
             cur = a[f'c{i}']
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
-        if self.policy.use_thin_head(ch[0], self.cout, B * H * Wd):
+        if self._pol.use_thin_head(ch[0], self.cout, B * H * Wd):
             ops.head_fwd(a['c9'], P['conv10.weight'], P['conv10.bias'], out, residual=x if self.m.res else None)
         else:
             o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
             ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
+            a['_pol'] = self._pol
             self.saved = (a, (B, H, Wd, dev), gen)
         return out
 
     # ---------------------------------------------------------------- backward
     def backward(self, g_out8, need_dx=False, accumulate=False, on_ready=None):
         a, (B, H, Wd, dev), _ = self.saved
+        self._pol = a['_pol']            # the kernel families this forward ran on (effective_policy)
         bufs = self.bufs[(B, H, Wd, dev)]
         ch, W = self.ch, self.W
         gb = lambda n, like: bufs.get('g_' + n, like.shape, dev)
@@ -257,16 +260,17 @@ class ResUnetEngine(_EngineBase):
 
         def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
             c2 = x2.shape[3] if x2 is not None else 0
-            if taps == 9 and self.policy.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2):
+            if taps == 9 and self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=gpre.shape[0],
+                                                    cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
-            elif taps == 9 and self.policy.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
+            elif taps == 9 and self._pol.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             else:
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
 
         # head
         g = gb('c9', a['c9'])
-        if self.policy.use_thin_head(ch[0], self.cout, B * H * Wd):
+        if self._pol.use_thin_head(ch[0], self.cout, B * H * Wd):
             ops.head_bwd(g_out8, a['c9'], P['conv10.weight'], g, G('conv10.weight'), G('conv10.bias'), wsf, mode=0, accumulate=acc)
         else:
             wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
@@ -324,7 +328,7 @@ class ResUnetEngine(_EngineBase):
                 else:
                     ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
             else:
-                if self.policy.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
+                if self._pol.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
                     ops.first_bwd_weight(g_x, ch[0], a['x8'], self.cin, G('conv_in.weight'), G('conv_in.bias'), wsf, accumulate=acc)
                 else:
                     wgrad('conv_in.weight', g_x, ch[0], a['x8'], self.cin, bias='conv_in.bias')

@@ -62,9 +62,13 @@ class ConvPolicy:
         """a one-tap-per-segment layer (ConvTranspose2d, 1x1, stride-2 3x3) on the pointwise bf16x3 GEMM kernel (csrc/gemm_x3.hip)?"""
         return self.x3 and ops.gemm_x3_supported(K, N)
 
-    def use_x3_wgrad(self, h, w, cout, c1, c2):
-        """backward-weight of a 3x3 layer on the bf16x3 kernel (csrc/wgrad_x3.hip)?"""
-        return self.x3 and ops.x3_wgrad_supported(h, w, cout, c1, c2)
+    def use_x3_wgrad(self, h, w, cout, c1, c2, batch=None, cs=None):
+        """backward-weight of a 3x3 layer on the bf16x3 kernel (csrc/wgrad_x3.hip)?  ``batch`` / ``cs`` (largest channel stride of
+        the tensors involved): the kernel addresses a whole [B][H][W][cs] map with 32-bit byte offsets; past that the layer falls
+        back to the Winograd / direct fp32 kernels instead of failing inside backward."""
+        if not (self.x3 and ops.x3_wgrad_supported(h, w, cout, c1, c2)):
+            return False
+        return batch is None or ops.x3_wgrad_fits(batch, h, w, cs if cs is not None else max(cout, c1, c2))
 
     def use_wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
         return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
@@ -79,6 +83,7 @@ class _EngineBase:
 
     def _init_base(self):
         self.policy = ConvPolicy(*DEFAULT_POLICY.key())
+        self._pol = self.policy      # the effective policy of the current forward (effective_policy)
         self.saved = None
         self.gen = 0                 # bumped by every forward that (re)writes an activation buffer set
         self._pack_key = None
@@ -92,9 +97,18 @@ class _EngineBase:
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused)
             cur.update(kw)
             policy = ConvPolicy(**cur)
-        self.policy = policy
+        self.policy = self._pol = policy
         self._pack_key = None        # re-pack for the other kernel family
         self._jobs_key = None
+
+    def effective_policy(self, H, W, cs_max):
+        """The policy a forward on [.,.,H,W] inputs runs with: the bf16x3 forward / backward-data / pointwise kernels address one
+        image of a map with 32-bit byte offsets (pnnp_x3_image_fits); an input whose largest map ([H][W][cs_max]) is past that runs
+        on the fp32-MFMA families, chosen HERE -- before the weights are packed -- rather than failing in the launcher."""
+        if self.policy.x3 and not ops.x3_image_fits(H, W, cs_max):
+            p = self.policy
+            return ConvPolicy(wino=p.wino, wino_wgrad=p.wino_wgrad, wino_mink=p.wino_mink, x3=False, thin=p.thin, pool_fused=p.pool_fused)
+        return self.policy
 
     def mark_dirty(self):
         """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
@@ -193,7 +207,7 @@ class UNetEngine(_EngineBase):
         launches (ops.PackJobs) instead of ~70."""
         dev = self.params.flat.device
         P = dict(self.m.named_parameters())
-        key = (dev, need_dgrad, self.policy.key(), tuple(p.data_ptr() for p in P.values()))
+        key = (dev, need_dgrad, self._pol.key(), tuple(p.data_ptr() for p in P.values()))
         if self._jobs_key != key:
             self._jobs, self._jobs_key = self._build_pack_jobs(need_dgrad, dev, P), key
         self._jobs.run()
@@ -213,7 +227,7 @@ class UNetEngine(_EngineBase):
             cop = self.cout_pad if name == 'conv10_1' else co
             bwd = need_dgrad and name != 'conv1_1'                 # no gradient w.r.t. the network input
             c1 = ci // 2 if (name.endswith('_1') and name[4] in '6789') else None       # decoder conv{6..9}_1 read cat([up, skip])
-            xf, xd = self.policy.use_x3(co, cip, taps, c1)
+            xf, xd = self._pol.use_x3(co, cip, taps, c1)
             xd = xd and bwd
             wf, wd = self._wino(name, co, ci, taps)
             wf, wd = wf and not xf, wd and bwd and not xd
@@ -230,7 +244,7 @@ class UNetEngine(_EngineBase):
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
             ci, co = w.shape[0], w.shape[1]
-            if self.policy.use_x3_pointwise(ci, 4 * co) and self.policy.use_x3_pointwise(co, ci):
+            if self._pol.use_x3_pointwise(ci, 4 * co) and self._pol.use_x3_pointwise(co, ci):
                 self._x3[name] = (True, True)                      # ConvTranspose2d on the pointwise bf16x3 GEMM kernel
                 jobs.add_x3_convt(w, buf((name, dev, 'x3f'), ops.x3mat_bytes(ci, 4 * co), torch.uint8),
                                   buf((name, dev, 'x3d'), ops.x3mat_bytes(4 * co, ci), torch.uint8) if need_dgrad else None)
@@ -253,11 +267,11 @@ class UNetEngine(_EngineBase):
 
     def _wino(self, name, co, ci, taps=9):
         """(forward, backward-data) through the Winograd F(2x2,3x3) kernel?  (self.policy)"""
-        return self.policy.use_wino(co, ci, taps)
+        return self._pol.use_wino(co, ci, taps)
 
     def _wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
         """Backward-weight through the Winograd kernel?  (self.policy)"""
-        return self.policy.use_wino_wgrad(h, w, cout, c1, c2, g_cs, x_cs)
+        return self._pol.use_wino_wgrad(h, w, cout, c1, c2, g_cs, x_cs)
 
     def _wu(self, name):
         dev = self.params.flat.device
@@ -279,7 +293,8 @@ class UNetEngine(_EngineBase):
         self.params.ensure(dev)
         # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
         # tensor._version, the fused Adam kernel goes through mark_dirty()
-        key = (train, dev, self._dirty_epoch) + tuple(p._version for p in self.m.parameters())
+        self._pol = self.effective_policy(H, W, max(self.ch[0], self.cin_pad, self.cout_pad))
+        key = (train, dev, self._dirty_epoch, self._pol.key()) + tuple(p._version for p in self.m.parameters())
         if key != self._pack_key:
             self.pack_weights(need_dgrad=train)
             self._pack_key = key
@@ -304,7 +319,7 @@ class UNetEngine(_EngineBase):
         cur = a['x8']
         for lvl in range(5):               # encoder: conv{l}_1, conv{l}_2, pool
             i = lvl + 1
-            if lvl == 0 and self.policy.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
+            if lvl == 0 and self._pol.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
                 # conv1_1 on the streaming kernel: its 4 input channels are not worth a (padded) GEMM chunk
                 a['c1a'] = ops.first_fwd(cur, P['conv1_1.weight'], P['conv1_1.bias'], g('conv1_1', (B, H, W, ch[0])), LRELU)
             else:
@@ -313,7 +328,7 @@ class UNetEngine(_EngineBase):
                 a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
                 continue
             codes = None
-            fused = self.policy.pool_fused and self._x3.get(f'conv{i}_2', (False, False))[0]
+            fused = self._pol.pool_fused and self._x3.get(f'conv{i}_2', (False, False))[0]
             if train or fused:                     # argmax + sign codes: the backward pass then does not re-read the full-resolution map
                 codes = bufs.t.get(f'pc{i}')
                 shp = (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])
@@ -342,12 +357,13 @@ class UNetEngine(_EngineBase):
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             cur = a[f'c{i}']
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=dev)
-        if self.policy.use_thin_head(ch[0], self.cout, B * H * W):
+        if self._pol.use_thin_head(ch[0], self.cout, B * H * W):
             ops.head_fwd(a['c9'], P['conv10_1.weight'], P['conv10_1.bias'], out, residual=x if self.m.res else None)
         else:
             o = conv('conv10_1', a['c9'], None, H, W, self.cout, act=0, taps=1, out=g('o', (B, H, W, self.cout)))
             ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
         if train:
+            a['_pol'] = self._pol
             self.saved = (a, (B, H, W, dev), gen)
         return out
 
@@ -358,6 +374,7 @@ class UNetEngine(_EngineBase):
         finish in exactly the reverse of the flat parameter order) so a data-parallel reducer
         can start all-reducing the tail while the rest of the backward pass still runs."""
         a, (B, H, W, dev), _ = self.saved
+        self._pol = a['_pol']            # the kernel families this forward ran on (effective_policy)
         bufs = self.bufs[(B, H, W, dev)]
         ch = self.ch
         gb = lambda n, s: bufs.get('g_' + n, s, dev)
@@ -382,7 +399,8 @@ class UNetEngine(_EngineBase):
 
         def wgrad(name, gpre, cout, x1, c1, x2=None, taps=9):
             c2 = x2.shape[3] if x2 is not None else 0
-            if taps == 9 and self.policy.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2):
+            if taps == 9 and self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=B,
+                                                    cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
                                        G(name + '.bias', (cout,)), wsf, accumulate=acc)
             elif taps == 9 and self._wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
@@ -395,7 +413,7 @@ class UNetEngine(_EngineBase):
 
         # conv10_1 (1x1, no activation); its input c9 is a LeakyReLU output
         g_cur = gb('c9', a['c9'].shape)
-        if self.policy.use_thin_head(ch[0], self.cout, B * H * W):
+        if self._pol.use_thin_head(ch[0], self.cout, B * H * W):
             ops.head_bwd(g_out8, a['c9'], P['conv10_1.weight'], g_cur, G('conv10_1.weight', P['conv10_1.weight'].shape),
                          G('conv10_1.bias', (self.cout,)), wsf, mode=LRELU, accumulate=acc)
             done('conv10_1')
@@ -435,7 +453,7 @@ class UNetEngine(_EngineBase):
                 g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
                 ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1, codes=a.get(f'pc{i - 1}'))
             else:
-                if self.policy.use_thin_first(self.cin, ch[0], H, W, a['x8'].shape[3]):
+                if self._pol.use_thin_first(self.cin, ch[0], H, W, a['x8'].shape[3]):
                     ops.first_bwd_weight(g_a, ch[0], a['x8'], self.cin, G('conv1_1.weight', P['conv1_1.weight'].shape),
                                          G('conv1_1.bias', (ch[0],)), wsf, accumulate=acc)
                     done('conv1_1')

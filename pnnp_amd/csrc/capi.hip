@@ -16,14 +16,15 @@ const char* pnnp_error_string(int code) {
     }
 }
 
-int pnnp_device_cus(void) {            // compute units of the CURRENT device (cached per device)
-    static PnnpPerDevice cache;
-    return cache.get([] {
+int pnnp_device_cus(void) {            // compute units of the CURRENT device (cached per device); never below 1: grids and workspace
+    static PnnpPerDevice cache;        // sizes are derived from it, and a failed query must not turn into a 0-block launch
+    const int n = cache.get([] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         return n;
     });
+    return n >= 1 ? n : 256;           // MI355X
 }
 
 }  // extern "C"

@@ -177,7 +177,7 @@ int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
         int blocks = 0;
         for (int i = 0; i < tb.n; ++i) {
             const PnnpPackJob& j = jobs[i0 + i];
-            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0))) return PNNP_E_INVALID;
+            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0 || (j.K & 7)))       /* kind 3 enumerates whole 8-row groups */) return PNNP_E_INVALID;
             tb.job[i] = j;
             blocks += job_blocks(j);
             tb.blk_end[i] = blocks;

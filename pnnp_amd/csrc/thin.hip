@@ -119,7 +119,9 @@ head_bwd_kernel(HeadBwd a) {
         }
 #pragma unroll
         for (int k = 0; k < LPP; ++k) {
-            const f32x4 g4 = gv[k];
+            f32x4 g4 = gv[k];
+#pragma unroll
+            for (int co = 0; co < 4; ++co) g4[co] = co < a.cout ? g4[co] : 0.f;      // padding channels of g may hold anything (0 x NaN would poison gx)
             f32x4 d = wq[0] * g4[0];
             d += wq[1] * g4[1]; d += wq[2] * g4[2]; d += wq[3] * g4[3];
             if (a.mode) {

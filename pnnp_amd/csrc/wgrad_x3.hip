@@ -471,6 +471,11 @@ int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2) {
     return (H > 0 && W > 0 && Cout > 0 && C1 > 0 && Cout % 32 == 0 && C1 % 32 == 0 && C2 % 32 == 0) ? 1 : 0;
 }
 
+// the backward-weight kernel addresses the WHOLE batch of a map through one 32-bit byte offset: does [B][H][W][cstride] fit?
+int pnnp_x3_wgrad_fits(int B, int H, int W, int cstride) {
+    return (B > 0 && H > 0 && W > 0 && cstride > 0 && ((int64_t)B * H + 2) * W * cstride * 4 < (1ll << 31)) ? 1 : 0;
+}
+
 int64_t pnnp_x3_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin) {
     if (Cout % 32 || Cin % 32) return 0;
     return (int64_t)wx3_splits(B, H, W, Cout, Cin) * ((int64_t)9 * Cout * Cin + Cout);
@@ -487,8 +492,8 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
     if (g_cs < Cout || x1_cs < C1 || (x2 && x2_cs < C2) || (g_cs & 3) || (x1_cs & 3) || (x2 && (x2_cs & 3))) return PNNP_E_INVALID;
     if ((((uintptr_t)g) | ((uintptr_t)x1) | ((uintptr_t)x2)) & 15) return PNNP_E_INVALID;
     // 32-bit byte offsets into the whole tensors (bit 31 marks "outside")
-    const int64_t cmax = g_cs > x1_cs ? g_cs : x1_cs;
-    if (((int64_t)B * H + 2) * W * cmax * 4 >= (1ll << 31) || (x2 && ((int64_t)B * H + 2) * W * x2_cs * 4 >= (1ll << 31))) return PNNP_E_UNSUPPORTED;
+    const int cmax = g_cs > x1_cs ? g_cs : x1_cs;
+    if (!pnnp_x3_wgrad_fits(B, H, W, cmax) || (x2 && !pnnp_x3_wgrad_fits(B, H, W, x2_cs))) return PNNP_E_UNSUPPORTED;
     if (workspace_floats < pnnp_x3_wgrad_workspace_floats(B, H, W, Cout, N)) return PNNP_E_WORKSPACE;
     hipStream_t st = as_stream(stream);
     Wx3Args a{};

@@ -145,6 +145,15 @@ def x3_supported(K, N):
     return bool(_prep().pnnp_x3_supported(int(K), int(N)))
 
 
+def x3_image_fits(H, W, cstride):
+    """one [H][W][cstride] image within the 32-bit offsets of the bf16x3 forward / backward-data / pointwise kernels?"""
+    return bool(_prep().pnnp_x3_image_fits(int(H), int(W), int(cstride)))
+
+
+def x3_wgrad_fits(B, H, W, cstride):
+    return bool(_prep().pnnp_x3_wgrad_fits(int(B), int(H), int(W), int(cstride)))
+
+
 def x3_weight_bytes(K, N):
     return int(_prep().pnnp_x3_weight_bytes(int(K), int(N)))
 

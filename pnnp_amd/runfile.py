@@ -27,10 +27,14 @@ from .utils import load_weights
 PROXY_DATASETS = ('NF_Syn_Dataset', 'IMX686_NF_Syn_Dataset')      # trainer_SID.py:463, trainer_LRID.py:419
 
 
-def build_proxy(cfg, device='cuda'):
+def build_proxy(cfg, device='cuda', allow_uninitialised_proxy=False):
     """`arch_proxy` of a run file -> the NoiseFlow proxy the train step samples from (trainer_SID.py:33-42,
-    trainer_LRID.py:33-39): built by name, weights from `<fast_ckpt>/<camera>_NoiseFlow_last_model.pth` when that file exists
-    (the checkpoints are not distributed with the reference, so a missing file leaves the random-initialised flow and says so).
+    trainer_LRID.py:33-39): built by name, weights from `<fast_ckpt>/<camera>_NoiseFlow_last_model.pth`.  A missing file raises
+    FileNotFoundError, as the reference's unconditional ``torch.load`` does (trainer_SID.py:39-40, trainer_LRID.py:36-37): a wrong
+    `fast_ckpt` must not train the denoiser on the noise of a random flow.  ``allow_uninitialised_proxy=True`` (tests, benchmarks:
+    the checkpoints are not distributed with the reference) keeps the initial weights and says so.
+    Deviation: trainer_SID.py:39 hard-codes 'SonyA7S2_NoiseFlow_last_model.pth' whatever the camera; here the file name follows
+    dst.camera_type, which is what trainer_LRID.py:36 does and equals the reference for the SonyA7S2 run files.
     The two trainers differ and both are kept: trainer_SID loads by_name=True and calls ``.eval()`` (:41-42); trainer_LRID loads
     by_name=False and never calls ``.eval()`` (:37-39), so its proxy samples with BatchNorm on BATCH statistics (NoiseFlow.sample
     in training mode).  Returns None when the run file has no proxy."""
@@ -46,8 +50,11 @@ def build_proxy(cfg, device='cuda'):
     lrid = dst.get('dataset') == 'IMX686_NF_Syn_Dataset'
     if os.path.exists(path):
         net = load_weights(net, torch.load(path, map_location='cpu'), by_name=not lrid)
-    else:
+    elif allow_uninitialised_proxy:
         print(f'No checkpoint file!!!  ({path}: the {proxy["name"]} proxy keeps its initial weights)', flush=True)
+    else:
+        raise FileNotFoundError(f'{path} (the NoiseFlow proxy checkpoint of arch_proxy; pass allow_uninitialised_proxy=True to '
+                                f'train on a random-initialised flow)')
     net = net.to(device)
     return net.train() if lrid else net.eval()
 
@@ -65,7 +72,7 @@ def lr_schedule(hyper):
     return lambda epoch: get_cos_lr(epoch - int(hyper['last_epoch']), period=period, peak=peak, lr=lr0)
 
 
-def build(cfg, device='cuda', rank=0, world=1, group=None):
+def build(cfg, device='cuda', rank=0, world=1, group=None, allow_uninitialised_proxy=False):
     """-> (net, train_step, lr_of_epoch, shapes).  Unknown architectures raise KeyError like `globals()[name]`."""
     arch = cfg['arch']
     cls = getattr(archs, arch['name'], None)
@@ -85,7 +92,7 @@ def build(cfg, device='cuda', rank=0, world=1, group=None):
     net = net.to(device)
     proxy_kw = {}
     if dst.get('dataset') in PROXY_DATASETS:                        # the preprocess branch is chosen by dst_train.dataset
-        proxy_net = build_proxy(cfg, device)
+        proxy_net = build_proxy(cfg, device, allow_uninitialised_proxy)
         if proxy_net is None:
             raise KeyError('arch_proxy')                            # the reference would fail on self.proxy_net
         proxy_kw = dict(proxy_net=proxy_net)
@@ -105,11 +112,13 @@ def main(argv=None):
     ap.add_argument('--epochs', type=int, default=2)
     ap.add_argument('--steps', type=int, default=4, help='steps per epoch')
     ap.add_argument('--patch', type=int, default=0, help='override dst.patch_size')
+    ap.add_argument('--allow-uninitialised-proxy', action='store_true',
+                    help='arch_proxy run files: train on a random-initialised NoiseFlow when its checkpoint is missing (default: fail like the reference)')
     a = ap.parse_args(argv)
     if not a.synthetic:
         sys.exit('only --synthetic data is available here (datasets / rawpy are out of scope)')
     cfg = load(a.runfile)
-    net, step, lr_of, sh = build(cfg)
+    net, step, lr_of, sh = build(cfg, allow_uninitialised_proxy=a.allow_uninitialised_proxy)
     S = a.patch or sh['patch']
     hyper = cfg['hyper']
     e0 = int(hyper['last_epoch'])

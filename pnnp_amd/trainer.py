@@ -58,6 +58,10 @@ class BucketedAllReduce:
         self.comm_stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
         # one event per bucket, allocated once: "the backward stream has finished this bucket's gradients"
         self.events = [torch.cuda.Event() for _ in self.buckets] if (self.cuda and self.active) else []
+        # measurement (bench.py --gpus N): with `time_waits` set, finish() brackets its waits with an event pair on the compute
+        # stream; wait_ms() then says how long the compute stream stood still for the collectives (0 = communication hidden)
+        self.time_waits = False
+        self.wait_pairs = []
 
     def reset(self):
         self.pending = len(self.buckets) - 1
@@ -83,10 +87,27 @@ class BucketedAllReduce:
 
     def finish(self):
         """Launch what is left and make the current stream wait for every bucket."""
+        timed = self.time_waits and self.cuda and self.active
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream())
         self.ready(0)
         for w in self.works:
             w.wait()
         self.works = []
+        if timed:
+            e1.record(torch.cuda.current_stream())
+            self.wait_pairs.append((e0, e1))
+
+    def wait_ms(self):
+        """Per finish() since the last call: milliseconds the compute stream spent between reaching finish() and having every
+        bucket reduced (synchronises).  Includes launching the buckets backward had not released yet."""
+        if not self.wait_pairs:
+            return []
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in self.wait_pairs]
+        self.wait_pairs = []
+        return out
 
 
 def shard_crops(global_batch, rank, world):
@@ -113,11 +134,18 @@ class HipTrainStep:
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
                  seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False,
-                 proxy_net=None, proxy_ratio_choices=None, proxy_iso=None):
+                 proxy_net=None, proxy_ratio_choices=None, proxy_iso=None, global_batch=None):
         """``proxy_net`` (a NoiseFlow, `arch_proxy` of the run files): noise comes from ``proxy_net.sample`` instead of the
         physics sampler -- the 'NF_Syn_Dataset' branch of preprocess (trainer_SID.py:463-472: ratio ~ U(100,300) per crop,
         one random legal ISO per batch) or, with ``proxy_ratio_choices`` (dst.ratio_list), the 'IMX686_NF_Syn_Dataset'
-        branch (trainer_LRID.py:33,419-427: one ratio of the list per batch, ISO from the data: ``proxy_iso`` or step(iso=))."""
+        branch (trainer_LRID.py:33,419-427: one ratio of the list per batch, ISO from the data: ``proxy_iso`` or step(iso=)).
+
+        ``global_batch``: None = weak scaling, every rank steps on the same number of crops and rank r owns global crops
+        [r B, (r+1) B).  An integer = strong scaling of ONE global batch over the ranks by ``shard_crops`` (remainders to the low
+        ranks, so shards may differ by one crop): the rank's crops are [lo, hi) of that batch -- the sampler's counter base is
+        ``lo``, and the local gradient (a mean over the rank's crops) is weighted by B_local / global_batch so that the
+        all-reduced sum is the mean over the global batch."""
+        self.global_batch = global_batch
         self.net = net
         self.engine = net.engine
         self.lr = lr
@@ -168,6 +196,17 @@ class HipTrainStep:
         if not self._synced:
             self.sync_replicas()
 
+    def shard(self, B):
+        """(first global crop index of this rank's B local crops, weight of the local mean-gradient in the global mean x world)."""
+        if self.global_batch is None:
+            return self.rank * B, 1.0
+        lo, hi = shard_crops(self.global_batch, self.rank, self.world)
+        if hi - lo != B:
+            raise PnnpError(f'rank {self.rank} of {self.world} owns crops [{lo}, {hi}) of a global batch of {self.global_batch}, got {B} crops')
+        if B == 0:
+            raise PnnpError('a rank without crops cannot take part in the step (global batch < world size)')
+        return lo, B * self.world / self.global_batch
+
     def sample_noise_params(self, batch):
         """trainer_SID.py:451-459: one host-side parameter draw per crop."""
         return [process.sample_params_max(camera_type=self.camera_type, ratio=None) for _ in range(batch)]
@@ -189,7 +228,7 @@ class HipTrainStep:
         if self.clip:
             flags |= process.F_POST_MAX1 | (0 if self.clip == process.HALF_CLIP else process.F_POST_MIN0)
         return process.noise_sample(hr, rows, flags, seed=self.seed, offset=self.step_count,
-                                    crop_base=self.rank * B), rows
+                                    crop_base=self.shard(B)[0]), rows
 
     LEGAL_ISO = (50, 64, 80, 100, 125, 160, 200, 250, 320, 400, 500, 640, 800, 1000, 1250, 1600, 2000, 2500, 3200,
                  4000, 5000, 6400, 8000, 10000, 12800, 16000, 20000, 25600)             # trainer_SID.py:33-34
@@ -243,6 +282,9 @@ class HipTrainStep:
         loss = bufs.get('loss_out', (1 + B,), dev)
         lws = bufs.get('loss_ws', (128 * B,), dev)
         ops.l1_clamp_loss(pred, target, g8, loss, lws, scale=scale)
+        weight = self.shard(B)[1]
+        if weight != 1.0:                                    # uneven shards of a global batch: this rank's mean counts B_local / B_global
+            g8.mul_(weight)
         if self.reducer is not None:
             self.reducer.reset()
         e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)

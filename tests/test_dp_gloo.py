@@ -93,3 +93,28 @@ def test_lr_schedule_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, 'misc.npz'))
     lr = np.array([get_cos_lr(int(s), period=200, peak=10, lr=1e-4) for s in g['lr_steps']])
     np.testing.assert_allclose(lr, g['lr'], rtol=1e-15)
+
+
+def test_shard_of_a_global_batch_gives_counter_base_and_gradient_weight():
+    """HipTrainStep.shard: the sampler's counter base is the shard's first global crop (NOT rank * B_local, which collides when
+    shards differ by one crop) and the local mean-gradient counts B_local * world / B_global under the 1/world of the all-reduce."""
+    import types
+    from pnnp_amd._lib import PnnpError
+    from pnnp_amd.trainer import HipTrainStep
+    net = types.SimpleNamespace(engine=None)
+    # weak scaling: every rank holds B crops
+    assert HipTrainStep(net, rank=3, world=8).shard(16) == (48, 1.0)
+    # strong scaling, 5 crops over 2 ranks: [0,3) and [3,5)
+    a = HipTrainStep(net, rank=0, world=2, global_batch=5).shard(3)
+    b = HipTrainStep(net, rank=1, world=2, global_batch=5).shard(2)
+    assert a == (0, 3 * 2 / 5) and b == (3, 2 * 2 / 5)
+    assert abs((a[1] + b[1]) / 2 - 1.0) < 1e-12                    # the weights average to 1 over the ranks
+    covered = []
+    for r in range(8):                                             # 13 crops over 8 ranks: bases tile [0, 13) without overlap
+        lo, hi = shard_crops(13, r, 8)
+        base, w = HipTrainStep(net, rank=r, world=8, global_batch=13).shard(hi - lo)
+        assert base == lo and abs(w - (hi - lo) * 8 / 13) < 1e-12
+        covered += list(range(base, base + hi - lo))
+    assert covered == list(range(13))
+    with pytest.raises(PnnpError):                                 # a rank handed the wrong number of crops is an error, not a collision
+        HipTrainStep(net, rank=1, world=2, global_batch=5).shard(3)

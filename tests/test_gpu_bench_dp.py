@@ -44,3 +44,17 @@ def test_weak_scaling_two_ranks():
     out = _run(['--batch', '2'])
     assert out['scaling'] == 'weak' and out['config']['crops_per_gpu'] == 2 and out['config']['global_batch'] == 4
     assert out['replica_checksum_spread'] == 0.0
+
+
+def test_strong_scaling_uneven_global_batch_and_per_rank_record():
+    """A global batch of 5 over 2 ranks (3 + 2 crops): bench.py no longer refuses it; the line carries the per-rank step times
+    and the all-reduce wait (event pair around reducer.finish()) the scaling record needs."""
+    out = _run(['--strong', '--batch', '5'])
+    assert out['config']['global_batch'] == 5 and out['config']['crops_per_gpu'] == 3      # rank 0's shard
+    assert abs(out['value'] - 5 * 3 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
+    assert out['replica_checksum_spread'] == 0.0
+    pr = out['per_rank_ms_per_step']
+    assert len(pr['all']) == 2 and 0 < pr['min'] <= pr['max'] <= out['ms_per_step'] * 1.05
+    w = out['allreduce_wait_ms_per_step']
+    assert w['mean_min_over_ranks'] >= 0.0 and w['worst_step_any_rank'] >= w['mean_max_over_ranks'] >= w['mean_min_over_ranks']
+    assert w['grad_bytes'] > 0

@@ -78,3 +78,116 @@ def test_two_rank_step_equals_single_process():
     # the global loss is the mean of the ranks' local losses
     for s in range(3):
         assert abs(0.5 * (res[0][0][s] + res[1][0][s]) - ref_losses[s]) < 1e-5 * abs(ref_losses[s]) + 1e-7
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 3: replicas that start DIFFERENT must be repaired by sync_replicas; uneven shards of a global batch.
+def _worker_seeds(rank, world, port, hr_all, sync, out):
+    """Each rank builds its network from its OWN seed (5 + rank).  With sync_replicas (the default) rank 0's weights are
+    broadcast at the first step and the checksum spread is 0 after step 1 and after step 3; with the broadcast suppressed the
+    same run must show a non-zero spread -- so the assertion cannot pass without the broadcast."""
+    import torch.distributed as dist
+    from pnnp_amd.trainer import HipTrainStep
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        B = hr_all.shape[0] // world
+        hr = hr_all[rank * B:(rank + 1) * B].cuda()
+        net = _net(5 + rank)
+        ts = HipTrainStep(net, lr=1e-3, seed=7, rank=rank, world=world, bucket_bytes=32 << 10)
+        if not sync:
+            ts._synced = True                                       # suppress the start-up broadcast (negative control)
+        spreads = []
+        for s in range(3):
+            np.random.seed(100 + s)
+            plist = ts.sample_noise_params(B * world)[rank * B:(rank + 1) * B]
+            ts.step(hr, plist=plist)
+            if s in (0, 2):
+                spreads.append(ts.replica_checksum())
+        out.put((rank, spreads, net.engine.params.flat.detach().cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(target, args_of_rank, world=2):
+    ctx = mp.get_context('spawn')
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + args_of_rank(r) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        item = q.get()
+        res[item[0]] = item[1:]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.mark.parametrize('sync', [True, False])
+def test_replicas_from_different_seeds_need_and_get_the_broadcast(sync):
+    g = torch.Generator().manual_seed(2)
+    hr_all = torch.rand(4, 4, 64, 64, generator=g)
+    res = _spawn(_worker_seeds, lambda r: (hr_all, sync))
+    for r in range(2):
+        s1, s3 = res[r][0]
+        if sync:
+            assert s1 == 0.0 and s3 == 0.0, (r, s1, s3)             # after step 1 and after step 3
+        else:
+            assert s1 > 0.0 and s3 > 0.0, (r, s1, s3)               # without sync_replicas the same check fails
+    assert np.array_equal(res[0][1], res[1][1]) == sync
+
+
+def _worker_uneven(rank, world, port, hr_all, out):
+    """Global batch 5 over 2 ranks: shard_crops gives rank 0 crops [0,3), rank 1 crops [3,5)."""
+    import torch.distributed as dist
+    from pnnp_amd.trainer import HipTrainStep, shard_crops
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        Bg = hr_all.shape[0]
+        lo, hi = shard_crops(Bg, rank, world)
+        hr = hr_all[lo:hi].cuda()
+        net = _net(5)
+        ts = HipTrainStep(net, lr=1e-3, seed=7, rank=rank, world=world, bucket_bytes=32 << 10, global_batch=Bg)
+        losses, noisy0 = [], None
+        for s in range(3):
+            np.random.seed(100 + s)
+            plist = ts.sample_noise_params(Bg)[lo:hi]
+            if s == 0:
+                noisy0 = ts.make_noisy(hr, plist)[0].cpu().numpy()
+            losses.append(float(ts.step(hr, plist=plist)[0]))
+        out.put((rank, losses, net.engine.params.flat.detach().cpu().numpy(), noisy0, (lo, hi)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_uneven_shards_of_a_global_batch_of_5():
+    """crop_base is the shard's `lo` (not rank * B_local): the two ranks' noisy crops are exactly crops [0,3) and [3,5) of the
+    single-process batch (no Philox counter collision), and three optimiser steps end at the single-process weights -- the
+    local mean-gradients are weighted 3/5 and 2/5."""
+    from pnnp_amd.trainer import HipTrainStep
+    g = torch.Generator().manual_seed(3)
+    hr_all = torch.rand(5, 4, 64, 64, generator=g)
+    net = _net(5)
+    ts = HipTrainStep(net, lr=1e-3, seed=7)
+    ref_losses = []
+    for s in range(3):
+        np.random.seed(100 + s)
+        plist = ts.sample_noise_params(5)
+        if s == 0:
+            ref_noisy = ts.make_noisy(hr_all.cuda(), plist)[0].cpu().numpy()
+        ref_losses.append(float(ts.step(hr_all.cuda(), plist=plist)[0]))
+    ref = net.engine.params.flat.detach().cpu().numpy()
+    res = _spawn(_worker_uneven, lambda r: (hr_all,))
+    assert res[0][3] == (0, 3) and res[1][3] == (3, 5)
+    assert np.array_equal(res[0][2], ref_noisy[0:3]) and np.array_equal(res[1][2], ref_noisy[3:5])
+    assert np.array_equal(res[0][1], res[1][1])                     # identical replicas
+    rel = np.linalg.norm(res[0][1] - ref) / np.linalg.norm(ref)
+    assert rel < 2e-5, rel
+    for s in range(3):                                              # global loss = crop-weighted mean of the local losses
+        assert abs(0.6 * res[0][0][s] + 0.4 * res[1][0][s] - ref_losses[s]) < 1e-5 * abs(ref_losses[s]) + 1e-7

@@ -161,3 +161,37 @@ def test_full_sid_frame_wino_equals_direct():
         yf = _fwd(net, x, fam)
         assert yf.shape == x.shape and torch.isfinite(yf).all()
         assert _rel(yf, yd) < 2e-5, fam
+
+
+def test_config5_batch_of_12_resunet_is_12_independent_crops_and_their_mean_gradient():
+    """BASELINE config 5's batch (12 crops of 4 x 512 x 512 through ResUnet nf = 32: stride-2 convolutions, 1x1 shortcuts, residual
+    adds) through the same size-independent properties as config 3's batch of 16: every crop's output equals that crop run alone
+    (no cross-crop leakage through tiles, halos, persistent work lists, parity-class GEMMs), and -- the loss being a mean over the
+    batch -- the batch gradient is the mean of the 12 single-crop gradients (same kernels, other split-K partitions)."""
+    from pnnp_amd.trainer import HipTrainStep
+    net, _ = _he_net('resunet')
+    g = torch.Generator(device='cuda').manual_seed(5)
+    x = torch.rand(12, 4, 512, 512, device='cuda', generator=g)
+    t = (torch.rand(12, 4, 512, 512, device='cuda', generator=g) > 0.5).float()
+    net.engine.set_policy(**FAMILIES['x3'])
+    with torch.no_grad():
+        y12 = net(x).clone()
+        assert torch.isfinite(y12).all() and float(y12.abs().max()) > 1e-3
+        for b in (0, 5, 11):
+            alone = net(x[b:b + 1].contiguous())
+            assert _rel(alone[0], y12[b]) < 1e-6, b
+    ts = HipTrainStep(net, lr=0.0, clip=0)
+    lo = ts.step(t, noisy=x)
+    loss12, g12 = float(lo[0]), _grads(net)
+    acc = {k: torch.zeros_like(v, dtype=torch.float64) for k, v in g12.items()}
+    loss_sum = 0.0
+    for b in range(12):
+        lo = ts.step(t[b:b + 1].contiguous(), noisy=x[b:b + 1].contiguous())
+        loss_sum += float(lo[0])
+        for k, v in _grads(net).items():
+            acc[k] += v.double()
+    assert abs(loss_sum / 12 - loss12) < 2e-6
+    for k, v in g12.items():
+        ref = acc[k] / 12
+        rel = float((v.double() - ref).norm() / (ref.norm() + 1e-20))
+        assert rel < 2e-3, (k, rel)

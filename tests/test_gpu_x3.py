@@ -249,3 +249,138 @@ def test_fused_maxpool_equals_conv_then_pool_kernel(cin, cout, shape):
     ops.conv_x3_fwd_pool(x, None, wx, b, y1, p1, c1, cout, 1)
     assert torch.equal(y1, y0) and torch.equal(p1, p0) and torch.equal(c1, c0)
     assert int((c0 & 3 != 0).sum()) > 0 and int((c0 >> 2 == 0).sum()) > 0      # the case has non-trivial argmax and all-negative windows
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Precision case of the bf16x3 family, hardened (round 3): float64 yardsticks for backward-data and backward-weight next to
+# their fp32-MFMA twins, a max-element bound under cancellation, and the dynamic range the 3-way split supports
+# (include/pnnp_hip.h, "bf16x3 dynamic range").
+def _f64_wgrad(g, x):
+    """dW[co][ci][ky][kx] = sum_{b,y,x} g[b,y,x,co] xpad[b,y+ky,x+kx,ci] in float64 on the GPU (NHWC inputs), one batch
+    element at a time (a plain matmul per tap: the yardstick, not a product path)."""
+    B, H, W, Co = g.shape
+    Ci = x.shape[3]
+    dW = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device=g.device)
+    for b in range(B):
+        xp = F.pad(x[b].double(), (0, 0, 1, 1, 1, 1))
+        gb = g[b].double().reshape(H * W, Co)
+        for ky in range(3):
+            for kx in range(3):
+                dW[:, :, ky, kx] += gb.t() @ xp[ky:ky + H, kx:kx + W].reshape(H * W, Ci)
+    return dW
+
+
+def test_x3_dgrad_is_as_accurate_as_the_fp32_mfma_kernel():
+    """conv_x3_bwd_data and the fp32-MFMA backward-data kernel against float64 on a K = 9 x 512 reduction with gradients spanning
+    8 decades: the bf16x3 error stays within 2x the fp32-MFMA kernel's, both at float32 level."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 16, 32, 64, 512
+    gen = torch.Generator().manual_seed(1)
+    g = torch.randn(B, Co, H, W, generator=gen) * torch.logspace(-4, 4, Co, base=10.0).reshape(1, Co, 1, 1).roll(3, 1)
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.05
+    ref = F.conv_transpose2d(g.double(), w.double(), None, padding=1)              # = d/dx of conv2d(x, w, padding=1)
+    _, d3 = _packs(w.cuda(), fwd=False)
+    d32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), None, d32)
+    y3 = torch.empty((B, H, W, Ci), device='cuda'); y32 = torch.empty_like(y3)
+    ops.conv_x3_bwd_data(nhwc(g).cuda(), d3, y3)
+    ops.conv_bwd_data(nhwc(g).cuda(), d32, y32)
+    e3 = float((nchw(y3).cpu().double() - ref).norm() / ref.norm())
+    e32 = float((nchw(y32).cpu().double() - ref).norm() / ref.norm())
+    m3 = float((nchw(y3).cpu().double() - ref).abs().max() / ref.abs().max())
+    m32 = float((nchw(y32).cpu().double() - ref).abs().max() / ref.abs().max())
+    print(f'dgrad vs float64: rel L2 bf16x3 {e3:.2e} fp32-MFMA {e32:.2e}; max-element / max|ref| bf16x3 {m3:.2e} fp32-MFMA {m32:.2e}')
+    assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7
+    assert m3 < 2.0 * m32 + 1e-8
+
+
+@pytest.mark.parametrize('shape', [(16, 512, 512, 32, 32), (4, 128, 128, 64, 128)])
+def test_x3_wgrad_is_as_accurate_as_the_fp32_mfma_kernel(shape):
+    """wgrad_x3 splits BOTH operands on the fly; its reduction runs over pixels -- K = 16 x 512 x 512 = 4.2 M terms per weight at
+    the benchmark's top level.  Against a float64 evaluation of the same sums (GPU matmuls in double) next to the fp32-MFMA
+    backward-weight kernel: relative L2 AND max-element error within 2x the fp32 kernel's."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = shape
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen) * torch.logspace(-2, 2, Ci, device='cuda').roll(5)
+    g = torch.randn(B, H, W, Co, device='cuda', generator=gen) * torch.logspace(-3, 1, Co, device='cuda')
+    ref = _f64_wgrad(g, x)
+    assert ops.x3_wgrad_supported(H, W, Co, Ci, 0)
+    ws = torch.empty(max(ops.x3_wgrad_workspace_floats(B, H, W, Co, Ci), ops.wgrad_workspace_floats(B, H, W, Co, Ci, 9)), device='cuda')
+    d3 = torch.empty(Co, Ci, 3, 3, device='cuda'); d32 = torch.empty_like(d3)
+    ops.conv_x3_bwd_weight(g, Co, x, Ci, None, d3, None, ws)
+    ops.conv_bwd_weight(g, Co, x, Ci, None, d32, None, 9, ws)
+    rn = ref.norm()
+    # per-weight condition: sum |g||x| is ~sqrt(K) x the result for random signs, so scale the max-element error by the row scale
+    e3, e32 = float((d3.double() - ref).norm() / rn), float((d32.double() - ref).norm() / rn)
+    scale = ref.abs().amax(dim=(2, 3), keepdim=True).clamp_min(1e-30)
+    m3, m32 = float(((d3.double() - ref).abs() / scale).max()), float(((d32.double() - ref).abs() / scale).max())
+    print(f'wgrad {shape} vs float64: rel L2 bf16x3 {e3:.2e} fp32-MFMA {e32:.2e}; max-element (per (co,ci) scale) bf16x3 {m3:.2e} fp32-MFMA {m32:.2e}')
+    assert e3 < 2.0 * e32 + 1e-8, (e3, e32)
+    assert m3 < 2.0 * m32 + 1e-7, (m3, m32)
+
+
+def test_x3_max_element_error_under_cancellation():
+    """Sums that cancel: every output is sum_k (w_k x_k - w_k x_k') with x' = x (1 + 2^-12 r), O(1) terms whose sum is ~2^-12 of
+    their magnitude.  An fp32 dot product is accurate to ~K 2^-24 max|term|, not to the (tiny) result; the bf16x3 kernel must obey
+    the SAME absolute bound element by element (max, not L2) and stay within 2x the fp32-MFMA kernel's worst element."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 16, 32, 256, 64
+    gen = torch.Generator().manual_seed(4)
+    xa = torch.randn(B, Ci // 2, H, W, generator=gen)
+    xb = xa * (1 + 2.0 ** -12 * torch.randn(B, Ci // 2, H, W, generator=gen))
+    x = torch.stack([xa, xb], 2).reshape(B, Ci, H, W)                       # channel 2k: x, 2k+1: x'
+    wa = torch.randn(Co, Ci // 2, 3, 3, generator=gen) * 0.1
+    w = torch.stack([wa, -wa], 2).reshape(Co, Ci, 3, 3)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    terms = F.conv2d(x.double().abs(), w.double().abs(), None, padding=1)   # sum of |terms| per output
+    assert float(ref.abs().mean() / terms.mean()) < 1e-3                     # the case does cancel
+    f3, _ = _packs(w.cuda(), dgrad=False)
+    f32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), f32, None)
+    y3 = torch.empty((B, H, W, Co), device='cuda'); y32 = torch.empty_like(y3)
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f3, None, y3, Co, 0)
+    ops.conv_fwd(nhwc(x).cuda(), None, f32, None, y32, Co, 9, 0)
+    r3 = ((nchw(y3).cpu().double() - ref).abs() / terms).max()
+    r32 = ((nchw(y32).cpu().double() - ref).abs() / terms).max()
+    print(f'cancellation: max |err| / sum|terms|: bf16x3 {float(r3):.2e}, fp32-MFMA {float(r32):.2e} (2^-24 = {2.0 ** -24:.2e})')
+    assert float(r3) < 2.0 * float(r32) + 2.0 ** -26 and float(r3) < 8 * 2.0 ** -24
+
+
+@pytest.mark.parametrize('xs,wsc', [(1e-30, 1.0), (1e+30, 1e-3), (1e-15, 1e-15), (1.0, 1e-30)])
+def test_x3_dynamic_range(xs, wsc):
+    """The supported range (include/pnnp_hip.h): a piece is a bf16 with the float32 exponent range, so the three pieces of |a| >=
+    2^-110 (7.7e-34) are all normal numbers and the split is exact; products and sums obey float32's own range.  Operands scaled
+    to 1e-30 / 1e+30 / both 1e-15 give results as accurate (vs float64) as at scale 1, and within 2x of the fp32-MFMA kernel."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 8, 32, 128, 32
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Ci, H, W, generator=gen) * xs
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.05 * wsc
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    f3, _ = _packs(w.cuda(), dgrad=False)
+    f32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), f32, None)
+    y3 = torch.empty((B, H, W, Co), device='cuda'); y32 = torch.empty_like(y3)
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f3, None, y3, Co, 0)
+    ops.conv_fwd(nhwc(x).cuda(), None, f32, None, y32, Co, 9, 0)
+    e3 = float((nchw(y3).cpu().double() - ref).norm() / ref.norm())
+    e32 = float((nchw(y32).cpu().double() - ref).norm() / ref.norm())
+    print(f'scale x {xs:g} w {wsc:g}: rel L2 vs float64 bf16x3 {e3:.2e}, fp32-MFMA {e32:.2e}')
+    assert torch.isfinite(y3).all()
+    assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7
+
+
+def test_x3_below_the_supported_range_degrades_gracefully():
+    """Below 2^-110 the `lo` (then `mid`) piece is a bf16 subnormal: whether the matrix core keeps or flushes it, the result loses
+    at most those pieces -- the error stays below 2^-8 relative (one piece) and the output finite.  Documented limit, not a
+    float32-accuracy claim."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 8, 32, 64, 32
+    gen = torch.Generator().manual_seed(6)
+    x = torch.randn(B, Ci, H, W, generator=gen) * 1e-36
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.5
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    f3, _ = _packs(w.cuda(), dgrad=False)
+    y3 = torch.empty((B, H, W, Co), device='cuda')
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f3, None, y3, Co, 0)
+    e3 = float((nchw(y3).cpu().double() - ref).norm() / ref.norm())
+    print(f'x at 1e-36 (below the supported 7.7e-34): rel L2 vs float64 {e3:.2e}')
+    assert torch.isfinite(y3).all() and e3 < 2.0 ** -7

@@ -67,10 +67,12 @@ def test_arch_proxy_runfile_trains_on_noiseflow_samples(capsys, monkeypatch):
     rf = os.path.join(HERE, 'fixtures', 'runfile_imx686_nf.yml')
     cfg = runfile.load(rf)
     np.random.seed(0); torch.manual_seed(0)
-    net, step, lr_of, sh = runfile.build(cfg)
+    with pytest.raises(FileNotFoundError):                                                     # trainer_SID.py:39-40 / trainer_LRID.py:36-37: torch.load fails hard
+        runfile.build(cfg)
+    net, step, lr_of, sh = runfile.build(cfg, allow_uninitialised_proxy=True)
     assert isinstance(step.proxy_net, archs.NoiseFlow) and step.proxy_net.training             # trainer_LRID.py:37-39 never calls .eval()
     cfg_sid = runfile.load(rf); cfg_sid['dst_train']['dataset'] = 'NF_Syn_Dataset'
-    assert not runfile.build_proxy(cfg_sid).training                                           # trainer_SID.py:42 does
+    assert not runfile.build_proxy(cfg_sid, allow_uninitialised_proxy=True).training                                           # trainer_SID.py:42 does
     assert step.proxy_ratio_choices == (1, 2, 4, 8, 16)
     calls = []
     real = step.proxy_net.sample
@@ -79,7 +81,7 @@ def test_arch_proxy_runfile_trains_on_noiseflow_samples(capsys, monkeypatch):
     hr = torch.rand(sh['batch'], sh['channels'], 64, 64, device='cuda') * 0.05
     out = step.step(hr, iso=6400)
     assert calls == [6400] and torch.isfinite(out).all()
-    assert runfile.main([rf, '--synthetic', '--epochs', '2', '--steps', '3']) == 0
+    assert runfile.main([rf, '--synthetic', '--epochs', '2', '--steps', '3', '--allow-uninitialised-proxy']) == 0
     assert len([l for l in capsys.readouterr().out.splitlines() if l.startswith('Epoch')]) == 2
     del cfg['arch_proxy']
     with pytest.raises(KeyError):
