@@ -70,7 +70,7 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(H, W, budget_s=90.0):
+def cpu_baseline(H, W, budget_s=75.0):
     """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py + oracle/noise_np.py), timed on this
     box's host cores by the protocol of BASELINE.md section 3: per crop `sample_params_max('SonyA7S2')` ->
     `generate_noisy_torch('pr', clip=2)` -> clamp -> UNetSeeInDark nf=32 forward -> L1(clamp) -> backward -> Adam(lr 1e-4),
@@ -79,9 +79,12 @@ def cpu_baseline(H, W, budget_s=90.0):
       * one thread (the reference exports OMP_NUM_THREADS=1, utils/utils.py:2) on B = 1 crop        -> `one_thread`
     with the four buckets the reference's tqdm line shows (trainer_SID.py:81-123): dataloader (here: synthetic clean crops),
     preprocess (parameters + sampler + clamp), net (forward), bp (loss + backward + Adam).
-    Bounded by `budget_s` seconds (--cpu-baseline-seconds; 3/4 for the all-cores leg, 1/4 for the one-thread leg): a leg that
-    runs out of budget stops after the step in progress -- warm-ups first, at least one timed step -- and the record says how
-    many warm-up / timed steps it actually did (`protocol_complete` false), instead of silently shrinking the sample."""
+    Bounded by `budget_s` seconds (--cpu-baseline-seconds; the one-thread leg runs first within 1/4 of it, the all-cores leg gets
+    the rest): a leg that runs out of budget stops after the step in progress -- warm-ups first, at least one timed step -- and
+    the record says how many warm-up / timed steps it actually did (`protocol_complete` false), instead of silently shrinking
+    the sample.  On the pool's 128-core hosts one all-cores step of 16 crops takes ~23 s (torch-CPU convolutions scale poorly
+    past ~32 threads: round 2 measured 1.39 crops/s with 32 threads on 4 crops), so the complete protocol needs
+    --cpu-baseline-seconds 200; profiles/r3/cpu_baseline_full.json holds such a run."""
     import numpy as np
     import torch
     from oracle import net_torch as O, noise_np as N
@@ -138,8 +141,9 @@ def cpu_baseline(H, W, budget_s=90.0):
         return dict(value=batch * done_timed / total, timed_s=total, warmup_steps=done_warm, timed_steps=done_timed, batch=batch, threads=threads,
                     split={k: round(val / done_timed, 3) for k, val in buckets.items()})
 
-    A = leg(all_cores, 16, 2, 5, 0.75 * budget_s)
-    O1 = leg(1, 1, 2, 5, 0.25 * budget_s)
+    t_all = time.perf_counter()
+    O1 = leg(1, 1, 2, 5, 0.25 * budget_s)                  # the cheap leg first (~12 s) ...
+    A = leg(all_cores, 16, 2, 5, budget_s - (time.perf_counter() - t_all))       # ... the rest of the budget for the all-cores leg
     torch.set_num_threads(all_cores)
     # the dataloader-side sampler (generate_noisy_obs: numpy, one core, as a DataLoader worker runs it), one crop per code
     obs = {}
@@ -192,7 +196,7 @@ def main():
     ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
                     help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-seconds', type=float, default=90.0,
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=75.0,
                     help='time budget of the CPU baseline legs (BASELINE.md section 3 protocol: B=16, 2 warm-up + 5 timed steps, all physical cores + 1 thread); '
                          'a leg that runs out stops early and says so')
     ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '

@@ -170,9 +170,9 @@ int pnnp_pack_jobs_add_conv3x3s2_dgrad(PnnpPackJob* jobs, int* n, int cap, const
  * pnnp_conv_bwd_data_res_f32 with taps = 9 (archs/Unet.py:16-52,54-92; archs/modules.py:176-197); the weights are x3 packs:
  * kind-2 jobs of the pack table, pnnp_x3_weight_bytes(K, N) bytes each (K = channels reduced over, N = channels written). */
 int pnnp_x3_supported(int K, int N);
-/* size limit of the bf16x3 forward / backward-data / pointwise kernels: one image [H][W][cstride] of every map they touch must
- * fit a 32-bit byte offset ((H + 4) W cstride 4 < 2^31); beyond it the launchers return PNNP_E_UNSUPPORTED -- ask first and run the
- * layer on the fp32-MFMA families (pnnp_conv_* / pnnp_conv3x3_wino_*), which the Python engines do.
+/* size limit of the convolution kernels (bf16x3 AND fp32-MFMA families: all address one image through a buffer resource): one
+ * image [H][W][cstride] of every map they touch must fit a 32-bit byte offset ((H + 4) W cstride 4 < 2^31); beyond it the launchers
+ * return PNNP_E_UNSUPPORTED -- ask first and tile the frame (the Python engines refuse such a frame before launching anything).
  * bf16x3 dynamic range: a piece is a bf16, which has float32's exponent range, so for 2^-110 (7.7e-34) <= |a| <= float32 max all
  * three pieces are normal numbers and hi + mid + lo == a exactly; below that the lo (then mid) piece becomes a bf16 subnormal and
  * may be flushed by the matrix core: accuracy degrades gracefully to 16 (8) significand bits, never to garbage

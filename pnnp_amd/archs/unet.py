@@ -102,12 +102,15 @@ class _EngineBase:
         self._jobs_key = None
 
     def effective_policy(self, H, W, cs_max):
-        """The policy a forward on [.,.,H,W] inputs runs with: the bf16x3 forward / backward-data / pointwise kernels address one
-        image of a map with 32-bit byte offsets (pnnp_x3_image_fits); an input whose largest map ([H][W][cs_max]) is past that runs
-        on the fp32-MFMA families, chosen HERE -- before the weights are packed -- rather than failing in the launcher."""
-        if self.policy.x3 and not ops.x3_image_fits(H, W, cs_max):
-            p = self.policy
-            return ConvPolicy(wino=p.wino, wino_wgrad=p.wino_wgrad, wino_mink=p.wino_mink, x3=False, thin=p.thin, pool_fused=p.pool_fused)
+        """The policy a forward on [.,.,H,W] inputs runs with (also what its backward uses, whatever set_policy does in between).
+        Every convolution kernel of the library -- bf16x3 and fp32-MFMA families alike -- addresses ONE image of a map through a
+        buffer resource with 32-bit byte offsets, so the largest map of the network ([H][W][cs_max] floats) must stay below 2 GB
+        per image (pnnp_x3_image_fits; ~16.7 M pixels at nf = 32).  A larger frame is refused HERE, before anything is packed or
+        launched, instead of failing with PNNP_E_UNSUPPORTED somewhere inside the network: tile the frame.  (The batch-wide limit of
+        the bf16x3 backward-weight kernel is different: past it the layer falls back to the fp32 kernels, ConvPolicy.use_x3_wgrad.)"""
+        if not ops.x3_image_fits(H, W, cs_max):
+            raise PnnpError(f'frame {H} x {W} is too large for the HIP convolution kernels: one image of a {cs_max}-channel map must stay '
+                            f'below 2 GB ((H + 4) * W * {cs_max} * 4 bytes); run the frame in tiles')
         return self.policy
 
     def mark_dirty(self):

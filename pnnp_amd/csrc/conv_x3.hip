@@ -44,8 +44,24 @@ namespace {
 #endif
 constexpr int NWAVE = X3_NWAVE, NTHR = 64 * NWAVE, MT = 16 / NWAVE;
 constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row tile, 612 halo pixels
+#ifndef X3_M16
+#define X3_M16 1                   // 1: v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (see mfma_row16); 0: v_mfma_f32_32x32x16_bf16
+#endif
+#if X3_M16
+// halo image in 16-byte words: [piece 3][k-octet 2][pixel, plane padded to a multiple of 16 words].  A 16x16x32 operand read takes
+// lanes 0-15 / 16-31 of a bank group from the two octet planes: with the plane stride a multiple of 256 bytes the ds_read_b128 is
+// conflict-free (the lane groups of the instruction are {0-3,12-15,20-27} and {4-11,16-19,28-31}).
+constexpr int NPIXP = (NPIX + 15) / 16 * 16;                       // 624
+constexpr int XS_F4 = 3 * 2 * NPIXP;
+#define XS_PLANE(piece, oct) (((piece) * 2 + (oct)) * NPIXP)
+constexpr int XS_PIECE_STRIDE = 2 * NPIXP;
+#else
+constexpr int NPIXP = NPIX;
 constexpr int XS_F4 = 2 * 3 * NPIX;                                // one halo image in 16-byte words: [k-octet 2][piece 3][pixel]
-constexpr int XS_BYTES = XS_F4 * 16;                               // 58752
+#define XS_PLANE(piece, oct) (((oct) * 3 + (piece)) * NPIX)
+constexpr int XS_PIECE_STRIDE = NPIX;
+#endif
+constexpr int XS_BYTES = XS_F4 * 16;                               // 58752 (59904 with padded planes)
 constexpr int WBLK = 3 * 2 * 3 * 32 * 16;                          // one filter row of one 32-channel block: [tap 3][octet 2][piece 3][32][16 B] = 9216
 constexpr int NSLOT = (2 * NPIX + NTHR - 1) / NTHR;                 // halo staging slots per thread: 1224 (pixel, octet) pairs / 512 -> 3
 constexpr int NSLICE = 4 * NSLOT;                                  // staging slices (two floats each) per chunk
@@ -58,11 +74,23 @@ template <int BN> struct X3Cfg {
     // Weight ring: BN = 64 requests an item's weights one item ahead (an item is 72 MFMAs per wave, ~2.3 us with two waves
     // per SIMD: more than the L2 round trip); a BN = 32 item is half as long, so its weights are requested TWO items ahead.
     static constexpr int NSTAGE = BN == 32 ? 3 : 2, AHEAD = NSTAGE - 1;
-    static constexpr int EPI = NWAVE * 2048;                       // per wave: (16 pixels x 32 channels) floats
+#if X3_M16
+    // epilogue patch per wave: 16 pixels x 32 channels of floats; rows padded to 36 floats where the patch aliases a weight stage
+    // (a 16x16 accumulator block puts pixel 4 q + r on lane group q: with 32-float rows the four groups write the same banks)
+    static constexpr int EPS = BN == 64 ? 36 : 32;
+#else
+    static constexpr int EPS = 32;
+#endif
+    static constexpr int EPI = NWAVE * 16 * EPS * 4;               // per wave: (16 pixels x 32 channels) floats
     // BN = 64: the epilogue patches live in the weight stage the tile's last item has just consumed (a barrier in between)
     static constexpr bool EPI_ALIAS = WS_STAGE >= EPI;
     static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // 154368 / 161536
 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {                  // f(integral_constant<int, I>) ... for I .. N - 1: every index a constant
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 
 __device__ __forceinline__ int xcd_remap(int id, int n) {
     const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
@@ -117,7 +145,7 @@ igemm_x3_kernel(const IgemmArgs a) {
         rk[k] = r - 1;
         qk[k] = q - 1;
         pixk[k] = (unsigned)(r * a.IW + q);
-        xdst[k] = (oct * 3) * NPIX + pix;                           // + piece * NPIX (+ image * XS_F4)
+        xdst[k] = XS_PLANE(0, oct) + pix;                           // + piece * XS_PIECE_STRIDE (+ image * XS_F4)
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
     auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned voff, int soff) {
@@ -176,7 +204,7 @@ igemm_x3_kernel(const IgemmArgs a) {
         sh[k][p] = h; sm[k][p] = m; sl[k][p] = l;
         if (p == 3) {
             u32x4* d = xs + img * XS_F4 + xdst[k];
-            d[0] = sh[k]; d[NPIX] = sm[k]; d[2 * NPIX] = sl[k];
+            d[0] = sh[k]; d[XS_PIECE_STRIDE] = sm[k]; d[2 * XS_PIECE_STRIDE] = sl[k];
         }
     };
     // the same slice as five dependent pieces of 1-4 VALU instructions (step 0 .. 4) + the stores (step 5), one piece per MFMA gap
@@ -197,7 +225,7 @@ igemm_x3_kernel(const IgemmArgs a) {
             sl[k][p] = cvt_pk_bf16(pa0[u], pa1[u]);
         } else if (p == 3) {
             u32x4* d = xs + img * XS_F4 + xdst[k];
-            d[0] = sh[k]; d[NPIX] = sm[k]; d[2 * NPIX] = sl[k];
+            d[0] = sh[k]; d[XS_PIECE_STRIDE] = sm[k]; d[2 * XS_PIECE_STRIDE] = sl[k];
         }
     };
     // LDS-DMA of the weights of item (tile n0, chunk g, filter row tr) into stage st: per 32-channel block 9216 contiguous
@@ -223,6 +251,33 @@ igemm_x3_kernel(const IgemmArgs a) {
         for (int i = 0; i < Cfg::DPW; ++i) dma_piece(tl, g, tr, st, valid, i);
     };
 
+#if X3_M16
+    // 16 x 16 accumulator blocks: acc[2 i + h][j] = pixel row i of the wave, 16-pixel half h, channels 16 j .. 16 j + 15;
+    // lane l holds channel l & 15 of pixels 4 (l >> 4) + r, r = 0 .. 3
+    constexpr int MB = 2 * MT, NB = BN / 16;
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q16 = lane >> 4, oct16 = q16 & 1, ps16 = q16 >> 1;
+    // operand forms (two pieces concatenated along K = 32: k-blocks 0,1 = the 16 channels of the first piece, 2,3 = of the second):
+    //   A form 0 = [hi | mid], form 1 = [hi | lo];   B form 0 = [hi' | hi'], 1 = [mid' | mid'], 2 = [lo' | hi']
+    //   A1 B2 = hi lo' + lo hi',  A0 B1 = hi mid' + mid mid',  A0 B0 = hi hi' + mid hi'  -- the six products of the bf16x3 scheme
+    const int aoff0 = XS_PLANE(ps16 ? 1 : 0, oct16) + r16, aoff1 = XS_PLANE(ps16 ? 2 : 0, oct16) + r16;            // 16-byte words
+    const int boff0 = ((oct16 * 3 + 0) * 32 + r16) * 16, boff1 = ((oct16 * 3 + 1) * 32 + r16) * 16,
+              boff2 = ((oct16 * 3 + (ps16 ? 0 : 2)) * 32 + r16) * 16;                                            // bytes inside one tap
+    // the 8 accumulator values of a lane for (pixel row i, 32-column block k, 16-pixel half h2) -> the wave's patch [16 px][EPS]
+    auto spill_half = [&](float* eb, int i, int k, int h2) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                eb[(4 * q16 + r) * Cfg::EPS + nb * 16 + r16] = acc[2 * i + h2][2 * k + nb][r];
+                acc[2 * i + h2][2 * k + nb][r] = 0.f;
+            }
+    };
+#else
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -230,7 +285,78 @@ igemm_x3_kernel(const IgemmArgs a) {
         for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto spill_half = [&](float* eb, int i, int k, int h2) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][8 * h2 + r];
+            acc[i][k][8 * h2 + r] = 0.f;
+        }
+    };
+#endif
 
+#if X3_M16
+    // MFMA over the three taps of filter row tr on v_mfma_f32_16x16x32_bf16 (halo image img, weight stage st).
+    // K = 32 of one instruction = the tap's 16 channels of one piece ++ the same 16 channels of another piece (the forms above), so
+    // the six piece products of a (16 px x 16 ch) block are THREE instructions, and a chunk stays 16 channels -- no tap pairing,
+    // no second halo image.  The 16x16x32 shape does the same multiply-adds per cycle as 32x32x16 at less energy per FLOP (the
+    // chip is power-limited here: DESIGN section 5; bare loops on random data: +9-14 %).
+    // Order per tap: pass j (16 output channels) x pixel block mb x the three products, smallest terms first.  Operands: the 8 A
+    // words of the tap (4 pixel blocks x 2 forms) stay in registers for all passes and are refreshed IN PLACE for the next tap
+    // during the last pass (form 1 right after its only use, form 0 after the block's third MFMA: >= 10 gaps ahead of their next
+    // use); the 3 B words of a pass are read one pass ahead into the other of two register sets.  Everything that is not an MFMA
+    // sits in the gaps between MFMAs, one or two instructions per gap, fenced (as in the 32x32x16 version below):
+    //   reads as just described; FILL: the 72 (slice, step) units of the next chunk's halo staging (one per gap at BN = 32, every
+    //   other gap at BN = 64); `requests`: the item's LDS-DMA / halo-load pieces in read-free gaps of pass 1 (BN = 64) or 0.
+    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests) {
+        constexpr bool FILL = decltype(fill_tag)::value;
+        constexpr int NHP = decltype(halo_tag)::value ? NSLOT + 1 : 0;
+        constexpr int GT = NB * MB * 3;                             // MFMAs (= gaps) per tap
+        const char* wst = wsb + st * Cfg::WS_STAGE;
+        const u32x4* xim = xs + img * XS_F4;
+        u32x4 A[MB][2], Bv[2][3];
+        auto a_read = [&](int tp, int mb, int f) {
+            A[mb][f] = xim[(f ? aoff1 : aoff0) + (wave * MT + (mb >> 1) + tr) * HC + tp + 16 * (mb & 1)];
+        };
+        auto b_read = [&](int tp, int j, int f, int buf) {
+            Bv[buf][f] = *reinterpret_cast<const u32x4*>(wst + (j >> 1) * WBLK + tp * 3072 + (f == 0 ? boff0 : (f == 1 ? boff1 : boff2)) + (j & 1) * 256);
+        };
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { a_read(0, mb, 1); a_read(0, mb, 0); }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) b_read(0, 0, 2 - f, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, 3 * GT>([&](auto G) {
+            constexpr int g = decltype(G)::value;
+            constexpr int tp = g / GT, gt = g % GT, j = gt / (MB * 3), w = gt % (MB * 3), mb = w / 3, sp = w % 3;
+            constexpr int pass = tp * NB + j, buf = pass & 1;
+#define X3_MFMA16(FA, FB) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[mb][FA]), __builtin_bit_cast(bf16x8, Bv[buf][FB]), acc[mb][j], 0, 0, 0)
+            if constexpr (sp == 0) X3_MFMA16(1, 2);                 // hi lo' + lo hi'
+            else if constexpr (sp == 1) X3_MFMA16(0, 1);            // hi mid' + mid mid'
+            else X3_MFMA16(0, 0);                                   // hi hi' + mid hi'
+#undef X3_MFMA16
+            // the next pass's B words (first needed 12 - w gaps from here), smallest-term form first
+            if constexpr (w < 3 && pass + 1 < 3 * NB) b_read((pass + 1) / NB, (pass + 1) % NB, 2 - w, buf ^ 1);
+            // the next tap's A words, in place, during the tap's last pass
+            if constexpr (j == NB - 1 && tp < 2) {
+                if constexpr (sp == 0) a_read(tp + 1, mb, 1);
+                if constexpr (sp == 2) a_read(tp + 1, mb, 0);
+            }
+            if constexpr (FILL) {
+                constexpr int STRIDE = 3 * GT / (NSLICE * 6);       // gaps per staging unit: 1 (BN = 32) or 2 (BN = 64)
+                static_assert(3 * GT == STRIDE * NSLICE * 6, "staging units per filter row");
+                if constexpr (g % STRIDE == STRIDE - 1) stage_piece((g / STRIDE) / 6, 0, (g / STRIDE) % 6, img ^ 1);
+            }
+            // requests: gaps w = 4, 6, 8, 10 of pass RP (no operand reads there; at BN = 64 no staging unit either)
+            constexpr int RP = NB > 2 ? 1 : 0;
+            if constexpr (j == RP && w >= 4 && (w & 1) == 0) {
+                constexpr int rp = (w - 4) / 2;
+                if constexpr (tp == 0 && rp < Cfg::DPW) requests(rp);
+                if constexpr (tp == 1 && rp < NHP) requests(Cfg::DPW + rp);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+#else
     // MFMA over the three taps of filter row tr: halo image img, weight stage st.  FILL: the 12 staging slices of the next
     // chunk's halo (into image img ^ 1) are dealt over the 3 * MT * NT groups of six MFMAs.  `requests` (the LDS-DMA / halo
     // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right after the first group
@@ -342,11 +468,13 @@ igemm_x3_kernel(const IgemmArgs a) {
 #endif
     };
 
+#endif      // X3_M16
+
     // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
     // channel base are wave-uniform per 32-column block); half a 32x32 tile (16 pixels) at a time through a 2 KB patch
     auto epilogue = [&](const Tile& tl, float* epi) {
         const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
-        float* eb = epi + wave * 512;
+        float* eb = epi + wave * (16 * Cfg::EPS);
         const int q4 = (lane & 7) * 4, pr = lane >> 3;
         if constexpr (POOL) {
             // Forward layer in front of MaxPool2d(2) (archs/Unet.py:35,41,47,53): single destination, bias + activation only.
@@ -377,14 +505,10 @@ igemm_x3_kernel(const IgemmArgs a) {
                     const bool ok2 = py0 < a.DH && px < a.DW && n_ok;            // even sizes: the whole window is inside or outside
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                        for (int r = 0; r < 8; ++r) {
-                            eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][8 * h2 + r];
-                            acc[i][k][8 * h2 + r] = 0.f;
-                        }
+                        spill_half(eb, i, k, h2);
 #pragma unroll
                         for (int e = 0; e < 2; ++e) {
-                            f32x4 o = *reinterpret_cast<const f32x4*>(eb + (2 * pr + e) * 32 + q4) + bias4;
+                            f32x4 o = *reinterpret_cast<const f32x4*>(eb + (2 * pr + e) * Cfg::EPS + q4) + bias4;
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
                             win[i][e] = o;
@@ -463,11 +587,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 const bool rowok = py < a.DH;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        eb[((r & 3) + 8 * (r >> 2) + 4 * half) * 32 + l31] = acc[i][k][8 * h2 + r];
-                        acc[i][k][8 * h2 + r] = 0.f;
-                    }
+                    spill_half(eb, i, k, h2);
                     unsigned vo[2];
                     f32x4 v2[2], m2[2], ad2[2];
 #pragma unroll
@@ -475,7 +595,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                         const int p = pr + 8 * e, px = x0 + 16 * h2 + p;
                         const bool ok2 = rowok && px < a.DW && n_ok;
                         vo[e] = ok2 ? (unsigned)(((py * a.OW + px) * cs2 + chw + q4) * 4) : OOB;
-                        v2[e] = *reinterpret_cast<const f32x4*>(eb + p * 32 + q4);
+                        v2[e] = *reinterpret_cast<const f32x4*>(eb + p * Cfg::EPS + q4);
                     }
                     if (mm2) {
 #pragma unroll

@@ -41,6 +41,18 @@ struct Wx3Args {
 
 constexpr int NTHR = 512, NWAVE = 8;
 
+// Alternating signs over the pixel splits.  Measured (tools/x3_bias_probe.py, profiles/r3/x3_bias_probe.txt): the bf16 matrix core
+// does not round its accumulation to nearest -- every v_mfma_f32_*_bf16 leaves an error of about -2^-25 of the magnitude of the 16-term
+// dot product it adds, ALWAYS towards minus infinity, whatever the signs.  Over K accumulated terms that is a coherent offset of
+// ~ -K 2^-27 |term|: nothing against a sum of K same-signed terms, but against a gradient whose terms cancel (sum ~ sqrt(K) |term|)
+// it is sqrt(K) 2^-27 relative -- 4e-6 at the top level's K = 16 x 512 x 512 pixels, 5x the fp32-MFMA kernel's error.
+// The offset does not depend on the data's sign, so it cancels between two partial sums accumulated with OPPOSITE signs: workgroups
+// with an odd pixel-split index z stage -G (one v_xor per value while splitting), their slabs hold -partial, and the reduce kernel
+// adds the slabs with alternating signs.  No extra MFMA; the result is the same sum with the drift removed (to its fluctuation).
+#ifndef WX3_ALT_SIGN
+#define WX3_ALT_SIGN 1
+#endif
+
 template <int WM, int WN, int TH>
 struct Wx3Cfg {
     static constexpr int WK = NWAVE / (WM * WN);
@@ -129,6 +141,11 @@ wgrad_x3_kernel(const Wx3Args a) {
 
     f32x4 rg[NG], rx[NX];
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+    const unsigned sflip = (WX3_ALT_SIGN && (z & 1)) ? 0x80000000u : 0u;    // odd pixel splits accumulate -G * X (see WX3_ALT_SIGN)
+    auto gsign = [&](f32x4 v) {
+        return f32x4{__uint_as_float(__float_as_uint(v.x) ^ sflip), __uint_as_float(__float_as_uint(v.y) ^ sflip),
+                     __uint_as_float(__float_as_uint(v.z) ^ sflip), __uint_as_float(__float_as_uint(v.w) ^ sflip)};
+    };
     auto load_tile = [&](int tile) {
         int q = tile;
         const int tx = q % tiles_x; q /= tiles_x;
@@ -154,7 +171,7 @@ wgrad_x3_kernel(const Wx3Args a) {
     auto stage_slice = [&](int s, int img) {
         char* ib = smem + img * Cfg::IMG_BYTES;
         const bool isg = s < NG;
-        const f32x4 v = isg ? rg[isg ? s : 0] : rx[isg ? 0 : s - NG];
+        const f32x4 v = isg ? gsign(rg[isg ? s : 0]) : rx[isg ? 0 : s - NG];
         const int dst = isg ? g_dst[isg ? s : 0] : x_dst[isg ? 0 : s - NG];
         const int pstride = (isg ? GPIX : XPIX) * 64;
         unsigned h0, m0_, l0, h1, m1, l1;
@@ -176,7 +193,7 @@ wgrad_x3_kernel(const Wx3Args a) {
     auto stage_piece = [&](int sl, int step, int img) {
         const bool isg = sl < NG;
         switch (step) {
-        case 0: pv = isg ? rg[isg ? sl : 0] : rx[isg ? 0 : sl - NG]; ph[0] = cvt_pk_bf16(pv.x, pv.y); ph[1] = cvt_pk_bf16(pv.z, pv.w); break;
+        case 0: pv = isg ? gsign(rg[isg ? sl : 0]) : rx[isg ? 0 : sl - NG]; ph[0] = cvt_pk_bf16(pv.x, pv.y); ph[1] = cvt_pk_bf16(pv.z, pv.w); break;
         case 1: if (isg) { bsum[0] = fmaf(pv.x, bmul, bsum[0]); bsum[1] = fmaf(pv.y, bmul, bsum[1]); bsum[2] = fmaf(pv.z, bmul, bsum[2]); bsum[3] = fmaf(pv.w, bmul, bsum[3]); } break;
         case 2: pv.x -= __uint_as_float(ph[0] << 16); pv.y -= __uint_as_float(ph[0] & 0xffff0000u); break;
         case 3: pv.z -= __uint_as_float(ph[1] << 16); pv.w -= __uint_as_float(ph[1] & 0xffff0000u); break;
@@ -409,11 +426,12 @@ wgrad_x3_kernel(const Wx3Args a) {
 #endif
 }
 
-// out[o(i)] (+)= sum_z slab[z][i]; i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t  (the parameter's own layout)
+// out[o(i)] (+)= sum_z (-1)^z slab[z][i] (odd splits accumulated -G * X: WX3_ALT_SIGN); i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t  (the parameter's own layout)
 __global__ void __launch_bounds__(256)
 wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate, int64_t mn, int taps) {
     __shared__ float red[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float sg = (WX3_ALT_SIGN && (ty & 1)) ? -1.f : 1.f;      // a thread row sums splits ty, ty + 8, ...: one parity, one sign (odd splits hold -partial)
     for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n; i0 += (int64_t)gridDim.x * 32) {
         const int64_t i = i0 + tx;
         float s0 = 0.f, s1 = 0.f;
@@ -422,7 +440,7 @@ wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64
             for (; zz + 8 < Z; zz += 16) { s0 += slab[(int64_t)zz * n + i]; s1 += slab[(int64_t)(zz + 8) * n + i]; }
             for (; zz < Z; zz += 8) s0 += slab[(int64_t)zz * n + i];
         }
-        red[ty][tx] = s0 + s1;
+        red[ty][tx] = sg * (s0 + s1);
         __syncthreads();
         if (ty == 0 && i < n) {
             float s = 0.f;

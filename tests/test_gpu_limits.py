@@ -1,6 +1,7 @@
-"""Size limits of the bf16x3 kernels (32-bit byte offsets: include/pnnp_hip.h, pnnp_x3_image_fits / pnnp_x3_wgrad_fits) and the
-engines' fallback to the fp32-MFMA families past them (the policy used to check channel divisibility only and
-`check()` raised PNNP_E_UNSUPPORTED in the middle of backward for B = 64 crops of 512 x 512 at nf = 32)."""
+"""Size limits of the convolution kernels (32-bit byte offsets: include/pnnp_hip.h, pnnp_x3_image_fits / pnnp_x3_wgrad_fits) and
+what the engines do past them (the policy used to check channel divisibility only and `check()` raised
+PNNP_E_UNSUPPORTED in the middle of backward for B = 64 crops of 512 x 512 at nf = 32): the batch-wide limit of the bf16x3
+backward-weight kernel falls back to the fp32 kernels; the per-image limit, which every family shares, is refused up front."""
 import pytest
 import torch
 
@@ -10,7 +11,7 @@ pytestmark = pytest.mark.gpu
 def test_fit_queries_mirror_the_launchers():
     from pnnp_amd import ops
     assert ops.x3_image_fits(512, 512, 32) and ops.x3_image_fits(1424, 2128, 64)
-    assert not ops.x3_image_fits(4096, 4112, 32)                     # (H + 4) W C 4 >= 2^31
+    assert not ops.x3_image_fits(4096, 4112, 32)                     # (H + 4) W C 4 >= 2^31: refused by every family (test below)
     assert ops.x3_wgrad_fits(16, 512, 512, 32) and ops.x3_wgrad_fits(16, 512, 512, 64)
     assert not ops.x3_wgrad_fits(64, 512, 512, 32) and not ops.x3_wgrad_fits(16, 1024, 1024, 32)
     # the launcher agrees: one launch past the limit is refused with PNNP_E_UNSUPPORTED, not executed with wrapped offsets
@@ -56,24 +57,22 @@ def test_train_step_past_the_wgrad_limit_falls_back_instead_of_failing():
     assert rel < 2e-3, rel                                            # different kernels + split-K partitions: float32 rounding level
 
 
-def test_single_frame_past_the_image_limit_runs_on_the_fp32_families():
-    """An eval frame whose top-level map exceeds 2 GB per image (4 x 4096 x 4112 at nf = 32): effective_policy switches the whole
-    forward to the fp32-MFMA families before packing; the result is bit-identical to the forward with x3 switched off by hand."""
-    from pnnp_amd.archs import UNetSeeInDark, initialize_weights
+def test_single_frame_past_the_image_limit_is_refused_up_front():
+    """Every convolution kernel (bf16x3 and fp32-MFMA alike) addresses one image of a map with 32-bit byte offsets: a frame whose
+    top-level map exceeds 2 GB per image (4 x 4096 x 4112 at nf = 32) cannot run untiled.  The engine says so BEFORE packing or
+    launching anything -- not with PNNP_E_UNSUPPORTED from some layer in the middle of the network -- and stays usable."""
+    from pnnp_amd._lib import PnnpError
+    from pnnp_amd.archs import ResUnet, UNetSeeInDark, initialize_weights
     torch.manual_seed(4)
-    net = UNetSeeInDark(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
-    initialize_weights(net)
-    net = net.cuda().eval()
-    x = torch.rand(1, 4, 4096, 4112, device='cuda')
-    assert net.engine.policy.x3
-    with torch.no_grad():
-        y = net(x).clone()
-    assert not net.engine._pol.x3 and net.engine.policy.x3            # this forward fell back; the user's policy is untouched
-    assert torch.isfinite(y).all()
-    with torch.no_grad():
-        small = net(x[:, :, :512, :512])                              # a frame that fits goes back to bf16x3
-    assert net.engine._pol.x3 and torch.isfinite(small).all()
-    net.engine.set_policy(x3=False)
-    with torch.no_grad():
-        y2 = net(x)
-    assert torch.equal(y, y2)
+    for cls in (UNetSeeInDark, ResUnet):
+        net = cls(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4))
+        initialize_weights(net)
+        net = net.cuda().eval()
+        x = torch.zeros(1, 4, 4096, 4112, device='cuda')
+        gen0 = net.engine.gen
+        with torch.no_grad(), pytest.raises(PnnpError, match='too large'):
+            net(x)
+        assert net.engine.gen == gen0 and not net.engine.bufs                # nothing was allocated or launched
+        with torch.no_grad():
+            small = net(torch.rand(1, 4, 256, 256, device='cuda'))           # the engine is still usable
+        assert torch.isfinite(small).all()

@@ -365,7 +365,7 @@ def test_x3_dynamic_range(xs, wsc):
     e32 = float((nchw(y32).cpu().double() - ref).norm() / ref.norm())
     print(f'scale x {xs:g} w {wsc:g}: rel L2 vs float64 bf16x3 {e3:.2e}, fp32-MFMA {e32:.2e}')
     assert torch.isfinite(y3).all()
-    assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7
+    assert e3 < 2.0 * e32 + 1e-8 and e3 < 1e-6          # (uniform-scale data at K = 1152: ~5e-7 for both kernels, tools/x3_bias_probe.py)
 
 
 def test_x3_below_the_supported_range_degrades_gracefully():
