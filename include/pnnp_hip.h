@@ -302,6 +302,10 @@ int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x,
 /* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);
  * the NCHW result can add a residual (arch 'res' flag, archs/Unet.py:95-98). */
 int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream);
+/* the same into a frame that is reflect-padded by `pad` pixels on every side, dst [B][H+2pad][W+2pad][Cp]: the eval loop's
+ * F.pad(imgs_lr, (4,4,4,4), mode='reflect') for frames whose width is not a multiple of 16 (trainer_SID.py:221-226), folded into the
+ * layout change the network input goes through anyway */
+int pnnp_nchw_to_nhwc_reflect_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, void* stream);
 int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual /*or null*/, float* dst,
                           int B, int C, int H, int W, int Cp, void* stream);
 /* out[c] (+)= sum over pixels (bias gradient of a ConvTranspose2d); workspace >= 1024*C floats */
@@ -315,6 +319,10 @@ int pnnp_l1_clamp_loss_f32(const float* pred, const float* hr, float* grad_nhwc,
                            int B, int C, int H, int W, int Cp, float* workspace, void* stream);
 /* the same with the `ori` branch of the train loop (trainer_SID.py:97-99: pred = pred * ratio before the loss):
  * scale [B] (device, or null = 1) multiplies crop b's prediction first; loss, SSE and dL/dpred (x scale[b]) follow. */
+/* pnnp_l1_clamp_loss_scaled_f32 with the TARGET clamped to [0,1] inside the kernel when clamp_target != 0 (preprocess's
+ * `imgs_hr.clamp(0, 1)` under dst.clip, trainer_SID.py:485, without an elementwise pass of its own) */
+int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* scale /*[B] or null*/, float* grad_nhwc, float* loss_out,
+                              int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream);
 int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale /*[B] or null*/, float* grad_nhwc,
                                   float* loss_out, int B, int C, int H, int W, int Cp, float* workspace, void* stream);
 /* torch.optim.Adam step (trainer_SID.py:44,101) over a flat parameter buffer; step is 1-based;
@@ -331,6 +339,16 @@ int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, 
 int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, void* stream);
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul, void* stream);
+/* the same step with the trainer's preprocess around sample() fused in (trainer_SID.py:463-472,481-485; trainer_LRID.py:419-427):
+ * the clean crop is divided by clean_div[b] (or clean_div_s) where it enters the signal-dependent scale (`clean = imgs_hr / ratio`);
+ * with mix_base the result is clamp(mix_base + (sample * mix_mul[b] or mix_mul_s), clamp_lo, clamp_hi) (`imgs_lr = imgs_hr + noise *
+ * ratio; imgs_lr.clamp(lb, 1)`); flag (device int, or null): bit 0 is set when the scale a*clean + b is negative anywhere -- the
+ * reference's `assert scale >= 0` (signal_dependant.py:50) without a host round trip per step. */
+int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
+                         const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul,
+                         const float* clean_div /*[B] or null*/, float clean_div_s, const float* mix_base /*or null*/,
+                         const float* mix_mul /*[B] or null*/, float mix_mul_s, float clamp_lo, float clamp_hi, int* flag /*or null*/,
+                         void* stream);
 /* One [Conv2d1x1, AffineCoupling] pair of the forward (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130);
  * partial [B][ceil(H/32)*ceil(W/32)] receives the per-workgroup sums of the pixel-wise log-det terms. */
 int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H, int W, const float* step /*[host]*/,

@@ -442,7 +442,10 @@ class NoiseFlow(nn.Module):
             h1 = torch.empty((B, 4, H, W), **f32); h2 = torch.empty_like(h1)
             part = torch.empty(max(tiles, pb) * 8, **f32); bn = torch.empty(24, **f32)
             n = float(B * H * W)
-        for (vec, winv, g_after, s_after, host), (ac, _cv, _g, _s) in zip(self._tables(), self._plan()):
+        _clean_div, _mix, _defer_check = kwargs.get('_clean_div'), kwargs.get('_mix'), bool(kwargs.get('_defer_check', False))
+        tables, plan = self._tables(), self._plan()
+        n_pairs = len(plan)
+        for pair_index, ((vec, winv, g_after, s_after, host), (ac, _cv, _g, _s)) in enumerate(zip(tables, plan)):
             if train:
                 # batch statistics of this coupling's hidden maps for the tensor it is about to transform (its first two planes are
                 # the coupling network's input in both directions), folded into the BatchNorm scale / offset slots of the step table
@@ -473,10 +476,56 @@ class NoiseFlow(nn.Module):
                 beta1 = np.exp(host['s_beta1'] * cam[0]); beta2 = np.exp(host['s_beta2'] * cam[1])
                 gain = np.exp(host['s_gain'] * cam[2]) * np.float32(iso)
                 a, b, cl = np.float32(beta1 / gain), np.float32(beta2), clean
+            last = pair_index == n_pairs - 1
+            mix = _mix if (last and _mix is not None) else None
+            cdiv_t, cdiv_s = (None, 1.0)
+            if cl is not None and _clean_div is not None:
+                cdiv_t, cdiv_s = (_clean_div, 1.0) if torch.is_tensor(_clean_div) else (None, float(_clean_div))
+            flag = None
+            if cl is not None and _defer_check:
+                flag = self._flag(clean.device)                             # the device records a negative scale; check_scale_flag() reads it
+            elif cl is not None:
                 if float(a) * float(clean.min()) + float(b) < 0:
                     raise AssertionError('scale must be non-negative')      # signal_dependant.py:50
-            buf = (C.c_float * 317)(*vec.tolist())
-            _lib.check(L.pnnp_nf_step_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
-                                          C.c_float(1.0), _lib.stream()), 'nf_step')
+            buf = vec.ctypes.data_as(C.POINTER(C.c_float))
+            if mix is None and cdiv_t is None and cdiv_s == 1.0 and flag is None:
+                _lib.check(L.pnnp_nf_step_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
+                                              C.c_float(1.0), _lib.stream()), 'nf_step')
+            else:
+                base, mul, lo, hi = mix if mix is not None else (None, 1.0, 0.0, 0.0)
+                mul_t, mul_s = (mul, 1.0) if torch.is_tensor(mul) else (None, float(mul))
+                _lib.check(L.pnnp_nf_step_mix_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
+                                                  C.c_float(1.0), _lib.ptr(cdiv_t), C.c_float(cdiv_s), _lib.ptr(base), _lib.ptr(mul_t),
+                                                  C.c_float(mul_s), C.c_float(lo), C.c_float(hi),
+                                                  C.c_void_p(flag.data_ptr()) if flag is not None else None, _lib.stream()), 'nf_step_mix')
             cur, nxt = nxt, cur
         return cur
+
+    # ------------------------------------------------------------------ the trainer's preprocess around sample(), fused
+    def _flag(self, device):
+        f = getattr(self, '_scale_flag', None)
+        if f is None or f.device != device:
+            f = self._scale_flag = torch.zeros(1, dtype=torch.int32, device=device)
+        return f
+
+    def check_scale_flag(self):
+        """The reference asserts ``scale >= 0`` inside every sample() (signal_dependant.py:50), which costs a device-to-host round
+        trip per step.  ``sample_mixed`` records the condition in a device flag instead; this reads it (one sync) and raises the same
+        AssertionError if any sample since the last check saw a negative scale."""
+        f = getattr(self, '_scale_flag', None)
+        if f is not None and int(f.item()) != 0:
+            f.zero_()
+            raise AssertionError('scale must be non-negative')
+
+    def sample_mixed(self, hr, ratio, iso, clamp_lo=-float('inf'), clamp_hi=float('inf'), z=None):
+        """preprocess() of the proxy branches as ONE chain of kernels (trainer_SID.py:463-472,481-485; trainer_LRID.py:419-427):
+
+            clean = hr / ratio;  noise = sample(clean=clean, iso=iso) * ratio;  lr = (hr + noise).clamp(clamp_lo, clamp_hi)
+
+        ``ratio``: a host scalar (LRID: one per batch) or a tensor [B] / [B,1,1,1] (SID: one per crop).  The division happens where
+        the clean crop enters the signal-dependent scale, the multiply / add / clamp in the last step's store, and the scale >= 0
+        assertion is deferred to ``check_scale_flag``: no elementwise torch kernels, no host synchronisation."""
+        _lib.require_cuda(hr)
+        r = ratio.reshape(-1).contiguous().float() if torch.is_tensor(ratio) else float(ratio)
+        kw = {} if z is None else {'z': z}
+        return self.sample(clean=hr, iso=iso, _clean_div=r, _mix=(hr.contiguous().float(), r, float(clamp_lo), float(clamp_hi)), _defer_check=True, **kw)

@@ -172,11 +172,17 @@ class ResUnetEngine(_EngineBase):
         return ops.conv_bwd_data(gsrc, self.W[name][1], dx1, **kw)
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, train):
+    def forward(self, x, train, reflect_pad=0):
+        """``reflect_pad`` > 0 (eval loop, trainer_SID.py:221-226): the network runs on the frame reflect-padded by that many pixels on
+        every side -- the padding happens inside the NCHW -> NHWC layout pass, the result has the PADDED size (the caller crops)."""
         if not x.is_cuda:
             raise PnnpError('ResUnet.forward: input must be a CUDA tensor (pnnp_amd has no CPU path)')
         x = x.contiguous().float()
         B, Cin, H, Wd = x.shape
+        if reflect_pad:
+            if self.m.res or train:
+                raise PnnpError('reflect_pad is an eval-mode option of networks without the input residual')
+            H, Wd = H + 2 * reflect_pad, Wd + 2 * reflect_pad
         if Cin != self.cin or H % 16 or Wd % 16:
             raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
         dev = x.device
@@ -195,7 +201,7 @@ class ResUnetEngine(_EngineBase):
         g = lambda n, s: bufs.get(n, s, dev)
         hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
         a = {}
-        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad)
+        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
         if self._pol.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
             a['t0'] = ops.first_fwd(a['x8'], P['conv_in.weight'], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), RELU)
         else:

@@ -285,11 +285,17 @@ class UNetEngine(_EngineBase):
         return self.packed.get((name, dev, 'x3f')), self.packed.get((name, dev, 'x3d'))
 
     # ------------------------------------------------------------------ forward
-    def forward(self, x, train):
+    def forward(self, x, train, reflect_pad=0):
+        """``reflect_pad`` > 0 (eval loop, trainer_SID.py:221-226): the network runs on the frame reflect-padded by that many pixels on
+        every side -- the padding happens inside the NCHW -> NHWC layout pass, the result has the PADDED size (the caller crops)."""
         if not x.is_cuda:
             raise PnnpError('UNetSeeInDark.forward: input must be a CUDA tensor (pnnp_amd has no CPU path)')
         x = x.contiguous().float()
         B, Cin, H, W = x.shape
+        if reflect_pad:
+            if self.m.res or train:
+                raise PnnpError('reflect_pad is an eval-mode option of networks without the input residual')
+            H, W = H + 2 * reflect_pad, W + 2 * reflect_pad
         if Cin != self.cin or H % 16 or W % 16:
             raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
         dev = x.device
@@ -307,7 +313,7 @@ class UNetEngine(_EngineBase):
         ch = self.ch
         g = lambda n, s: bufs.get(n, s, dev)
         a = {}
-        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad)
+        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
 
         def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
             y = out if out is not None else g(name, (B, h, w, cout))

@@ -16,12 +16,21 @@ int grid1d(int64_t n, int cap = 256 * 8) {
 
 // [B][C][H][W] -> [B][H][W][Cp], channels >= C zero-filled (Cp multiple of 4).
 __global__ void __launch_bounds__(256)
-nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int Cp) {
-    const int64_t hw = (int64_t)H * W, total = (int64_t)B * hw * (Cp / 4);
+nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int Cp, int pad) {
+    // dst is [B][H + 2 pad][W + 2 pad][Cp]: pad > 0 reflects the frame (F.pad(..., mode='reflect'): index -k -> k, H-1+k -> H-1-k)
+    const int Ho = H + 2 * pad, Wo = W + 2 * pad;
+    const int64_t hw = (int64_t)H * W, hwo = (int64_t)Ho * Wo, total = (int64_t)B * hwo * (Cp / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int cq = (int)(i % (Cp / 4));
         const int64_t p = i / (Cp / 4);
-        const int64_t b = p / hw, s = p % hw;
+        const int64_t b = p / hwo;
+        int64_t s = p % hwo;
+        if (pad) {
+            int y = (int)(s / Wo) - pad, x = (int)(s % Wo) - pad;
+            y = y < 0 ? -y : (y >= H ? 2 * H - 2 - y : y);
+            x = x < 0 ? -x : (x >= W ? 2 * W - 2 - x : x);
+            s = (int64_t)y * W + x;
+        }
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -241,7 +250,8 @@ rows_sum_kernel(const float* __restrict__ partial, float* __restrict__ out, int 
 // never straddles two crops (grid = B x blocks_per_crop).
 __global__ void __launch_bounds__(256)
 l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, const float* __restrict__ scale,
-                float* __restrict__ grad_nhwc, float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop) {
+                float* __restrict__ grad_nhwc, float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop,
+                int clamp_target) {
     const int b = blockIdx.x / blocks_per_crop, blk = blockIdx.x % blocks_per_crop;
     const float sc = scale ? scale[b] : 1.f;            // `ori`: pred * ratio before the loss (trainer_SID.py:97-98)
     const float gsc = inv_n * sc;
@@ -252,7 +262,8 @@ l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, co
         for (int k = 0; k < 8; ++k) g[k] = 0.f;
         for (int c = 0; c < C; ++c) {
             const int64_t i = ((int64_t)b * C + c) * hw + s;
-            const float p = pred[i] * sc, t = hr[i];
+            const float p = pred[i] * sc, t0 = hr[i];
+            const float t = clamp_target ? fminf(fmaxf(t0, 0.f), 1.f) : t0;      // preprocess: imgs_hr.clamp(0, 1) when dst.clip (trainer_SID.py:485)
             const float pc = fminf(fmaxf(p, 0.f), 1.f);
             const float d = pc - t;
             l1 += fabsf(d);
@@ -326,11 +337,16 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 
 extern "C" {
 
-int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
-    if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3)) return PNNP_E_INVALID;
+int pnnp_nchw_to_nhwc_reflect_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, void* stream) {
+    if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3) || pad < 0 || pad >= H || pad >= W) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * H * W * (Cp / 4))), dim3(256), 0, as_stream(stream), src, dst, B, C, H, W, Cp);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * (H + 2 * pad) * (W + 2 * pad) * (Cp / 4))), dim3(256), 0, as_stream(stream),
+                       src, dst, B, C, H, W, Cp, pad);
     return pnnp_launch_status();
+}
+
+int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
+    return pnnp_nchw_to_nhwc_reflect_f32(src, dst, B, C, H, W, Cp, 0, stream);
 }
 
 int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual, float* dst, int B, int C, int H, int W, int Cp, void* stream) {
@@ -386,13 +402,25 @@ int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int ac
 // loss_out[0] = mean |clamp(pred,0,1) - hr| (trainer_SID.py:99); loss_out[1+b] = sum_b (clamp(pred)-clamp(hr))^2
 // (PSNR_b = -10 log10(SSE_b / (C*H*W)), losses/__init__.py:4-15).  grad_nhwc (optional): dL/dpred laid out
 // [B][H][W][Cp] for the backward pass.  workspace >= 2 * B * 64 floats.
+int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
+                              int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream);
+
 int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
                                   int B, int C, int H, int W, int Cp, float* workspace, void* stream) {
+    return pnnp_l1_clamp_loss_tc_f32(pred, hr, scale, grad_nhwc, loss_out, B, C, H, W, Cp, workspace, 0, stream);
+}
+
+// the same with the target clamped to [0,1] inside the kernel (the trainer's `imgs_hr.clamp(0, 1)` of preprocess, trainer_SID.py:485,
+// without a separate elementwise pass over the clean crops)
+// the same with the target clamped to [0,1] inside the kernel (the trainer's `imgs_hr.clamp(0, 1)` of preprocess, trainer_SID.py:485,
+// without a separate elementwise pass over the clean crops)
+int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
+                              int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream) {
     if (!pred || !hr || !loss_out || !workspace || B <= 0 || C <= 0 || C > 8 || (grad_nhwc && (Cp < C || (Cp != 4 && Cp != 8)))) return PNNP_E_INVALID;
     const int bpc = 64;
     const float inv_n = 1.0f / ((float)B * C * H * W);
     hipLaunchKernelGGL(l1_clamp_kernel, dim3(B * bpc), dim3(256), 0, as_stream(stream), pred, hr, scale, grad_nhwc, workspace, C,
-                       (int64_t)H * W, Cp, inv_n, bpc);
+                       (int64_t)H * W, Cp, inv_n, bpc, clamp_target);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, loss_out, B, bpc, inv_n);
     return pnnp_launch_status();
 }

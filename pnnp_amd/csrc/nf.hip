@@ -19,6 +19,21 @@ struct NfStep {              // 317 floats, passed by value as a kernel argument
     float winv[4][4];                         // the Conv2d1x1 inverse that follows (x gain where it applies)
 };
 
+// Optional fusion of the trainer's preprocess around NoiseFlow.sample (trainer_SID.py:463-472,481-485; trainer_LRID.py:419-427):
+//   clean = imgs_hr / ratio                      -> clean_div: the kernel divides the clean crop it reads for the signal-dependent scale
+//   imgs_lr = imgs_hr + sample(...) * ratio       -> mix_base = imgs_hr, mix_mul / mix_mul_s = ratio (per crop / one scalar)
+//   imgs_lr.clamp(lb, 1)                         -> lo, hi
+//   assert scale >= 0 (signal_dependant.py:50)   -> flag: bit 0 set on the device when a * clean + b < 0 anywhere (read it later)
+struct NfMix {
+    const float* clean_div;   // [B] or null
+    float clean_div_s;        // used when clean_div is null (1 = none)
+    const float* mix_base;    // [B][4][H][W] or null: y = clamp(mix_base + (sample * mix_mul), lo, hi)
+    const float* mix_mul;     // [B] or null
+    float mix_mul_s;
+    float lo, hi;
+    int* flag;                // or null
+};
+
 namespace {
 
 constexpr int TS = 32;                        // output tile
@@ -37,6 +52,14 @@ __device__ __forceinline__ uint4 philox_nf(uint32_t c0, uint32_t c1, uint32_t c2
 
 __device__ __forceinline__ float u01_nf(uint32_t x) { return ((float)(x >> 9) + 0.5f) * 1.1920928955078125e-07f; }
 
+// base + r * m with TWO roundings, like the tensor ops `noise * ratio` and `imgs_lr += noise` (HIP's __fmul_rn / __fadd_rn are plain
+// operators: without the pragma the compiler contracts them into one fma)
+__device__ __forceinline__ float mul_then_add(float base, float r, float m) {
+#pragma clang fp contract(off)
+    const float t = r * m;
+    return base + t;
+}
+
 // z ~ N(0,1): 4 values per Philox block (two Box-Muller pairs, both outputs used)
 __global__ void __launch_bounds__(256)
 normal_fill_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1, uint32_t off) {
@@ -53,7 +76,7 @@ normal_fill_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
 
 __global__ void __launch_bounds__(256)
 nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, const NfStep p,
-               const float* __restrict__ clean, float sdn_a, float sdn_b, float out_mul) {
+               const float* __restrict__ clean, float sdn_a, float sdn_b, float out_mul, const NfMix mx) {
     __shared__ float z0s[2][ZW][ZW + 1];
     __shared__ float hs[4][HW_][HW_ + 1];
     const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
@@ -120,17 +143,29 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                             (z1a - o3[0]) * expf(-(p.scale * tanhf(o3[2]))),
                             (z1b - o3[1]) * expf(-(p.scale * tanhf(o3[3])))};
         float post = out_mul;
+        const float cdiv = mx.clean_div ? mx.clean_div[b] : mx.clean_div_s;
+        const float mmul = mx.mix_mul ? mx.mix_mul[b] : mx.mix_mul_s;
+        bool neg = false;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 4; ++c) s += p.winv[o][c] * v[c];
             if (clean) {
-                const float cl = clean[((int64_t)b * 4 + o) * plane + pix];
-                post = out_mul * sqrtf(sdn_a * cl + sdn_b);
+                float cl = clean[((int64_t)b * 4 + o) * plane + pix];
+                if (cdiv != 1.f) cl = __fdiv_rn(cl, cdiv);               // imgs_hr / ratio, rounded like the tensor op
+                const float sc2 = sdn_a * cl + sdn_b;
+                neg = neg || sc2 < 0.f;
+                post = out_mul * sqrtf(sc2);
             }
-            y[((int64_t)b * 4 + o) * plane + pix] = s * post;
+            float r = s * post;
+            if (mx.mix_base) {                                           // imgs_hr + noise * ratio, two roundings like the tensor ops, then the clamp
+                r = mul_then_add(mx.mix_base[((int64_t)b * 4 + o) * plane + pix], r, mmul);
+                if (r == r) r = fminf(fmaxf(r, mx.lo), mx.hi);              // (a NaN stays a NaN, as in Tensor.clamp)
+            }
+            y[((int64_t)b * 4 + o) * plane + pix] = r;
         }
+        if (neg && mx.flag) atomicOr(mx.flag, 1);
     }
 }
 
@@ -258,16 +293,24 @@ int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 // One [AffineCoupling^-1, Conv2d1x1^-1] pair of the reversed chain on x [B][4][H][W] -> y.
 // step [host]: 317 floats laid out as struct NfStep.  clean (optional, [B][4][H][W]): multiply the
 // result by sqrt(sdn_a*clean + sdn_b) (SignalDependantISO^-1, last pair); out_mul: scalar factor.
-int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
-                     const float* clean, float sdn_a, float sdn_b, float out_mul, void* stream) {
-    if (!x || !y || !step || B < 0 || H <= 0 || W <= 0 || x == y) return PNNP_E_INVALID;
+int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
+                         const float* clean, float sdn_a, float sdn_b, float out_mul,
+                         const float* clean_div, float clean_div_s, const float* mix_base, const float* mix_mul, float mix_mul_s,
+                         float clamp_lo, float clamp_hi, int* flag, void* stream) {
+    if (!x || !y || !step || B < 0 || H <= 0 || W <= 0 || x == y || y == mix_base) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     NfStep p;
     static_assert(sizeof(NfStep) == 317 * sizeof(float), "NfStep layout");
     memcpy(&p, step, sizeof p);
+    NfMix mx{clean_div, clean_div_s, mix_base, mix_mul, mix_mul_s, clamp_lo, clamp_hi, flag};
     hipLaunchKernelGGL(nf_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
-                       x, y, H, W, p, clean, sdn_a, sdn_b, out_mul);
+                       x, y, H, W, p, clean, sdn_a, sdn_b, out_mul, mx);
     return pnnp_launch_status();
+}
+
+int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
+                     const float* clean, float sdn_a, float sdn_b, float out_mul, void* stream) {
+    return pnnp_nf_step_mix_f32(x, y, B, H, W, step, clean, sdn_a, sdn_b, out_mul, nullptr, 1.f, nullptr, nullptr, 1.f, 0.f, 0.f, nullptr, stream);
 }
 
 // One [Conv2d1x1, AffineCoupling] pair of the FORWARD (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130).

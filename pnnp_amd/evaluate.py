@@ -31,8 +31,12 @@ def evaluate(net, imgs_lr, imgs_hr, ratio=None, ori=False, brightness_correct=Tr
         raise PnnpError('evaluate expects one frame per call: [1,C,H,W] (DataLoader batch_size 1, trainer_SID.py:52)')
     with torch.no_grad():
         if imgs_lr.shape[-1] % 16 != 0:                       # :221 -- the reference tests the width only
-            padded = F.pad(imgs_lr, (4, 4, 4, 4), mode='reflect')
-            dn = net(padded)[..., 4:-4, 4:-4]
+            eng = getattr(net, 'engine', None)
+            if eng is not None and hasattr(eng, 'forward') and not getattr(net, 'res', False):
+                # the reflection is folded into the layout pass the input goes through anyway (no F.pad kernel, no padded copy)
+                dn = eng.forward(imgs_lr, False, reflect_pad=4)[..., 4:-4, 4:-4]
+            else:
+                dn = net(F.pad(imgs_lr, (4, 4, 4, 4), mode='reflect'))[..., 4:-4, 4:-4]
         else:
             dn = net(imgs_lr)
         lr = imgs_lr

@@ -495,10 +495,11 @@ def maxpool_bwd(x, gy, gx, act_mode, accumulate, codes=None):
         check(_prep().pnnp_maxpool2_bwd_f32(ptr(x), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd')
 
 
-def nchw_to_nhwc(src, dst, cp):
+def nchw_to_nhwc(src, dst, cp, reflect_pad=0):
+    """NCHW -> zero-padded-channel NHWC; ``reflect_pad`` > 0: dst is the frame reflect-padded by that many pixels on every side."""
     require_cuda(src, dst)
     B, Cc, H, W = src.shape
-    check(_prep().pnnp_nchw_to_nhwc_f32(ptr(src), ptr(dst), B, Cc, H, W, cp, stream()), 'nchw_to_nhwc')
+    check(_prep().pnnp_nchw_to_nhwc_reflect_f32(ptr(src), ptr(dst), B, Cc, H, W, cp, int(reflect_pad), stream()), 'nchw_to_nhwc')
     return dst
 
 
@@ -515,13 +516,14 @@ def channel_sum(x, out, ws, accumulate=0):
     check(_prep().pnnp_channel_sum_f32(ptr(x), ptr(out), _i64(x.numel() // Cc), Cc, accumulate, ptr(ws), stream()), 'channel_sum')
 
 
-def l1_clamp_loss(pred, hr, grad_nhwc, loss_out, ws, scale=None):
-    """``scale`` [B] (or None): the `ori` branch of the train loop, pred * ratio before the loss (trainer_SID.py:97-99)."""
+def l1_clamp_loss(pred, hr, grad_nhwc, loss_out, ws, scale=None, clamp_target=False):
+    """``scale`` [B] (or None): the `ori` branch of the train loop, pred * ratio before the loss (trainer_SID.py:97-99).
+    ``clamp_target``: clamp ``hr`` to [0,1] inside the kernel (preprocess's imgs_hr.clamp(0,1) under dst.clip, trainer_SID.py:485)."""
     require_cuda(pred, hr, loss_out, ws, scale)
     B, Cc, H, W = pred.shape
     cp = grad_nhwc.shape[3] if grad_nhwc is not None else 0
-    check(_prep().pnnp_l1_clamp_loss_scaled_f32(ptr(pred), ptr(hr), ptr(scale), ptr(grad_nhwc), ptr(loss_out), B, Cc, H, W, cp, ptr(ws),
-                                                stream()), 'l1_clamp_loss')
+    check(_prep().pnnp_l1_clamp_loss_tc_f32(ptr(pred), ptr(hr), ptr(scale), ptr(grad_nhwc), ptr(loss_out), B, Cc, H, W, cp, ptr(ws),
+                                            int(bool(clamp_target)), stream()), 'l1_clamp_loss')
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

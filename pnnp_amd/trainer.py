@@ -146,6 +146,7 @@ class HipTrainStep:
         ``lo``, and the local gradient (a mean over the rank's crops) is weighted by B_local / global_batch so that the
         all-reduced sum is the mean over the global batch."""
         self.global_batch = global_batch
+        self.proxy_check_every = 50          # steps between reads of the NoiseFlow proxy's `scale >= 0` flag (a host sync each)
         self.net = net
         self.engine = net.engine
         self.lr = lr
@@ -241,15 +242,29 @@ class HipTrainStep:
         B = hr.shape[0]
         if ratio is None:
             if ratio_choices is not None:
-                ratio = torch.full((B, 1, 1, 1), float(ratio_choices[np.random.randint(len(ratio_choices))]), device=hr.device)
+                ratio = float(ratio_choices[np.random.randint(len(ratio_choices))])      # one host scalar per batch: no device op at all
             else:
                 ratio = torch.rand(B, dtype=torch.float32, device=hr.device).view(-1, 1, 1, 1) * 200 + 100
         if iso is None:
             iso = self.LEGAL_ISO[np.random.randint(len(self.LEGAL_ISO))]
-        noise = proxy_net.sample(clean=hr / ratio, iso=iso)
-        noisy = torch.addcmul(hr, noise, ratio)
-        if self.clip:
-            noisy = noisy.clamp_(max=1.0) if self.clip == process.HALF_CLIP else noisy.clamp_(0.0, 1.0)
+        if hasattr(proxy_net, 'sample_mixed'):
+            # one pass: clean = hr / ratio inside the signal-dependent step, hr + noise * ratio and the clamp in the last step's store,
+            # the reference's `assert scale >= 0` as a device flag that is read every `proxy_check_every` steps (check_proxy_flag)
+            lo, hi = (-float('inf'), float('inf'))
+            if self.clip:
+                lo, hi = (-float('inf') if self.clip == process.HALF_CLIP else 0.0), 1.0
+            noisy = proxy_net.sample_mixed(hr, ratio, iso, lo, hi)
+            self._proxy_steps = getattr(self, '_proxy_steps', 0) + 1
+            if self._proxy_steps % self.proxy_check_every == 0:
+                proxy_net.check_scale_flag()
+        else:
+            rt = ratio if torch.is_tensor(ratio) else torch.full((B, 1, 1, 1), ratio, device=hr.device)
+            noise = proxy_net.sample(clean=hr / rt, iso=iso)
+            noisy = torch.addcmul(hr, noise, rt)
+            if self.clip:
+                noisy = noisy.clamp_(max=1.0) if self.clip == process.HALF_CLIP else noisy.clamp_(0.0, 1.0)
+        if not torch.is_tensor(ratio):
+            ratio = torch.full((B, 1, 1, 1), ratio, device=hr.device) if self.ori else ratio
         return noisy, ratio, iso
 
     def step(self, hr, plist=None, rows=None, noisy=None, lr=None, ratio=None, iso=None):
@@ -275,13 +290,12 @@ class HipTrainStep:
             scale = ratio.reshape(-1).to(device=dev, dtype=torch.float32).contiguous()
             if scale.numel() == 1 and B > 1:
                 scale = scale.expand(B).contiguous()
-        target = hr.clamp(0, 1) if self.clip else hr        # trainer_SID.py:485 (plumbing)
         pred = e.forward(noisy, True)
         bufs = e.bufs[(B, H, W, dev)]
         g8 = bufs.get('g_out8', (B, H, W, e.cout_pad), dev)
         loss = bufs.get('loss_out', (1 + B,), dev)
         lws = bufs.get('loss_ws', (128 * B,), dev)
-        ops.l1_clamp_loss(pred, target, g8, loss, lws, scale=scale)
+        ops.l1_clamp_loss(pred, hr, g8, loss, lws, scale=scale, clamp_target=bool(self.clip))      # trainer_SID.py:485: the target is clamped under dst.clip, in the kernel
         weight = self.shard(B)[1]
         if weight != 1.0:                                    # uneven shards of a global batch: this rank's mean counts B_local / B_global
             g8.mul_(weight)

@@ -81,12 +81,46 @@ def test_config5_resunet_with_noiseflow_proxy_step(golden_dir):
     hr = torch.rand(3, 4, 64, 64, device='cuda') * 0.01
     noisy, ratio, iso = ts.make_noisy_proxy(hr, proxy, ratio_choices=(1, 2, 4, 8, 16))
     assert noisy.shape == hr.shape and torch.isfinite(noisy).all() and float(noisy.max()) <= 1.0
-    assert float(ratio.flatten()[0]) in (1, 2, 4, 8, 16) and iso in ts.LEGAL_ISO
+    assert float(torch.as_tensor(ratio).flatten()[0]) in (1, 2, 4, 8, 16) and iso in ts.LEGAL_ISO
     losses = []
     for _ in range(10):
         noisy, _, _ = ts.make_noisy_proxy(hr, proxy, ratio=ratio, iso=1600)
         losses.append(float(ts.step(hr, noisy=noisy)[0]))
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+
+
+def test_fused_preprocess_equals_the_tensor_ops_of_the_reference(golden_dir):
+    """NoiseFlow.sample_mixed = the proxy branch of preprocess (trainer_SID.py:463-472,481-485; trainer_LRID.py:419-427) in one chain
+    of kernels: with the prior draw injected it must equal, BIT FOR BIT, the reference's sequence of tensor ops
+
+        clean = hr / ratio;  noise = sample(clean=clean, iso=iso) * ratio;  lr = (hr + noise).clamp(lb, 1)
+
+    for a per-batch scalar ratio (LRID) and per-crop ratios (SID), half clip and full clip; and the deferred `scale >= 0` check
+    raises the reference's AssertionError when (and only when) a sample saw a negative scale."""
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    net = _net(g)
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    hr = torch.rand(3, 4, 48, 80, device='cuda', generator=gen) * 0.02
+    hr[0, :, :4] = 0.999                                                     # pixels that the upper clamp catches
+    z = torch.randn(hr.shape, device='cuda', generator=gen)
+    for ratio in (4.0, torch.tensor([100.0, 237.5, 300.0], device='cuda')):
+        rt = ratio.view(-1, 1, 1, 1) if torch.is_tensor(ratio) else ratio
+        for lo in (-float('inf'), 0.0):
+            # the elementwise ops of the reference on the CPU (IEEE division / multiply / add, one rounding each), sample() on the device
+            rc = rt.cpu() if torch.is_tensor(rt) else rt
+            clean = (hr.cpu() / rc).cuda()
+            ref = (hr.cpu() + net.sample(clean=clean, iso=1600.0, z=z).cpu() * rc).clamp(lo, 1.0).cuda()
+            got = net.sample_mixed(hr, ratio, 1600.0, lo, 1.0, z=z)
+            same = (got == ref) | (got.isnan() & ref.isnan())
+            assert bool(same.all()), (ratio, lo, int((~same).sum()), float((got - ref).abs().nan_to_num().max()), got[~same][:4].tolist(), ref[~same][:4].tolist())
+    net.check_scale_flag()                                                   # nothing negative so far: no error, no flag
+    bad = torch.full_like(hr, -1e4)                                          # a * clean + b < 0
+    net.sample_mixed(bad, 1.0, 1600.0, z=z)
+    with pytest.raises(AssertionError):
+        net.check_scale_flag()
+    net.check_scale_flag()                                                   # the flag was cleared by the raise
+    with pytest.raises(AssertionError):                                      # the plain API still asserts at once, like the reference
+        net.sample(clean=bad, iso=1600.0, z=z)
 
 
 def test_forward_and_loss_match_reference_golden(golden_dir):
