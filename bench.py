@@ -193,6 +193,8 @@ def main():
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--arch', default='unet', choices=['unet', 'resunet'], help='resunet + --noise noiseflow = BASELINE config 5')
     ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
+    ap.add_argument('--proxy-mode', default='train', choices=['train', 'eval'],
+                    help='NoiseFlow proxy BatchNorm mode while sampling: train = trainer_LRID (config 5), eval = trainer_SID')
     ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
                     help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -246,7 +248,10 @@ def main():
             for k, v in proxy.state_dict().items():
                 if k.endswith('conv2d_3.weight'):
                     v.normal_(0, 0.05)
-        proxy = proxy.to(dev).eval()
+        # trainer_LRID.py:34-39 never calls .eval() on the proxy it samples from: BASELINE config 5 (IMX686 LRID) samples with
+        # BatchNorm on BATCH statistics (training mode); --proxy-mode eval is the SID trainer's variant (trainer_SID.py:41-42)
+        proxy = proxy.to(dev)
+        proxy = proxy.train() if args.proxy_mode == 'train' else proxy.eval()
     net = net.to(dev)
     net.engine.set_policy(x3=args.family == 'x3', wino=args.family != 'direct')
     B, S = args.batch, args.size
@@ -332,7 +337,7 @@ def main():
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
             "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)" if pol.x3 else "f32", "data": "synthetic",
-            "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else "NoiseFlow.sample proxy (iso 6400, ratio in {1,2,4,8,16})") +
+            "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else f"NoiseFlow.sample proxy (iso 6400, ratio in {{1,2,4,8,16}}, BatchNorm in {args.proxy_mode} mode)") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
             "final_loss": loss_val,

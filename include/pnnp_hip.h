@@ -348,7 +348,14 @@ int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const fl
                          const float* clean /*or null*/, float sdn_a, float sdn_b, float out_mul,
                          const float* clean_div /*[B] or null*/, float clean_div_s, const float* mix_base /*or null*/,
                          const float* mix_mul /*[B] or null*/, float mix_mul_s, float clamp_lo, float clamp_hi, int* flag /*or null*/,
-                         void* stream);
+                         const float* bn_stats /*device [24] or null*/, void* stream);
+/* training-mode sampling (trainer_LRID.py:34-39,420-427: the proxy is never put in eval mode): with bn_stats = the batch statistics
+ * pnnp_nf_train_stats_f32 left on the device, the step's BatchNorm slots hold weight / bias and scale = gamma rstd, offset =
+ * beta - (mean + conv bias) scale are formed in the kernel; pnnp_nf_bn_update_f32 moves the running buffers of the coupling's two
+ * BatchNorm2d layers as nn.BatchNorm2d does (momentum 0.1, unbiased variance, num_batches_tracked += 1; n = B H W).  No host round trip. */
+int pnnp_nf_bn_update_f32(const float* bn_stats, const float* conv_bias1, const float* conv_bias2, float* running_mean1,
+                          float* running_var1, float* running_mean2, float* running_var2, long long* batches1 /*or null*/,
+                          long long* batches2 /*or null*/, double n, void* stream);
 /* One [Conv2d1x1, AffineCoupling] pair of the forward (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130);
  * partial [B][ceil(H/32)*ceil(W/32)] receives the per-workgroup sums of the pixel-wise log-det terms. */
 int pnnp_nf_fwd_step_f32(const float* x, float* y, float* partial, int B, int H, int W, const float* step /*[host]*/,

@@ -251,16 +251,23 @@ class NoiseFlow(nn.Module):
                 raise PnnpError(f'unsupported flow layer {type(m).__name__}')
         return plan
 
-    def _tables(self):
-        key = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
-        if self._steps is not None and key == self._steps_key:
-            return self._steps
+    def _tables(self, train=False):
+        """Host-side step tables.  ``train``: the BatchNorm slots hold weight / bias (the kernel forms scale / offset from the batch
+        statistics it finds on the device) and the cache does not depend on the running buffers -- which training-mode sampling moves
+        every step; eval: the running statistics are folded in here."""
+        key = tuple(p._version for p in self.parameters()) + (() if train else tuple(b._version for b in self.buffers()))
+        cache = self.__dict__.setdefault('_tcache', {})
+        hit = cache.get(bool(train))
+        if hit is not None and hit[0] == key:
+            return hit[1]
         steps = []
         for ac, cv, g_after, s_after in self._plan():
             s = ac._shift_and_log_scale
             f = lambda t: t.detach().cpu().float().numpy().reshape(-1)
             bn1, bn2 = s.net[1], s.net[4]
             def fold(bn):
+                if train:
+                    return f(bn.weight), f(bn.bias)
                 sc = bn.weight.detach().cpu() / torch.sqrt(bn.running_var.cpu() + BN_EPS)
                 return f(sc), f(bn.bias.detach().cpu() - bn.running_mean.cpu() * sc)
             s1, o1 = fold(bn1); s2, o2 = fold(bn2)
@@ -277,7 +284,7 @@ class NoiseFlow(nn.Module):
                 host['s_beta1'], host['s_beta2'], host['s_gain'] = (np.float32(s_after.beta1.item()), np.float32(s_after.beta2.item()),
                                                                    np.float32(s_after.gain.item()))
             steps.append((vec, cv.inverse_matrix().numpy().astype(np.float32), g_after, s_after, host))
-        self._steps, self._steps_key = steps, key
+        cache[bool(train)] = (key, steps)
         return steps
 
     # ------------------------------------------------------------------ API
@@ -438,34 +445,41 @@ class NoiseFlow(nn.Module):
         if train:
             tiles, pb = L.pnnp_nf_train_tiles(B, H, W), L.pnnp_nf_train_pblocks(B, H, W)
             f32 = dict(dtype=torch.float32, device=clean.device)
-            ident = torch.eye(4, **f32).reshape(-1).contiguous()
             h1 = torch.empty((B, 4, H, W), **f32); h2 = torch.empty_like(h1)
-            part = torch.empty(max(tiles, pb) * 8, **f32); bn = torch.empty(24, **f32)
+            part = torch.empty(max(tiles, pb) * 8, **f32)
+            bn_all = torch.empty((len(self._plan()), 24), **f32)          # one statistics record per coupling: nothing waits for the host
             n = float(B * H * W)
+            # the running buffers are moved through raw pointers below (no tensor version bump): the eval-mode tables are stale after this
+            self.__dict__.setdefault('_tcache', {}).pop(False, None)
+            pkey = (clean.device,) + tuple(p._version for p in self.parameters())
+            pc = self.__dict__.get('_prm_cache')
+            if pc is None or pc[0] != pkey:                             # the couplings' parameters as flat device rows, rebuilt only when they change
+                pc = (pkey, [torch.cat([t.detach().reshape(-1) for t in _coupling_params(ac)]).contiguous() for ac, _c, _g, _s in self._plan()],
+                      torch.eye(4, **f32).reshape(-1).contiguous())
+                self.__dict__['_prm_cache'] = pc
+            prm_rows, ident = pc[1], pc[2]
         _clean_div, _mix, _defer_check = kwargs.get('_clean_div'), kwargs.get('_mix'), bool(kwargs.get('_defer_check', False))
-        tables, plan = self._tables(), self._plan()
+        tables, plan = self._tables(train), self._plan()
         n_pairs = len(plan)
         for pair_index, ((vec, winv, g_after, s_after, host), (ac, _cv, _g, _s)) in enumerate(zip(tables, plan)):
             if train:
                 # batch statistics of this coupling's hidden maps for the tensor it is about to transform (its first two planes are
                 # the coupling network's input in both directions), folded into the BatchNorm scale / offset slots of the step table
                 sl = ac._shift_and_log_scale
-                prm = torch.cat([t.detach().reshape(-1) for t in _coupling_params(ac)]).contiguous()
+                prm = prm_rows[pair_index]
+                bn = bn_all[pair_index]
                 _lib.check(L.pnnp_nf_train_stats_f32(_lib.ptr(cur), _lib.ptr(ident), _lib.ptr(prm), _lib.ptr(bn), _lib.ptr(h1), _lib.ptr(h2),
                                                      _lib.ptr(part), B, H, W, _lib.stream()), 'nf_train_stats')
-                st = bn.cpu().numpy().astype(np.float64)                  # [mean1, rstd1, var1, mean2, rstd2, var2] x 4 (bias-free means)
-                vec = vec.copy()
-                for li, (bnm, conv, so, oo) in enumerate(((sl.net[1], sl.conv2d_1, 76, 80), (sl.net[4], sl.conv2d_2, 104, 108))):
-                    gam = bnm.weight.detach().cpu().numpy().astype(np.float64); bet = bnm.bias.detach().cpu().numpy().astype(np.float64)
-                    cb = conv.bias.detach().cpu().numpy().astype(np.float64)
-                    mean, rstd, var = st[12 * li:12 * li + 4], st[12 * li + 4:12 * li + 8], st[12 * li + 8:12 * li + 12]
-                    sc = gam * rstd
-                    vec[so:so + 4] = sc.astype(np.float32)
-                    vec[oo:oo + 4] = (bet - (mean + cb) * sc).astype(np.float32)     # the step kernel adds the conv bias: cancel it as the batch mean does
-                    with torch.no_grad():                                  # nn.BatchNorm2d buffers: momentum 0.1, unbiased variance
-                        bnm.running_mean.mul_(0.9).add_(torch.from_numpy((0.1 * (mean + cb)).astype(np.float32)).to(bnm.running_mean.device))
-                        bnm.running_var.mul_(0.9).add_(torch.from_numpy((0.1 * var * n / max(n - 1.0, 1.0)).astype(np.float32)).to(bnm.running_var.device))
-                        bnm.num_batches_tracked += 1
+                # the step kernel forms BatchNorm's scale / offset from `bn` itself (its table holds weight / bias in training mode) and
+                # the running buffers move on the device: nn.BatchNorm2d semantics (momentum 0.1, unbiased variance) without .cpu()
+                b1m, b2m = sl.net[1], sl.net[4]
+                _lib.check(L.pnnp_nf_bn_update_f32(_lib.ptr(bn), _lib.ptr(sl.conv2d_1.bias.detach()), _lib.ptr(sl.conv2d_2.bias.detach()),
+                                                   _lib.ptr(b1m.running_mean), _lib.ptr(b1m.running_var), _lib.ptr(b2m.running_mean),
+                                                   _lib.ptr(b2m.running_var), C.c_void_p(b1m.num_batches_tracked.data_ptr()),
+                                                   C.c_void_p(b2m.num_batches_tracked.data_ptr()), C.c_double(n), _lib.stream()), 'nf_bn_update')
+                bn_dev = bn
+            else:
+                bn_dev = None
             w = winv.copy()
             if g_after is not None:        # gain.py:79-86: x * exp(cam*gain_params) * iso  (scalar: folded into W^-1)
                 w *= np.float32(np.exp(_interp(host['g_cam'], iso) * host['g_gain']) * np.float32(iso))
@@ -488,7 +502,7 @@ class NoiseFlow(nn.Module):
                 if float(a) * float(clean.min()) + float(b) < 0:
                     raise AssertionError('scale must be non-negative')      # signal_dependant.py:50
             buf = vec.ctypes.data_as(C.POINTER(C.c_float))
-            if mix is None and cdiv_t is None and cdiv_s == 1.0 and flag is None:
+            if mix is None and cdiv_t is None and cdiv_s == 1.0 and flag is None and bn_dev is None:
                 _lib.check(L.pnnp_nf_step_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
                                               C.c_float(1.0), _lib.stream()), 'nf_step')
             else:
@@ -497,7 +511,7 @@ class NoiseFlow(nn.Module):
                 _lib.check(L.pnnp_nf_step_mix_f32(_lib.ptr(cur), _lib.ptr(nxt), B, H, W, buf, _lib.ptr(cl), C.c_float(a), C.c_float(b),
                                                   C.c_float(1.0), _lib.ptr(cdiv_t), C.c_float(cdiv_s), _lib.ptr(base), _lib.ptr(mul_t),
                                                   C.c_float(mul_s), C.c_float(lo), C.c_float(hi),
-                                                  C.c_void_p(flag.data_ptr()) if flag is not None else None, _lib.stream()), 'nf_step_mix')
+                                                  C.c_void_p(flag.data_ptr()) if flag is not None else None, _lib.ptr(bn_dev), _lib.stream()), 'nf_step_mix')
             cur, nxt = nxt, cur
         return cur
 

@@ -342,12 +342,16 @@ igemm_x3_kernel(const IgemmArgs a) {
                 if constexpr (sp == 2) a_read(tp + 1, mb, 0);
             }
             if constexpr (FILL) {
-                constexpr int STRIDE = 3 * GT / (NSLICE * 6);       // gaps per staging unit: 1 (BN = 32) or 2 (BN = 64)
-                static_assert(3 * GT == STRIDE * NSLICE * 6, "staging units per filter row");
-                if constexpr (g % STRIDE == STRIDE - 1) stage_piece((g / STRIDE) / 6, 0, (g / STRIDE) % 6, img ^ 1);
+                // the U = 6 NSLICE staging units of the row dealt evenly over its 3 GT gaps (8 waves: every gap at BN = 32, every other
+                // gap at BN = 64): unit n sits in gap ceil((n + 1) 3 GT / U) - 1
+                constexpr int U = NSLICE * 6, GR = 3 * GT;
+                static_assert(U <= GR, "at most one staging unit per gap");
+                constexpr int n0 = (g * U + GR - 1) / GR, n1 = ((g + 1) * U + GR - 1) / GR;
+                if constexpr (n1 > n0 && n0 < U) stage_piece(n0 / 6, 0, n0 % 6, img ^ 1);
             }
-            // requests: gaps w = 4, 6, 8, 10 of pass RP (no operand reads there; at BN = 64 no staging unit either)
+            // requests: the even gaps w >= 4 of pass RP (no operand reads there; at BN = 64 no staging unit either)
             constexpr int RP = NB > 2 ? 1 : 0;
+            static_assert(4 + 2 * ((Cfg::DPW > NHP ? Cfg::DPW : NHP) - 1) < MB * 3, "request slots of a pass");
             if constexpr (j == RP && w >= 4 && (w & 1) == 0) {
                 constexpr int rp = (w - 4) / 2;
                 if constexpr (tp == 0 && rp < Cfg::DPW) requests(rp);

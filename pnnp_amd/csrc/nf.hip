@@ -32,6 +32,11 @@ struct NfMix {
     float mix_mul_s;
     float lo, hi;
     int* flag;                // or null
+    // training-mode BatchNorm (trainer_LRID.py:34-39 never calls .eval() on the proxy it samples from): device [24] = the batch
+    // statistics [mean1, rstd1, var1, mean2, rstd2, var2] x 4 of pnnp_nf_train_stats_f32 (bias-free means), or null.  With it the
+    // step's s1 / o1 / s2 / o2 slots hold the BatchNorm weight / bias and scale, offset are formed here:
+    //   scale = gamma * rstd,  offset = beta - (mean + conv bias) * scale        (no host round trip for the statistics)
+    const float* bn_stats;
 };
 
 namespace {
@@ -82,6 +87,17 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
     const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
     const int64_t plane = (int64_t)H * W;
     const float* xb = x + (int64_t)b * 4 * plane;
+    float s1l[4], o1l[4], s2l[4], o2l[4];          // BatchNorm as y = s x + o: folded on the host (eval) or from the batch statistics
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+        if (mx.bn_stats) {
+            const float sa = p.s1[o] * mx.bn_stats[4 + o], sb = p.s2[o] * mx.bn_stats[16 + o];
+            s1l[o] = sa; o1l[o] = p.o1[o] - (mx.bn_stats[o] + p.b1[o]) * sa;
+            s2l[o] = sb; o2l[o] = p.o2[o] - (mx.bn_stats[12 + o] + p.b2[o]) * sb;
+        } else {
+            s1l[o] = p.s1[o]; o1l[o] = p.o1[o]; s2l[o] = p.s2[o]; o2l[o] = p.o2[o];
+        }
+    }
     // z0 tile (channels 0,1) with halo 2; zero outside the image (conv2d_1 pads with zeros)
     for (int i = threadIdx.x; i < 2 * ZW * ZW; i += 256) {
         const int c = i / (ZW * ZW), r = (i / ZW) % ZW, q = i % ZW;
@@ -103,14 +119,14 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                 for (int c = 0; c < 2; ++c)
 #pragma unroll
                     for (int t = 0; t < 9; ++t) s += p.w1[o][c][t] * z0s[c][r + t / 3][q + t % 3];
-                h1[o] = fmaxf(p.s1[o] * s + p.o1[o], 0.f);
+                h1[o] = fmaxf(s1l[o] * s + o1l[o], 0.f);
             }
 #pragma unroll
             for (int o = 0; o < 4; ++o) {
                 float s = p.b2[o];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) s += p.w2[o][c] * h1[c];
-                h2[o] = fmaxf(p.s2[o] * s + p.o2[o], 0.f);
+                h2[o] = fmaxf(s2l[o] * s + o2l[o], 0.f);
             }
         }
 #pragma unroll
@@ -166,6 +182,24 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
             y[((int64_t)b * 4 + o) * plane + pix] = r;
         }
         if (neg && mx.flag) atomicOr(mx.flag, 1);
+    }
+}
+
+// nn.BatchNorm2d's buffer update for the two BatchNorm layers of a coupling whose batch statistics pnnp_nf_train_stats_f32 left on the
+// device (momentum 0.1, unbiased variance; the kernels' means are bias-free, BatchNorm sees conv output + bias)
+__global__ void nf_bn_update_kernel(const float* __restrict__ bn, const float* __restrict__ cb1, const float* __restrict__ cb2,
+                                    float* rm1, float* rv1, float* rm2, float* rv2, long long* nb1, long long* nb2, float unbias) {
+    const int t = threadIdx.x;
+    if (t < 4) {
+        rm1[t] = rm1[t] * 0.9f + 0.1f * (bn[t] + cb1[t]);
+        rv1[t] = rv1[t] * 0.9f + 0.1f * bn[8 + t] * unbias;
+    } else if (t < 8) {
+        const int o = t - 4;
+        rm2[o] = rm2[o] * 0.9f + 0.1f * (bn[12 + o] + cb2[o]);
+        rv2[o] = rv2[o] * 0.9f + 0.1f * bn[20 + o] * unbias;
+    } else if (t == 8) {
+        if (nb1) *nb1 += 1;
+        if (nb2) *nb2 += 1;
     }
 }
 
@@ -293,16 +327,25 @@ int pnnp_normal_fill_f32(float* out, int64_t n, uint64_t seed, uint64_t offset, 
 // One [AffineCoupling^-1, Conv2d1x1^-1] pair of the reversed chain on x [B][4][H][W] -> y.
 // step [host]: 317 floats laid out as struct NfStep.  clean (optional, [B][4][H][W]): multiply the
 // result by sqrt(sdn_a*clean + sdn_b) (SignalDependantISO^-1, last pair); out_mul: scalar factor.
+int pnnp_nf_bn_update_f32(const float* bn_stats, const float* conv_bias1, const float* conv_bias2, float* running_mean1,
+                          float* running_var1, float* running_mean2, float* running_var2, long long* batches1, long long* batches2,
+                          double n, void* stream) {
+    if (!bn_stats || !conv_bias1 || !conv_bias2 || !running_mean1 || !running_var1 || !running_mean2 || !running_var2 || n < 1) return PNNP_E_INVALID;
+    hipLaunchKernelGGL(nf_bn_update_kernel, dim3(1), dim3(64), 0, as_stream(stream), bn_stats, conv_bias1, conv_bias2, running_mean1, running_var1,
+                       running_mean2, running_var2, batches1, batches2, (float)(n / (n > 1 ? n - 1 : 1)));
+    return pnnp_launch_status();
+}
+
 int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                          const float* clean, float sdn_a, float sdn_b, float out_mul,
                          const float* clean_div, float clean_div_s, const float* mix_base, const float* mix_mul, float mix_mul_s,
-                         float clamp_lo, float clamp_hi, int* flag, void* stream) {
+                         float clamp_lo, float clamp_hi, int* flag, const float* bn_stats, void* stream) {
     if (!x || !y || !step || B < 0 || H <= 0 || W <= 0 || x == y || y == mix_base) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     NfStep p;
     static_assert(sizeof(NfStep) == 317 * sizeof(float), "NfStep layout");
     memcpy(&p, step, sizeof p);
-    NfMix mx{clean_div, clean_div_s, mix_base, mix_mul, mix_mul_s, clamp_lo, clamp_hi, flag};
+    NfMix mx{clean_div, clean_div_s, mix_base, mix_mul, mix_mul_s, clamp_lo, clamp_hi, flag, bn_stats};
     hipLaunchKernelGGL(nf_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
                        x, y, H, W, p, clean, sdn_a, sdn_b, out_mul, mx);
     return pnnp_launch_status();
@@ -310,7 +353,7 @@ int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const fl
 
 int pnnp_nf_step_f32(const float* x, float* y, int B, int H, int W, const float* step /*[host]*/,
                      const float* clean, float sdn_a, float sdn_b, float out_mul, void* stream) {
-    return pnnp_nf_step_mix_f32(x, y, B, H, W, step, clean, sdn_a, sdn_b, out_mul, nullptr, 1.f, nullptr, nullptr, 1.f, 0.f, 0.f, nullptr, stream);
+    return pnnp_nf_step_mix_f32(x, y, B, H, W, step, clean, sdn_a, sdn_b, out_mul, nullptr, 1.f, nullptr, nullptr, 1.f, 0.f, 0.f, nullptr, nullptr, stream);
 }
 
 // One [Conv2d1x1, AffineCoupling] pair of the FORWARD (density) chain, NoiseFlow.forward (archs/noise_flow.py:113-130).

@@ -426,28 +426,34 @@ wgrad_x3_kernel(const Wx3Args a) {
 #endif
 }
 
-// out[o(i)] (+)= sum_z (-1)^z slab[z][i] (odd splits accumulated -G * X: WX3_ALT_SIGN); i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t  (the parameter's own layout)
+// out[o(i)] (+)= sum_z (-1)^z slab[z][i] (odd splits accumulated -G * X: WX3_ALT_SIGN); i = (t * M + m) * N + n  ->  o = (m * N + n) * taps + t
+// (the parameter's own layout).  ONE launch reduces the weight slabs and, behind them (i >= n), the bias slabs [Z][nb] into bias_out.
 __global__ void __launch_bounds__(256)
-wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate, int64_t mn, int taps) {
+wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int Z, int accumulate, int64_t mn, int taps,
+                  const float* __restrict__ bias_slab, float* __restrict__ bias_out, int nb) {
     __shared__ float red[8][33];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float sg = (WX3_ALT_SIGN && (ty & 1)) ? -1.f : 1.f;      // a thread row sums splits ty, ty + 8, ...: one parity, one sign (odd splits hold -partial)
-    for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < n; i0 += (int64_t)gridDim.x * 32) {
+    const int64_t ntot = n + (bias_slab ? nb : 0);
+    for (int64_t i0 = (int64_t)blockIdx.x * 32; i0 < ntot; i0 += (int64_t)gridDim.x * 32) {
         const int64_t i = i0 + tx;
+        const bool isb = i >= n;                                    // (n is a multiple of 32: a 32-wide group never straddles the two parts)
+        const float* src = isb ? bias_slab + (i - n) : slab + i;
+        const int64_t zs = isb ? nb : n;
         float s0 = 0.f, s1 = 0.f;
-        if (i < n) {
+        if (i < ntot) {
             int zz = ty;
-            for (; zz + 8 < Z; zz += 16) { s0 += slab[(int64_t)zz * n + i]; s1 += slab[(int64_t)(zz + 8) * n + i]; }
-            for (; zz < Z; zz += 8) s0 += slab[(int64_t)zz * n + i];
+            for (; zz + 8 < Z; zz += 16) { s0 += src[(int64_t)zz * zs]; s1 += src[(int64_t)(zz + 8) * zs]; }
+            for (; zz < Z; zz += 8) s0 += src[(int64_t)zz * zs];
         }
         red[ty][tx] = sg * (s0 + s1);
         __syncthreads();
-        if (ty == 0 && i < n) {
+        if (ty == 0 && i < ntot) {
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += red[k][tx];
-            const int64_t o = taps == 1 ? i : (i % mn) * taps + i / mn;
-            out[o] = accumulate ? out[o] + s : s;
+            float* o = isb ? bias_out + (i - n) : out + (taps == 1 ? i : (i % mn) * taps + i / mn);
+            *o = accumulate ? *o + s : s;
         }
         __syncthreads();
     }
@@ -529,12 +535,9 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
         default: rc = launch_wx3<1, 1, 4>(a, st); break;
     }
     if (rc != PNNP_OK) return rc;
-    const int64_t n = (int64_t)Cout * N * 9;
-    hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((n + 31) / 32 > 4096 ? 4096 : (n + 31) / 32)), dim3(256), 0, st,
-                       a.slab, dW, n, a.Z, accumulate, (int64_t)Cout * N, 9);
-    if (dbias)
-        hipLaunchKernelGGL(wx3_reduce_kernel, dim3((Cout + 31) / 32), dim3(256), 0, st, a.bias_slab, dbias, (int64_t)Cout, a.Z,
-                           accumulate, (int64_t)Cout, 1);
+    const int64_t n = (int64_t)Cout * N * 9, ntot = n + (dbias ? Cout : 0);       // n % 32 == 0 (channels in multiples of 32)
+    hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((ntot + 31) / 32 > 4096 ? 4096 : (ntot + 31) / 32)), dim3(256), 0, st,
+                       a.slab, dW, n, a.Z, accumulate, (int64_t)Cout * N, 9, dbias ? a.bias_slab : nullptr, dbias, Cout);
     return pnnp_launch_status();
 }
 

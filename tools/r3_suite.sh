@@ -1,0 +1,42 @@
+#!/bin/bash
+# Round-3 GPU suite (run on the GPU box from the repo root):  bash tools/r3_suite.sh <tag> <commit>
+# tests, bench line, rocprofv3 kernel stats of the same command, PMC traffic passes, config-5 line + stats, fp32-MFMA family line,
+# HBM-bound kernel table, eval forward.
+TAG=${1:-a}; COMMIT=${2:-unknown}
+OUT=/root/repo/gpurun_out/r3s$TAG; mkdir -p $OUT
+cd /root/repo
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1
+if [ -z "$SKIP_TESTS" ]; then
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $OUT/pytest.log
+timeout 300 python -m pytest tests/test_gpu_x3.py tests/test_gpu_fullsize.py -q -m gpu -s -k "accurate or golden or cancellation or dynamic_range or below" 2>&1 | grep -i "relative L2\|worst HIP\|vs float64\|cancellation\|scale x\|below the" > $OUT/accuracy.log
+fi
+timeout 600 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --family wino --no-cpu-baseline > $OUT/bench_family_wino.json 2> /dev/null
+export TMPDIR=/tmp; cd /tmp; rm -rf /tmp/rp_*
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_b -o b --output-format csv -- python3 /root/repo/bench.py --steps 6 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_bench.err
+cp $(find /tmp/rp_b -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+# config 5 (ResUnet + NoiseFlow proxy, B=12)
+cd /root/repo
+timeout 600 python bench.py --arch resunet --noise noiseflow --batch 12 --steps 10 --warmup 3 --no-cpu-baseline > $OUT/bench_config5.json 2> $OUT/bench_config5.err
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/rp_c5 -o c --output-format csv -- python3 /root/repo/bench.py --arch resunet --noise noiseflow --batch 12 --steps 4 --warmup 2 --no-cpu-baseline > $OUT/bench_config5_under_rocprof.json 2> /dev/null
+cp $(find /tmp/rp_c5 -name "*kernel_stats.csv" | head -1) $OUT/bench_config5_kernel_stats.csv
+# HBM-bound kernels under rocprofv3, eval forward
+cd /root/repo
+timeout 900 bash tools/aux_prof.sh > $OUT/aux.log 2>&1
+cp gpurun_out/aux_kernels.json gpurun_out/aux_kernel_stats.csv $OUT/ 2>/dev/null
+timeout 300 python tools/eval_bench.py > $OUT/eval_bench.txt 2>&1
+timeout 200 python tools/x3_bias_probe.py > $OUT/x3_bias_probe_head.txt 2>&1
+timeout 200 tools/ubench/wino_x3_model > $OUT/wino_x3_model.txt 2>&1
+# steady-state API sequence of one config-5 step (memcpys / memsets / launches per step)
+cd /tmp; rm -rf /tmp/rp_api
+timeout 300 rocprofv3 --hip-trace --kernel-trace -d /tmp/rp_api -o a --output-format csv -- python3 /root/repo/bench.py --arch resunet --noise noiseflow --batch 12 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1
+python3 /root/repo/tools/api_sequence.py /tmp/rp_api/a_hip_api_trace.csv /tmp/rp_api/a_kernel_trace.csv > $OUT/config5_steady_state.txt 2>&1
+cd /root/repo
+# HBM traffic of the conv kernels (two --pmc passes)
+timeout 900 bash tools/pmc_traffic.sh $COMMIT > $OUT/pmc.log 2>&1
+cp gpurun_out/traffic.json gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv $OUT/ 2>/dev/null
+# matrix-pipe utilisation per layer (PMC)
+timeout 600 bash tools/pmc_layers.sh util 'SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY' --x3 --only fwd,dgrad,wgrad --reps 2 > /dev/null 2>&1
+cp gpurun_out/pmc_layers_util.csv $OUT/ 2>/dev/null
+ls -la $OUT
