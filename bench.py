@@ -203,6 +203,9 @@ def main():
                          'a leg that runs out stops early and says so')
     ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '
                     '(for rocprofv3 traces of the collective kernels on the side stream overlapping the backward pass)')
+    ap.add_argument('--overlap-allreduce', action='store_true',
+                    help='N > 1: launch the gradient all-reduce in buckets from inside the backward pass (default: one collective after it; '
+                         'the persistent convolution kernels need every CU, see pnnp_amd.trainer.BucketedAllReduce)')
     ap.add_argument('--no-kernel-events', action='store_true', help='skip per-launch HIP events (roofline becomes whole-step)')
     args = ap.parse_args()
 
@@ -265,7 +268,7 @@ def main():
             raise SystemExit(f'--strong: global batch {global_batch} is smaller than {world} ranks')
     ts = HipTrainStep(net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=1997,
                       rank=rank, world=world, force_reducer=(world == 1 and args.force_reducer),
-                      global_batch=global_batch if args.strong else None)
+                      global_batch=global_batch if args.strong else None, overlap_allreduce=args.overlap_allreduce)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     hr = torch.rand(B, 4, S, S, device=dev, generator=g)          # synthetic clean crops, resident in HBM
     hr_nf = hr * 0.01                                             # dark crops for the NoiseFlow proxy (clean/gain scale)
@@ -351,7 +354,7 @@ def main():
                                            "all": [round(float(v), 4) for v in per_rank[:, 0]]}
             out["allreduce_wait_ms_per_step"] = {"mean_min_over_ranks": float(per_rank[:, 1].min()), "mean_max_over_ranks": float(per_rank[:, 1].max()),
                                                  "worst_step_any_rank": float(per_rank[:, 2].max()),
-                                                 "bucket_bytes": ts.bucket_bytes, "grad_bytes": int(net.engine.params.grad.numel() * 4)}
+                                                 "overlap": bool(args.overlap_allreduce), "bucket_bytes": ts.bucket_bytes, "grad_bytes": int(net.engine.params.grad.numel() * 4)}
         step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
         classes = {}
         if prof:

@@ -38,15 +38,24 @@ class BucketedAllReduce:
 
     xGMI is point-to-point (7 links x ~153 GB/s per GPU): a ring moves 2(N-1)/N x bytes over
     one link per direction, ~0.35 ms for the 31 MB of UNet gradients -- a few 8 MB buckets keep
-    each collective bandwidth-bound rather than latency-bound while leaving >= 3 to pipeline."""
+    each collective bandwidth-bound rather than latency-bound while leaving >= 3 to pipeline.
 
-    def __init__(self, flat, bucket_bytes=8 << 20, group=None, force=False):
+    ``overlap`` (default False).  The convolution kernels are PERSISTENT: one workgroup per CU (150-160 KB of LDS, 2 x ~230
+    registers per SIMD lane: nothing else fits beside it) with an equal, static share of the tiles.  A collective kernel that is
+    resident on even a few CUs when such a grid is dispatched leaves that many workgroups waiting for a free CU, and they run their
+    whole share after the others have finished: the layer takes up to twice as long.  With the gradient traffic this small (31 MB:
+    ~0.4-0.5 ms of ring time against a ~23 ms step, i.e. 2 %) hiding it is worth less than that risk, so by default the all-reduce is
+    ONE collective over the whole flat buffer, issued when the backward pass has finished; ``overlap=True`` launches the buckets
+    from the backward pass as described above (bench.py --overlap-allreduce; measure before relying on it)."""
+
+    def __init__(self, flat, bucket_bytes=8 << 20, group=None, force=False, overlap=False):
         import torch.distributed as dist
         self.dist = dist
         self.flat = flat
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the collective path at world size 1
+        self.overlap = bool(overlap)
         n = flat.numel()
         per = max(1, bucket_bytes // 4)
         edges = list(range(n, 0, -per))[::-1]            # bucket starts, counted from the end
@@ -69,8 +78,8 @@ class BucketedAllReduce:
 
     def ready(self, offset):
         """Everything at flat[offset:] has its final gradient: launch every bucket that lies
-        entirely in that range."""
-        if not self.active:
+        entirely in that range.  (Without ``overlap`` nothing is launched here: finish() reduces the whole buffer at once.)"""
+        if not self.active or not self.overlap:
             return
         while self.pending >= 0 and self.buckets[self.pending][0] >= offset:
             s, e = self.buckets[self.pending]
@@ -91,9 +100,13 @@ class BucketedAllReduce:
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream())
-        self.ready(0)
-        for w in self.works:
-            w.wait()
+        if self.active and not self.overlap:
+            self.dist.all_reduce(self.flat, group=self.group)          # one collective, in order behind the backward pass
+            self.pending = -1
+        else:
+            self.ready(0)
+            for w in self.works:
+                w.wait()
         self.works = []
         if timed:
             e1.record(torch.cuda.current_stream())
@@ -134,7 +147,7 @@ class HipTrainStep:
 
     def __init__(self, net, lr=1e-4, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=process.HALF_CLIP,
                  seed=1997, rank=0, world=1, group=None, bucket_bytes=8 << 20, force_reducer=False, tukey=False,
-                 proxy_net=None, proxy_ratio_choices=None, proxy_iso=None, global_batch=None):
+                 proxy_net=None, proxy_ratio_choices=None, proxy_iso=None, global_batch=None, overlap_allreduce=False):
         """``proxy_net`` (a NoiseFlow, `arch_proxy` of the run files): noise comes from ``proxy_net.sample`` instead of the
         physics sampler -- the 'NF_Syn_Dataset' branch of preprocess (trainer_SID.py:463-472: ratio ~ U(100,300) per crop,
         one random legal ISO per batch) or, with ``proxy_ratio_choices`` (dst.ratio_list), the 'IMX686_NF_Syn_Dataset'
@@ -146,6 +159,7 @@ class HipTrainStep:
         ``lo``, and the local gradient (a mean over the rank's crops) is weighted by B_local / global_batch so that the
         all-reduced sum is the mean over the global batch."""
         self.global_batch = global_batch
+        self.overlap_allreduce = overlap_allreduce      # BucketedAllReduce(overlap=): buckets from inside the backward pass (see its docstring)
         self.proxy_check_every = 50          # steps between reads of the NoiseFlow proxy's `scale >= 0` flag (a host sync each)
         self.net = net
         self.engine = net.engine
@@ -193,7 +207,8 @@ class HipTrainStep:
             self.m = torch.zeros_like(flat)
             self.v = torch.zeros_like(flat)
         if (self.world > 1 or self.force_reducer) and (self.reducer is None or self.reducer.flat is not self.engine.params.grad):
-            self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group, force=self.force_reducer)
+            self.reducer = BucketedAllReduce(self.engine.params.grad, self.bucket_bytes, self.group, force=self.force_reducer,
+                                             overlap=self.overlap_allreduce)
         if not self._synced:
             self.sync_replicas()
 

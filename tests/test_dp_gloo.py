@@ -23,7 +23,7 @@ def _worker(rank, world, port, n, bucket_bytes, offsets, out):
         g = torch.Generator().manual_seed(100 + rank)
         flat = torch.randn(n, generator=g)
         mine = flat.clone()
-        red = BucketedAllReduce(flat, bucket_bytes=bucket_bytes)
+        red = BucketedAllReduce(flat, bucket_bytes=bucket_bytes, overlap=True)      # the bucketed, overlapping mode
         assert red.world == world
         # buckets tile [0, n) exactly, no overlap
         cover = np.zeros(n, np.int32)
@@ -50,6 +50,16 @@ def _worker(rank, world, port, n, bucket_bytes, offsets, out):
             assert red.pending == -1
             other = torch.randn(n, generator=torch.Generator().manual_seed(100 + (1 - rank)))
             assert torch.allclose(flat, mine + other, atol=1e-6)
+        # default mode: nothing is launched from ready(), finish() reduces the whole buffer in one collective -- same result
+        flat2 = mine.clone()
+        red2 = BucketedAllReduce(flat2, bucket_bytes=bucket_bytes)
+        assert not red2.overlap
+        red2.reset()
+        for off in offsets:
+            red2.ready(off)
+            assert torch.equal(flat2, mine) and not red2.works           # untouched until finish()
+        red2.finish()
+        assert torch.allclose(flat2, mine + other, atol=1e-6)
         if rank == 0:
             out.put(launched)
     finally:

@@ -40,10 +40,13 @@ def test_strong_scaling_two_ranks_b_local_2():
     assert out['final_loss'] == out['final_loss'] and out['final_loss'] < 1.0                  # finite
 
 
-def test_weak_scaling_two_ranks():
-    out = _run(['--batch', '2'])
+@pytest.mark.parametrize('overlap', [False, True])
+def test_weak_scaling_two_ranks(overlap):
+    """Both reducer modes of bench.py: one collective after the backward pass (default) and buckets launched from inside it."""
+    out = _run(['--batch', '2'] + (['--overlap-allreduce'] if overlap else []))
     assert out['scaling'] == 'weak' and out['config']['crops_per_gpu'] == 2 and out['config']['global_batch'] == 4
     assert out['replica_checksum_spread'] == 0.0
+    assert out['allreduce_wait_ms_per_step']['overlap'] == overlap
 
 
 def test_strong_scaling_uneven_global_batch_and_per_rank_record():

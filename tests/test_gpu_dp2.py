@@ -28,7 +28,7 @@ def _net(seed):
 def _steps(net, hr, rank, world, group, steps=3):
     from pnnp_amd.trainer import HipTrainStep
     ts = HipTrainStep(net, lr=1e-3, camera_type='SonyA7S2', noise_code='pr', ori=False, clip=2, seed=7,
-                      rank=rank, world=world, group=group, bucket_bytes=32 << 10)
+                      rank=rank, world=world, group=group, bucket_bytes=32 << 10, overlap_allreduce=True)     # buckets from inside backward
     B = hr.shape[0]
     losses = []
     for s in range(steps):
