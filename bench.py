@@ -34,8 +34,8 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md (~2.5 PF dense): v_mfma
 # dense peak, and what the kernel is.  `roofline.frac` = executed / peak (a hardware fraction, always <= 1).
 FAMILY = {
     'x3':     (6.0, PEAK_BF16_MFMA_TFLOPS, ('conv9_fwd_x3', 'conv9_dgrad_x3'),
-               "igemm_x3_kernel (conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: six v_mfma_f32_32x32x16_bf16 "
-               "passes per fp32 product block, fp32 accumulation)"),
+               "igemm_x3_kernel (conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: the six piece products of a block as "
+               "three v_mfma_f32_16x16x32_bf16 with two pieces concatenated along K, i.e. 6 executed bf16 FLOP per algorithmic FLOP, fp32 accumulation)"),
     'wino':   (16.0 / 36.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd_wino', 'conv9_dgrad_wino'),
                "wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 multiply-adds where the direct form has 36)"),
     'direct': (1.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd', 'conv9_dgrad'),
@@ -387,7 +387,7 @@ def main():
                                "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
                                "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
             if fam == 'x3':
-                # informational: what a bare loop of the same MFMA sustains on this chip (tools/ubench/mfma_shape.hip, 8 waves per CU, operands
+                # informational: what a bare loop of the 32x32x16 MFMA sustains on this chip (the 16x16x32 shape the kernel uses: ~1950; tools/ubench/mfma_shape.hip, 8 waves per CU, operands
                 # re-read from LDS): 1790 TFLOP/s on random operands (power-limited clock), 2250 on zero operands; `peak` stays the 2.4 GHz figure
                 out["roofline"]["sustained_bare_mfma_loop"] = {"random_operands": 1790.0, "zero_operands": 2250.0, "unit": "TFLOP/s",
                                                                "source": "tools/ubench/mfma_shape.hip (DESIGN 5)"}
