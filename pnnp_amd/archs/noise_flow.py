@@ -227,8 +227,6 @@ class NoiseFlow(nn.Module):
             elif lyr == 'giso':
                 layers.append(GainISO(name=f'giso_{i}'))
         self.model = nn.ModuleList(layers)
-        self._steps = None
-        self._steps_key = None
         self.seed, self.offset = 1997, 0
         self._sdn_pair, self._last_bn = None, None
 

@@ -29,9 +29,6 @@ print('events between the last two device synchronisations (the timed steps):')
 print('  ' + ', '.join(out))
 print('totals:', dict(c))
 # kernels that STARTED between those two synchronisations (same clock as the API trace)
-t0, t1 = None, None
-sync_rows = [r for r in rows if r['Function'] == 'hipDeviceSynchronize']
-launch_rows = [r for r in rows if r['Function'] in ('hipLaunchKernel', 'hipModuleLaunchKernel')]
 ia, ib = segs[-1]
 names_in_seq = [r for r in rows if r['Function'] in ('hipMemcpyWithStream', 'hipLaunchKernel', 'hipMemcpyAsync', 'hipMemsetAsync', 'hipDeviceSynchronize',
                                                      'hipStreamSynchronize', 'hipEventSynchronize', 'hipModuleLaunchKernel')]
