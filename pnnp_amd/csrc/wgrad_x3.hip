@@ -41,12 +41,12 @@ struct Wx3Args {
 
 constexpr int NTHR = 512, NWAVE = 8;
 
-// Alternating signs over the pixel splits.  Measured (tools/x3_bias_probe.py, profiles/r3/x3_bias_probe.txt): the bf16 matrix core
-// does not round its accumulation to nearest -- every v_mfma_f32_*_bf16 leaves an error of about -2^-25 of the magnitude of the 16-term
-// dot product it adds, ALWAYS towards minus infinity, whatever the signs.  Over K accumulated terms that is a coherent offset of
-// ~ -K 2^-27 |term|: nothing against a sum of K same-signed terms, but against a gradient whose terms cancel (sum ~ sqrt(K) |term|)
-// it is sqrt(K) 2^-27 relative -- 4e-6 at the top level's K = 16 x 512 x 512 pixels, 5x the fp32-MFMA kernel's error.
-// The offset does not depend on the data's sign, so it cancels between two partial sums accumulated with OPPOSITE signs: workgroups
+// Alternating signs over the pixel splits.  Measured (tools/x3_bias_probe.py, profiles/r3/x3_bias_probe.txt; tools/ubench/mfma_round.hip):
+// the bf16 matrix core does not round its accumulation to nearest -- an inexact D = A B + C is rounded toward MINUS INFINITY, whatever the
+// signs (16777219 -> 16777218, -16777219 -> -16777220).  Over a long accumulation that is a coherent downward drift: nothing against a sum
+// of K same-signed terms, but against a gradient whose terms cancel (sum ~ sqrt(K) |term|) it reached 4e-6 relative at the top level's
+// K = 16 x 512 x 512 pixels, 5x the fp32-MFMA kernel's error.
+// The drift does not depend on the data's sign, so it cancels between two partial sums accumulated with OPPOSITE signs: workgroups
 // with an odd pixel-split index z stage -G (one v_xor per value while splitting), their slabs hold -partial, and the reduce kernel
 // adds the slabs with alternating signs.  No extra MFMA; the result is the same sum with the drift removed (to its fluctuation).
 #ifndef WX3_ALT_SIGN

@@ -1,0 +1,68 @@
+// How does the bf16 matrix core round when it adds a dot product to an fp32 accumulator?  (the float64-yardstick test of
+// wgrad_x3 found a coherent negative drift.)  One wave, D = A B + C with A = ones (32 x 16), every B column = v / 16 (so every dot
+// product is exactly v) and C preset so that C + v is NOT representable in float32: the result tells the rounding mode.
+//   C = +2^24, v = +3 -> exact 16777219: nearest-even 16777220, toward zero / -inf 16777218, toward +inf 16777220
+//   C = -2^24, v = -3 -> exact -16777219: nearest-even -16777220, toward zero -16777218, toward -inf -16777220
+//   C = +2^24, v = +1 -> exact 16777217 (a tie): nearest-even 16777216, toward -inf / zero 16777216, toward +inf 16777218
+//   C = -2^24, v = -1 -> exact -16777217 (a tie): nearest-even -16777216, toward zero -16777216, toward -inf -16777218
+// and the same through v_mfma_f32_32x32x2_f32 (the fp32 MFMA) for comparison.
+//   hipcc --offload-arch=gfx950 -O3 -o mfma_round mfma_round.hip && ./mfma_round
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void k(float* out, float c0, float v) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)1.0f; b[i] = (__bf16)(v / 16.0f); }
+    f32x16 c; for (int i = 0; i < 16; ++i) c[i] = c0;
+    f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    bf16x8 b2; for (int i = 0; i < 8; ++i) b2[i] = (__bf16)(v / 32.0f);
+    f32x4 c4 = {c0, c0, c0, c0};
+    f32x4 d4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b2, c4, 0, 0, 0);
+    f32x16 cf; for (int i = 0; i < 16; ++i) cf[i] = c0;
+    f32x16 df = __builtin_amdgcn_mfma_f32_32x32x2f32(1.0f, v / 2.0f, cf, 0, 0, 0);
+    // sixteen unequal products that sum to v: does the order / alignment inside the dot product matter?
+    bf16x8 b3; for (int i = 0; i < 8; ++i) b3[i] = (__bf16)((i == 0 && threadIdx.x < 32) ? v - 15.0f * 0.0078125f : 0.0078125f);
+    f32x16 d3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3, c, 0, 0, 0);
+    if (threadIdx.x == 0) { out[0] = d[0]; out[1] = d4[0]; out[2] = df[0]; out[3] = d3[0]; }
+}
+
+// chains: acc += dot16 over n MFMAs on pseudo-random bf16 values in [1, 2) (full 8-bit significands), the host accumulates the same
+// values in double.  mode 0: all terms positive (the sum grows: every addition rounds at the sum's ulp); mode 1: the signs alternate
+// inside every dot product (cancelling terms: the sum stays around the size of one term, like a weight gradient's).
+__host__ __device__ inline unsigned hsh(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
+__host__ __device__ inline float val(int it, int k) { return 1.0f + (float)(hsh((unsigned)it * 16u + (unsigned)k) & 127u) * 0.0078125f; }
+__global__ void chain(float* out, int n, int mode) {
+    const int kb = 8 * (threadIdx.x >> 5);
+    f32x16 c; for (int i = 0; i < 16; ++i) c[i] = 0.f;
+    for (int it = 0; it < n; ++it) {
+        bf16x8 a, b;
+        for (int i = 0; i < 8; ++i) { a[i] = (__bf16)((mode == 1 && ((kb + i) & 1)) ? -1.0f : 1.0f); b[i] = (__bf16)val(it, kb + i); }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+    }
+    if (threadIdx.x == 0) out[0] = c[0];
+}
+
+int main() {
+    float* out; hipMalloc(&out, 16);
+    const float cases[6][2] = {{16777216.f, 3.f}, {-16777216.f, -3.f}, {16777216.f, 1.f}, {-16777216.f, -1.f}, {16777216.f, 5.f}, {-16777216.f, -5.f}};
+    printf("%14s %4s | %14s %14s %14s %14s | exact\n", "C", "v", "32x32x16 bf16", "16x16x32 bf16", "32x32x2 f32", "bf16 unequal");
+    for (auto& cs : cases) {
+        hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cs[0], cs[1]);
+        float h[4]; hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
+        printf("%14.1f %4.0f | %14.1f %14.1f %14.1f %14.1f | %.1f\n", cs[0], cs[1], h[0], h[1], h[2], h[3], (double)cs[0] + cs[1]);
+    }
+    for (int mode = 0; mode < 2; ++mode)
+        for (int n : {100, 1000, 10000, 100000}) {
+            hipLaunchKernelGGL(chain, dim3(1), dim3(64), 0, 0, out, n, mode);
+            float h; hipMemcpy(&h, out, 4, hipMemcpyDeviceToHost);
+            double exact = 0, absum = 0; float f32 = 0.f;
+            for (int it = 0; it < n; ++it)
+                for (int k2 = 0; k2 < 16; ++k2) { const double t = ((mode == 1 && (k2 & 1)) ? -1.0 : 1.0) * val(it, k2); exact += t; absum += t < 0 ? -t : t; f32 = fmaf((float)t, 1.0f, f32); }
+            printf("chain mode %d n %6d MFMAs: got %.6f exact %.6f (float32 fma chain: %.6f)  error / sum|terms| = %+.3e (fma chain %+.3e), error in ulp(result) = %+.1f\n",
+                   mode, n, h, exact, f32, (h - exact) / absum, (f32 - exact) / absum, (h - exact) / (exact != 0 ? (exact < 0 ? -exact : exact) * 5.96e-8 : 1));
+        }
+    return 0;
+}
