@@ -309,7 +309,12 @@ igemm_x3_kernel(const IgemmArgs a) {
     //   other gap at BN = 64); `requests`: the item's LDS-DMA / halo-load pieces in read-free gaps of pass 1 (BN = 64) or 0.
     auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests) {
         constexpr bool FILL = decltype(fill_tag)::value;
-        constexpr int NHP = decltype(halo_tag)::value ? NSLOT + 1 : 0;
+        // halo requests of the row: 0 none; 1 all NSLOT + 1 pieces in tap 1 (BN = 64, filter row 0: the registers are free);
+        // 2 LATE (BN = 32, filter row 2, whose gaps also carry the staging that empties those registers slot by slot): the scalar part and
+        // slot 0 in tap 1 (slot 0's four slices were staged in tap 0), slot 1 in tap 2, slot 2 by the caller behind the row
+        constexpr int HM = (int)decltype(halo_tag)::value;
+        constexpr int NHP = HM == 1 ? NSLOT + 1 : (HM == 2 ? 2 : 0);
+        static_assert(HM != 2 || (NSLOT == 3 && FILL), "late halo requests follow the staging of a three-slot tile");
         constexpr int GT = NB * MB * 3;                             // MFMAs (= gaps) per tap
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
@@ -358,6 +363,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 constexpr int rp = (w - 4) / 2;
                 if constexpr (tp == 0 && rp < Cfg::DPW) requests(rp);
                 if constexpr (tp == 1 && rp < NHP) requests(Cfg::DPW + rp);
+                if constexpr (HM == 2 && tp == 2 && rp == 0) requests(Cfg::DPW + 2);
             }
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -733,8 +739,16 @@ igemm_x3_kernel(const IgemmArgs a) {
             // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
             __builtin_amdgcn_s_waitcnt(0x0f70 | D);
             __syncthreads();
+#if X3_M16
+            // the halo of the chunk after next: its requests ride in this row's gaps as the staging frees the registers (LATE, see mfma_row);
+            // same issue order as a lump behind the row -- [weights of the next row 1][halo] -- so the vmcnt counts above hold
+            mfma_row(2, 2, img, std::true_type{}, std::integral_constant<int, 2>{}, [&](int rp) {
+                if (rp < D) dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); else if (rp == D) halo_prep(n2.tile, n2.g); else halo_slot(rp - D - 1); });
+            halo_slot(2);
+#else
             mfma_row(2, 2, img, std::true_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); });
             load_halo(n2.tile, n2.g);
+#endif
             if (g == nchunks - 1) epilogue(cur, epi_sep);
             if (!n1.ok) break;
             if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
