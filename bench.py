@@ -70,7 +70,7 @@ def physical_cores():
     return os.cpu_count() or 1
 
 
-def cpu_baseline(H, W, budget_s=75.0):
+def cpu_baseline(H, W, budget_s=240.0):
     """The reference's train step restated on torch-CPU fp32 (oracle/net_torch.py + oracle/noise_np.py), timed on this
     box's host cores by the protocol of BASELINE.md section 3: per crop `sample_params_max('SonyA7S2')` ->
     `generate_noisy_torch('pr', clip=2)` -> clamp -> UNetSeeInDark nf=32 forward -> L1(clamp) -> backward -> Adam(lr 1e-4),
@@ -84,7 +84,7 @@ def cpu_baseline(H, W, budget_s=75.0):
     the record says how many warm-up / timed steps it actually did (`protocol_complete` false), instead of silently shrinking
     the sample.  On the pool's 128-core hosts one all-cores step of 16 crops takes ~23 s (torch-CPU convolutions scale poorly
     past ~32 threads: round 2 measured 1.39 crops/s with 32 threads on 4 crops), so the complete protocol needs
-    --cpu-baseline-seconds 200; profiles/r3/cpu_baseline_full.json holds such a run."""
+    ~175 s; the default budget is 240 s (round 4: the driver's own line must say `protocol_complete: true`)."""
     import numpy as np
     import torch
     from oracle import net_torch as O, noise_np as N
@@ -198,7 +198,7 @@ def main():
     ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
                     help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-baseline-seconds', type=float, default=75.0,
+    ap.add_argument('--cpu-baseline-seconds', type=float, default=240.0,
                     help='time budget of the CPU baseline legs (BASELINE.md section 3 protocol: B=16, 2 warm-up + 5 timed steps, all physical cores + 1 thread); '
                          'a leg that runs out stops early and says so')
     ap.add_argument('--force-reducer', action='store_true', help='N=1 only: run the bucketed RCCL all-reduce path on a 1-rank group '
@@ -348,11 +348,13 @@ def main():
         if spread is not None:
             out["replica_checksum_spread"] = spread
         if per_rank is not None:
-            # is the gradient all-reduce hidden behind backward?  allreduce_wait = time the compute stream stood still in
-            # reducer.finish() (event pair on the compute stream), per step; ~0 when RCCL overlaps the remaining backward kernels
+            # What the event pair around reducer.finish() on the compute stream measures depends on the mode, so the field is named after it:
+            #   --overlap-allreduce: `allreduce_wait_ms_per_step` = how long the compute stream stood still for buckets that were still in
+            #     flight (~0 when RCCL hides behind the remaining backward kernels);
+            #   default (one collective behind the backward pass): `allreduce_ms_per_step` = the whole collective, all of it exposed.
             out["per_rank_ms_per_step"] = {"min": float(per_rank[:, 0].min()), "max": float(per_rank[:, 0].max()),
                                            "all": [round(float(v), 4) for v in per_rank[:, 0]]}
-            out["allreduce_wait_ms_per_step"] = {"mean_min_over_ranks": float(per_rank[:, 1].min()), "mean_max_over_ranks": float(per_rank[:, 1].max()),
+            out["allreduce_wait_ms_per_step" if args.overlap_allreduce else "allreduce_ms_per_step"] = {"mean_min_over_ranks": float(per_rank[:, 1].min()), "mean_max_over_ranks": float(per_rank[:, 1].max()),
                                                  "worst_step_any_rank": float(per_rank[:, 2].max()),
                                                  "overlap": bool(args.overlap_allreduce), "bucket_bytes": ts.bucket_bytes, "grad_bytes": int(net.engine.params.grad.numel() * 4)}
         step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)

@@ -84,7 +84,8 @@ template <int BN> struct X3Cfg {
     static constexpr int EPI = NWAVE * 16 * EPS * 4;               // per wave: (16 pixels x 32 channels) floats
     // BN = 64: the epilogue patches live in the weight stage the tile's last item has just consumed (a barrier in between)
     static constexpr bool EPI_ALIAS = WS_STAGE >= EPI;
-    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // 154368 / 161536
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // X3_M16 (padded planes): 156672 (BN = 64) / 163840 (BN = 32: ALL of the LDS)
+    static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS: 160 KB on gfx950 (BN = 32 uses every byte: any growth must come out of something else)");
 };
 
 template <int I, int N, class F>

@@ -41,14 +41,23 @@ struct Wx3Args {
 
 constexpr int NTHR = 512, NWAVE = 8;
 
-// Alternating signs over the pixel splits.  Measured (tools/x3_bias_probe.py, profiles/r3/x3_bias_probe.txt; tools/ubench/mfma_round.hip):
-// the bf16 matrix core does not round its accumulation to nearest -- an inexact D = A B + C is rounded toward MINUS INFINITY, whatever the
-// signs (16777219 -> 16777218, -16777219 -> -16777220).  Over a long accumulation that is a coherent downward drift: nothing against a sum
-// of K same-signed terms, but against a gradient whose terms cancel (sum ~ sqrt(K) |term|) it reached 4e-6 relative at the top level's
-// K = 16 x 512 x 512 pixels, 5x the fp32-MFMA kernel's error.
+// Alternating signs over the pixel splits.  What was measured (tools/ubench/mfma_round.hip -> profiles/r3/mfma_round.txt, one MFMA with
+// C = +-2^24, ulp 2; tools/x3_bias_probe.py -> profiles/r3/x3_bias_probe.txt), per instruction shape and operand case:
+//   * equal small products (v_mfma_f32_32x32x16_bf16: 16 x v/16; v_mfma_f32_16x16x32_bf16: 32 x v/32): every PRODUCT is first rounded
+//     to the nearest 1/8 ulp of the accumulator (0.25 here) -- 16 x 3/16 -> 16 x 0.25 = +4 (16777220), 32 x 3/32 -> 32 x 0 = +0
+//     (16777216: the addend is dropped entirely), 32 x 5/32 -> 32 x 0.25 = +8 (16777224).  Both shapes follow the same rule; the
+//     16 x 16 x 32 shape just has twice as many products per instruction to round.  Zero-mean for data of random size.
+//   * one large + small products ("unequal" columns): the inexact SUM is rounded toward MINUS INFINITY whatever the signs
+//     (16777219 -> 16777218, -16777219 -> -16777220, ties 16777217 -> 16777216, -16777217 -> -16777218); v_mfma_f32_32x32x2_f32 (an
+//     fmaf chain) rounds to nearest.
+// The second effect is a coherent downward drift over a long accumulation: nothing against a sum of K same-signed terms (4.4e-8), but
+// against a gradient whose terms cancel (sum ~ sqrt(K) |term|) it reached 4e-6 relative at the top level's K = 16 x 512 x 512 pixels,
+// 5x the fp32-MFMA kernel's error.
 // The drift does not depend on the data's sign, so it cancels between two partial sums accumulated with OPPOSITE signs: workgroups
 // with an odd pixel-split index z stage -G (one v_xor per value while splitting), their slabs hold -partial, and the reduce kernel
 // adds the slabs with alternating signs.  No extra MFMA; the result is the same sum with the drift removed (to its fluctuation).
+// (conv_x3's forward / backward-data reductions, K <= 9216, keep the drift: -1.4e-6 of the L2 norm at K = 4608, bounded by
+// tests/test_gpu_x3.py::test_x3_forward_signed_mean_error_is_bounded.)
 #ifndef WX3_ALT_SIGN
 #define WX3_ALT_SIGN 1
 #endif

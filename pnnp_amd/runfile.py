@@ -138,6 +138,8 @@ def main(argv=None):
             else:
                 out = step.step(hr, lr=lr)
             losses.append(float(out[0])); psnrs.append(step.psnr_from(out, sh['channels'] * S * S))
+        if isinstance(step, HipTrainStep):
+            step.check_proxy()                                      # signal_dependant.py:50, deferred: at every epoch end, before the log line / a save
         # base_trainer / trainer_SID log line format: epoch, lr, loss, psnr
         if isinstance(step, NoiseFlowFitStep):
             print(f"Epoch {epoch:04d} | lr {lr:.3e} | nll {np.mean(losses):.5f} | std {np.mean(psnrs):.4f}", flush=True)

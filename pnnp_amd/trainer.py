@@ -114,10 +114,12 @@ class BucketedAllReduce:
 
     def wait_ms(self):
         """Per finish() since the last call: milliseconds the compute stream spent between reaching finish() and having every
-        bucket reduced (synchronises).  Includes launching the buckets backward had not released yet."""
+        bucket reduced (waits for the recorded events only).  With ``overlap`` that is the WAIT for collectives still in flight (0 =
+        communication hidden; includes launching the buckets backward had not released yet); without it (the default) the pair
+        brackets the one collective itself, i.e. the whole, exposed all-reduce time."""
         if not self.wait_pairs:
             return []
-        torch.cuda.synchronize()
+        self.wait_pairs[-1][1].synchronize()
         out = [a.elapsed_time(b) for a, b in self.wait_pairs]
         self.wait_pairs = []
         return out
@@ -264,13 +266,15 @@ class HipTrainStep:
             iso = self.LEGAL_ISO[np.random.randint(len(self.LEGAL_ISO))]
         if hasattr(proxy_net, 'sample_mixed'):
             # one pass: clean = hr / ratio inside the signal-dependent step, hr + noise * ratio and the clamp in the last step's store,
-            # the reference's `assert scale >= 0` as a device flag that is read every `proxy_check_every` steps (check_proxy_flag)
+            # the reference's `assert scale >= 0` (signal_dependant.py:50) as a device flag: read on the FIRST proxy step (a bad
+            # checkpoint or ISO fails at once, before any Adam step on NaN noise), then every `proxy_check_every` steps, and by
+            # check_proxy() -- which the epoch loop calls at every epoch end and before anything is saved or returned
             lo, hi = (-float('inf'), float('inf'))
             if self.clip:
                 lo, hi = (-float('inf') if self.clip == process.HALF_CLIP else 0.0), 1.0
             noisy = proxy_net.sample_mixed(hr, ratio, iso, lo, hi)
             self._proxy_steps = getattr(self, '_proxy_steps', 0) + 1
-            if self._proxy_steps % self.proxy_check_every == 0:
+            if self._proxy_steps == 1 or self._proxy_steps % self.proxy_check_every == 0:
                 proxy_net.check_scale_flag()
         else:
             rt = ratio if torch.is_tensor(ratio) else torch.full((B, 1, 1, 1), ratio, device=hr.device)
@@ -325,6 +329,13 @@ class HipTrainStep:
         e.mark_dirty()
         self._loss = loss
         return loss
+
+    def check_proxy(self):
+        """Raise the reference's ``AssertionError('scale must be non-negative')`` (signal_dependant.py:50) if any proxy sample since the
+        last check saw a negative scale.  One host synchronisation: call it at every epoch end and before a checkpoint is written
+        (`runfile.main` does); `make_noisy_proxy` itself checks on the first step and every ``proxy_check_every`` steps."""
+        if self.proxy_net is not None and hasattr(self.proxy_net, 'check_scale_flag'):
+            self.proxy_net.check_scale_flag()
 
     @staticmethod
     def psnr_from(loss_out, elems_per_crop):

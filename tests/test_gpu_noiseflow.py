@@ -89,6 +89,29 @@ def test_config5_resunet_with_noiseflow_proxy_step(golden_dir):
     assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
 
 
+def test_train_step_raises_the_scale_assertion_on_its_first_proxy_step_and_at_epoch_end(golden_dir):
+    """signal_dependant.py:50 asserts `scale >= 0` inside every proxy sample.  The fused step defers it to a device flag: it must be
+    read on the FIRST proxy step (a run shorter than `proxy_check_every` steps still fails, before Adam has seen NaN noise twice) and
+    by `check_proxy()`, which the epoch loop of runfile.main calls at every epoch end."""
+    from pnnp_amd.archs import ResUnet, initialize_weights
+    from pnnp_amd.trainer import HipTrainStep
+    g = np.load(os.path.join(golden_dir, 'noiseflow.npz'))
+    proxy = _net(g)
+    net = ResUnet(dict(nframes=1, res=False, nf=8, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda()
+    bad = torch.full((2, 4, 32, 32), -1e4, device='cuda')                    # a * clean + b < 0
+    good = torch.rand(2, 4, 32, 32, device='cuda') * 0.01
+    ts = HipTrainStep(net, lr=1e-4, clip=2, proxy_net=proxy, proxy_ratio_choices=(1,), proxy_iso=1600)
+    with pytest.raises(AssertionError):
+        ts.step(bad)                                                         # step 1 reads the flag
+    ts.check_proxy()                                                         # cleared by the raise
+    for _ in range(3):
+        ts.step(good)
+    ts.step(bad)                                                             # step 5: not a check step -- the flag stays set on the device
+    with pytest.raises(AssertionError):
+        ts.check_proxy()                                                     # ... until the epoch end
+    ts.check_proxy()
+
+
 def test_fused_preprocess_equals_the_tensor_ops_of_the_reference(golden_dir):
     """NoiseFlow.sample_mixed = the proxy branch of preprocess (trainer_SID.py:463-472,481-485; trainer_LRID.py:419-427) in one chain
     of kernels: with the prior draw injected it must equal, BIT FOR BIT, the reference's sequence of tensor ops

@@ -384,3 +384,37 @@ def test_x3_below_the_supported_range_degrades_gracefully():
     e3 = float((nchw(y3).cpu().double() - ref).norm() / ref.norm())
     print(f'x at 1e-36 (below the supported 7.7e-34): rel L2 vs float64 {e3:.2e}')
     assert torch.isfinite(y3).all() and e3 < 2.0 ** -7
+
+
+@pytest.mark.parametrize('positive', [False, True])
+def test_x3_forward_signed_mean_error_is_bounded(positive):
+    """The bf16 matrix core rounds an inexact accumulation toward MINUS INFINITY (csrc/wgrad_x3.hip, WX3_ALT_SIGN) and
+    rounds each small product to 1/8 ulp of the accumulator first.  `wgrad_x3` cancels the resulting drift with alternating signs;
+    the forward / backward-data kernel (v_mfma_f32_16x16x32_bf16, two pieces concatenated along K) keeps it.  This bounds it: on a
+    LONG uniform-scale reduction (K = 9 x 512 = 4608, every term the same size -- the worst case for a per-accumulation rounding
+    bias) the mean SIGNED relative error against float64 stays within 4e-6 (measured -1.4e-6; the fp32-MFMA kernel's is sign-random
+    at +-4e-7) and the L2 error within 2x of the fp32-MFMA kernel's.  All-positive data: the sum grows with K, each rounding is
+    relative to the running sum, and the bias must stay below 5e-7."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 16, 32, 512, 64
+    g = torch.Generator().manual_seed(0)
+    x = torch.rand(B, Ci, H, W, generator=g) + 0.5
+    w = (torch.rand(Co, Ci, 3, 3, generator=g) + 0.5) * 0.05
+    if not positive:
+        x = x * (torch.randint(0, 2, x.shape, generator=g) * 2 - 1)
+        w = w * (torch.randint(0, 2, w.shape, generator=g) * 2 - 1)
+    ref = F.conv2d(x.double(), w.double(), None, padding=1)
+    f3, _ = _packs(w.cuda(), dgrad=False)
+    f32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), f32, None)
+    y3 = torch.empty((B, H, W, Co), device='cuda'); y32 = torch.empty_like(y3)
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f3, None, y3, Co, 0)
+    ops.conv_fwd(nhwc(x).cuda(), None, f32, None, y32, Co, 9, 0)
+
+    def stats(y):
+        d = nchw(y).cpu().double() - ref
+        # bias relative to the typical output size (a per-element ratio would be dominated by outputs that cancel to ~0)
+        return float(d.norm() / ref.norm()), float(d.mean() / ref.abs().mean())
+    (l3, b3), (l32, b32) = stats(y3), stats(y32)
+    print(f'K=4608 {"positive" if positive else "rnd-sign"}: bf16x3 L2 {l3:.2e} signed mean {b3:+.2e} | fp32-MFMA L2 {l32:.2e} signed mean {b32:+.2e}')
+    assert l3 < 2.0 * l32 + 1e-8
+    assert abs(b3) < (5e-7 if positive else 4e-6)

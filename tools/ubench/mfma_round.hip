@@ -26,7 +26,10 @@ __global__ void k(float* out, float c0, float v) {
     // sixteen unequal products that sum to v: does the order / alignment inside the dot product matter?
     bf16x8 b3; for (int i = 0; i < 8; ++i) b3[i] = (__bf16)((i == 0 && threadIdx.x < 32) ? v - 15.0f * 0.0078125f : 0.0078125f);
     f32x16 d3 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b3, c, 0, 0, 0);
-    if (threadIdx.x == 0) { out[0] = d[0]; out[1] = d4[0]; out[2] = df[0]; out[3] = d3[0]; }
+    // the same for the 16x16x32 shape (k-block = lane >> 4: lanes 0-15 hold k 0-7): one large product + 31 of 2^-7
+    bf16x8 b5; for (int i = 0; i < 8; ++i) b5[i] = (__bf16)((i == 0 && threadIdx.x < 16) ? v - 31.0f * 0.0078125f : 0.0078125f);
+    f32x4 d5 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b5, c4, 0, 0, 0);
+    if (threadIdx.x == 0) { out[0] = d[0]; out[1] = d4[0]; out[2] = df[0]; out[3] = d3[0]; out[4] = d5[0]; }
 }
 
 // chains: acc += dot16 over n MFMAs on pseudo-random bf16 values in [1, 2) (full 8-bit significands), the host accumulates the same
@@ -46,13 +49,13 @@ __global__ void chain(float* out, int n, int mode) {
 }
 
 int main() {
-    float* out; hipMalloc(&out, 16);
+    float* out; hipMalloc(&out, 32);
     const float cases[6][2] = {{16777216.f, 3.f}, {-16777216.f, -3.f}, {16777216.f, 1.f}, {-16777216.f, -1.f}, {16777216.f, 5.f}, {-16777216.f, -5.f}};
-    printf("%14s %4s | %14s %14s %14s %14s | exact\n", "C", "v", "32x32x16 bf16", "16x16x32 bf16", "32x32x2 f32", "bf16 unequal");
+    printf("%14s %4s | %14s %14s %14s %14s %14s | exact\n", "C", "v", "32x32x16 bf16", "16x16x32 bf16", "32x32x2 f32", "32x32x16 uneq", "16x16x32 uneq");
     for (auto& cs : cases) {
         hipLaunchKernelGGL(k, dim3(1), dim3(64), 0, 0, out, cs[0], cs[1]);
-        float h[4]; hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
-        printf("%14.1f %4.0f | %14.1f %14.1f %14.1f %14.1f | %.1f\n", cs[0], cs[1], h[0], h[1], h[2], h[3], (double)cs[0] + cs[1]);
+        float h[5]; hipMemcpy(h, out, 20, hipMemcpyDeviceToHost);
+        printf("%14.1f %4.0f | %14.1f %14.1f %14.1f %14.1f %14.1f | %.1f\n", cs[0], cs[1], h[0], h[1], h[2], h[3], h[4], (double)cs[0] + cs[1]);
     }
     for (int mode = 0; mode < 2; ++mode)
         for (int n : {100, 1000, 10000, 100000}) {
