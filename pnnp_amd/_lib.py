@@ -10,7 +10,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libpnnp_hip.so')
+# PNNP_LIB: another build of the SAME library (A/B experiments: tools/build_variant.sh); never a different implementation
+LIB_PATH = os.environ.get('PNNP_LIB') or os.path.join(_HERE, 'libpnnp_hip.so')
 _lib = None
 
 ERRORS = {-1: 'invalid argument', -2: 'unsupported configuration', -3: 'kernel launch failed', -4: 'workspace too small'}

@@ -44,6 +44,14 @@ namespace {
 #endif
 constexpr int NWAVE = X3_NWAVE, NTHR = 64 * NWAVE, MT = 16 / NWAVE;
 constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row tile, 612 halo pixels
+#ifndef X3_FILLMODE
+#define X3_FILLMODE 0              // BN = 64: which waves stage the next chunk's halo in which filter row (see the main loop)
+#endif
+#ifdef X3_NOBAR                    // timing experiment only (racy, wrong results): no per-item barriers -- what would ANY relaxation of them buy?
+#define X3_SYNC()
+#else
+#define X3_SYNC() __syncthreads()
+#endif
 #ifndef X3_M16
 #define X3_M16 1                   // 1: v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (see mfma_row16); 0: v_mfma_f32_32x32x16_bf16
 #endif
@@ -87,6 +95,11 @@ template <int BN> struct X3Cfg {
     static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // X3_M16 (padded planes): 156672 (BN = 64) / 163840 (BN = 32: ALL of the LDS)
     static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS: 160 KB on gfx950 (BN = 32 uses every byte: any growth must come out of something else)");
 };
+
+// which staging units (slice, step) of the next chunk's halo a filter row carries in its MFMA gaps: units LO .. HI - 1 of the 6 NSLICE
+template <int LO, int HI> struct Fill { static constexpr int lo = LO, hi = HI; static constexpr bool value = HI > LO; };
+using FillNone = Fill<0, 0>;
+using FillAll = Fill<0, 6 * NSLICE>;
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {                  // f(integral_constant<int, I>) ... for I .. N - 1: every index a constant
@@ -315,7 +328,7 @@ igemm_x3_kernel(const IgemmArgs a) {
         // slot 0 in tap 1 (slot 0's four slices were staged in tap 0), slot 1 in tap 2, slot 2 by the caller behind the row
         constexpr int HM = (int)decltype(halo_tag)::value;
         constexpr int NHP = HM == 1 ? NSLOT + 1 : (HM == 2 ? 2 : 0);
-        static_assert(HM != 2 || (NSLOT == 3 && FILL), "late halo requests follow the staging of a three-slot tile");
+        static_assert(HM != 2 || (NSLOT == 3 && FILL && decltype(fill_tag)::lo == 0 && decltype(fill_tag)::hi == 6 * NSLICE), "late halo requests follow the staging of a three-slot tile");
         constexpr int GT = NB * MB * 3;                             // MFMAs (= gaps) per tap
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
@@ -350,12 +363,12 @@ igemm_x3_kernel(const IgemmArgs a) {
                 if constexpr (sp == 2) a_read(tp + 1, mb, 0);
             }
             if constexpr (FILL) {
-                // the U = 6 NSLICE staging units of the row dealt evenly over its 3 GT gaps (8 waves: every gap at BN = 32, every other
-                // gap at BN = 64): unit n sits in gap ceil((n + 1) 3 GT / U) - 1
-                constexpr int U = NSLICE * 6, GR = 3 * GT;
+                // the row's U staging units (all 6 NSLICE of them, or the share the fill tag names) dealt evenly over its 3 GT gaps
+                // (all of them: every gap at BN = 32, every other gap at BN = 64): its unit n sits in gap ceil((n + 1) 3 GT / U) - 1
+                constexpr int ULO = decltype(fill_tag)::lo, U = decltype(fill_tag)::hi - ULO, GR = 3 * GT;
                 static_assert(U <= GR, "at most one staging unit per gap");
                 constexpr int n0 = (g * U + GR - 1) / GR, n1 = ((g + 1) * U + GR - 1) / GR;
-                if constexpr (n1 > n0 && n0 < U) stage_piece(n0 / 6, 0, n0 % 6, img ^ 1);
+                if constexpr (n1 > n0 && n0 < U) stage_piece((ULO + n0) / 6, 0, (ULO + n0) % 6, img ^ 1);
             }
             // requests: the even gaps w >= 4 of pass RP (no operand reads there; at BN = 64 no staging unit either)
             constexpr int RP = NB > 2 ? 1 : 0;
@@ -485,7 +498,7 @@ igemm_x3_kernel(const IgemmArgs a) {
 
     // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
     // channel base are wave-uniform per 32-column block); half a 32x32 tile (16 pixels) at a time through a 2 KB patch
-    auto epilogue = [&](const Tile& tl, float* epi) {
+    auto epilogue = [&](const Tile& tl, float* epi) __attribute__((always_inline)) {
         const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
         float* eb = epi + wave * (16 * Cfg::EPS);
         const int q4 = (lane & 7) * 4, pr = lane >> 3;
@@ -670,37 +683,46 @@ igemm_x3_kernel(const IgemmArgs a) {
         //   row 0: [weights row 1][halo of the NEXT chunk]   row 1: [weights row 2]   row 2: [weights of the next chunk's row 0]
         int st = 0;
 #ifdef X3_STAMPS                  // debug build: where does an item's time go?  (cycle sums per wave, dumped into dst[0] at the end)
-        long long tw = 0, tb = 0, tm = 0, te = 0, tall = clock64();
+        long long tw = 0, tb = 0, tm = 0, tm1 = 0, tm2 = 0, te = 0, tall = clock64();
 #define X3_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
         long long tlast_ = clock64();
 #else
 #define X3_T(v)
 #endif
+        // Where the next chunk's halo staging (146 VALU + 9 LDS stores per wave) sits -- X3_FILLMODE:
+        //   0  every wave in filter row 2 (rounds 2-3);
+        //   1  waves 0-3 in row 1, waves 4-7 in row 2: waves w and w + 4 share a SIMD, so in each of the two rows one wave of a SIMD
+        //      is VALU-dense while its partner issues MFMAs + operand reads only (complementary pairing, split by wave >= 4);
+        //   2  the same with the halves swapped;   3  every wave, half of the units in row 1 and half in row 2.
+        // A wave that stages in row 1 needs its halo loads (requested in row 0, tap 1) there already: vmcnt(0) instead of vmcnt(HL).
+        // The loop is instantiated per (units in row 1, units in row 2): with modes 1 / 2 the two wave halves run two straight-line bodies.
+        auto run = [&](auto f1, auto f2) __attribute__((always_inline)) {
         for (;;) {
             const Ck n1 = chunk_at(1);
             // ---- filter row 0: its weights have landed; the barrier publishes them and halo image img (written during the
-            // previous chunk's row 2), and says every wave is done with the other image and stage
+            // previous chunk's rows 1 / 2), and says every wave is done with the other image and stage
             __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
             X3_T(tw)
-            __syncthreads();
+            X3_SYNC();
             X3_T(tb)
-            mfma_row(0, st, img, std::false_type{}, std::true_type{}, [&](int rp) {
+            mfma_row(0, st, img, FillNone{}, std::true_type{}, [&](int rp) {
                 if (rp < D) dma_piece(cur, g, 1, st ^ 1, true, rp); else if (rp == D) halo_prep(n1.tile, n1.g); else halo_slot(rp - D - 1); });
             X3_T(tm)
             // ---- filter row 1
-            __builtin_amdgcn_s_waitcnt(0x0f70 | HL);                    // the weights of row 1; the halo loads stay in flight
+            if constexpr (decltype(f1)::value) __builtin_amdgcn_s_waitcnt(0x0f70);
+            else __builtin_amdgcn_s_waitcnt(0x0f70 | HL);               // the weights of row 1; the halo loads stay in flight
             X3_T(tw)
-            __syncthreads();
+            X3_SYNC();
             X3_T(tb)
-            mfma_row(1, st ^ 1, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, st, true, rp); });
-            X3_T(tm)
-            // ---- filter row 2 (+ the next chunk's halo: registers -> split -> image img^1, between the MFMAs)
+            mfma_row(1, st ^ 1, img, f1, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, st, true, rp); });
+            X3_T(tm1)
+            // ---- filter row 2
             __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: wait for all
             X3_T(tw)
-            __syncthreads();
+            X3_SYNC();
             X3_T(tb)
-            mfma_row(2, st, img, std::true_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); });
-            X3_T(tm)
+            mfma_row(2, st, img, f2, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); });
+            X3_T(tm2)
             if (g == nchunks - 1) {
                 __syncthreads();                                        // every wave has finished reading stage st: it holds the epilogue patches now
                 epilogue(cur, reinterpret_cast<float*>(wsb + st * Cfg::WS_STAGE));
@@ -710,11 +732,17 @@ igemm_x3_kernel(const IgemmArgs a) {
             if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
             st ^= 1; img ^= 1;
         }
+        };
+        constexpr int FM = X3_FILLMODE;
+        if constexpr (FM == 0) run(FillNone{}, FillAll{});
+        else if constexpr (FM == 3) run(Fill<0, 3 * NSLICE>{}, Fill<3 * NSLICE, 6 * NSLICE>{});
+        else if ((FM == 1) == (wave < NWAVE / 2)) run(FillAll{}, FillNone{});
+        else run(FillNone{}, FillAll{});
 #ifdef X3_STAMPS
         if (lane == 0) {
             __syncthreads();
             float* d = a.dst[0] + ((int64_t)blockIdx.x * NWAVE + wave) * 8;
-            d[0] = (float)tw; d[1] = (float)tb; d[2] = (float)tm; d[3] = (float)te; d[4] = (float)(clock64() - tall);
+            d[0] = (float)tw; d[1] = (float)tb; d[2] = (float)tm; d[3] = (float)te; d[4] = (float)(clock64() - tall); d[5] = (float)tm1; d[6] = (float)tm2;
         }
 #endif
     } else {
@@ -732,22 +760,22 @@ igemm_x3_kernel(const IgemmArgs a) {
             // ---- row 0: outstanding [w row 0][w row 1][halo next]
             __builtin_amdgcn_s_waitcnt(0x0f70 | (D + HL));
             __syncthreads();
-            mfma_row(0, 0, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); });
+            mfma_row(0, 0, img, FillNone{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); });
             // ---- row 1: outstanding [w row 1][halo next][w row 2]
             __builtin_amdgcn_s_waitcnt(0x0f70 | (HL + D));
             __syncthreads();
-            mfma_row(1, 1, img, std::false_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); });
+            mfma_row(1, 1, img, FillNone{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); });
             // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
             __builtin_amdgcn_s_waitcnt(0x0f70 | D);
             __syncthreads();
 #if X3_M16
             // the halo of the chunk after next: its requests ride in this row's gaps as the staging frees the registers (LATE, see mfma_row);
             // same issue order as a lump behind the row -- [weights of the next row 1][halo] -- so the vmcnt counts above hold
-            mfma_row(2, 2, img, std::true_type{}, std::integral_constant<int, 2>{}, [&](int rp) {
+            mfma_row(2, 2, img, FillAll{}, std::integral_constant<int, 2>{}, [&](int rp) {
                 if (rp < D) dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); else if (rp == D) halo_prep(n2.tile, n2.g); else halo_slot(rp - D - 1); });
             halo_slot(2);
 #else
-            mfma_row(2, 2, img, std::true_type{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); });
+            mfma_row(2, 2, img, FillAll{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); });
             load_halo(n2.tile, n2.g);
 #endif
             if (g == nchunks - 1) epilogue(cur, epi_sep);

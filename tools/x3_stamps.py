@@ -12,8 +12,8 @@ y = torch.empty(B, S, S, Co, device='cuda')
 for _ in range(3): ops.conv_x3_fwd(x, None, wx, b, y, Co, 1)
 torch.cuda.synchronize()
 d = y.reshape(-1)[:256 * 8 * 8].reshape(256, 8, 8).cpu()
-names = ['wait', 'barrier', 'mfma', 'epi', 'total']
-for wv in (0, 4, 1, 5):
+names = ['wait', 'barrier', 'row0', 'epi', 'total', 'row1', 'row2']
+for wv in (0, 4, 1, 5, 2, 6, 3, 7):
     m = d[:, wv].mean(0)
     print('wave', wv, ' '.join(f'{n}={float(v):.0f}' for n, v in zip(names, m)))
 tiles = (S // 32) * (S // 16) * B * (Co // 64) / 256.0
