@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/r4e10; mkdir -p $O
+V=tools/scratch/variants
+for r in 1 2 3; do
+  for t in fm0 new biaslate; do
+    echo "== $t" >> $O/layers.txt
+    if [ $t = new ]; then unset PNNP_LIB; else export PNNP_LIB=$V/libpnnp_$t.so; fi
+    python tools/layer_bench.py --x3 --only fwd,dgrad --reps 7 2>/dev/null | grep -v "^layer" >> $O/layers.txt
+  done
+done
+echo done > $O/done.txt

@@ -11,12 +11,13 @@ jobs = ops.PackJobs(); jobs.add_x3(w, wx, None, cin_pad=(Ci + 15) // 16 * 16); j
 y = torch.empty(B, S, S, Co, device='cuda')
 for _ in range(3): ops.conv_x3_fwd(x, None, wx, b, y, Co, 1)
 torch.cuda.synchronize()
-d = y.reshape(-1)[:256 * 8 * 8].reshape(256, 8, 8).cpu()
-names = ['wait', 'barrier', 'row0', 'epi', 'total', 'row1', 'row2']
+d = y.reshape(-1)[:256 * 8 * 16].reshape(256, 8, 16)[:, :, :9].cpu()
+names = ['wait', 'barrier', 'row0', 'top', 'total', 'row1', 'row2', 'epiA', 'epiB']
 for wv in (0, 4, 1, 5, 2, 6, 3, 7):
     m = d[:, wv].mean(0)
     print('wave', wv, ' '.join(f'{n}={float(v):.0f}' for n, v in zip(names, m)))
-tiles = (S // 32) * (S // 16) * B * (Co // 64) / 256.0
+bn = 64 if (Co >= 64 and (S // 32) * (S // 16) * B * (Co // 64) * 4 >= 256 * 3) else 32
+tiles = (S // 32) * (S // 16) * B * (Co // bn) / 256.0
 items = tiles * (Ci // 16) * 3
 m = d.mean((0, 1))
-print(f'items per CU {items:.0f};  per item:', ' '.join(f'{n}={float(v) / items:.0f}' for n, v in zip(names, m)), ' (MFMA cycles per item and SIMD: 4608)')
+print(f'items per CU {items:.0f};  per item:', ' '.join(f'{n}={float(v) / items:.0f}' for n, v in zip(names, m)), ' (MFMA cycles per item and SIMD: %d; BN = %d)' % (4608 * bn // 64, bn))
