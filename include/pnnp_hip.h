@@ -223,6 +223,22 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
                                    const float* x2 /*or null*/, int x2_cs, int C2, float* dW, float* dbias /*or null*/,
                                    int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
 
+/* backward-weight of the POINTWISE / STRIDED layers on the same scheme (csrc/wgrad_x3g.hip, round 4; they ran on the fp32 matrix cores
+ * before): kind 0 = Conv2d 1x1 (M = Cout, N = C1 + C2; replaces pnnp_conv_bwd_weight_f32 with taps = 1, archs/modules.py:184-187),
+ * 1 = ConvTranspose2d 2x2 stride 2 (M = Cin, N = Cout; replaces pnnp_convt2x2_bwd_weight_f32, archs/Unet.py:35-47),
+ * 2 = Conv2d 3x3 stride 2 (M = Cout, N = Cin; replaces pnnp_conv3x3s2_bwd_weight_f32, archs/ResUnet.py:18-27).  Same contracts as
+ * the entries they replace; `supported` says whether (M, N) has a tile configuration (otherwise use the fp32 entry); the workspace
+ * query takes the LOW-resolution map (the layer input of the ConvTranspose2d, the output of the stride-2 convolution). */
+int pnnp_x3g_wgrad_supported(int kind, int M, int N);
+int64_t pnnp_x3g_wgrad_workspace_floats(int kind, int B, int UH, int UW, int M, int N);
+int pnnp_convt2x2_x3_bwd_weight_f32(const float* x, int Cin, const float* g, int Cout, float* dW, float* dbias /*or null*/,
+                                    int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
+int pnnp_conv3x3s2_x3_bwd_weight_f32(const float* g, int Cout, const float* x, int Cin, float* dW, float* dbias /*or null*/,
+                                     int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
+int pnnp_conv1x1_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,
+                                   const float* x2 /*or null*/, int x2_cs, int C2, float* dW, float* dbias /*or null*/,
+                                   int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
+
 /* (The Winograd kernel's cycle-stamp hook `pnnp_wino_set_debug` exists only in profiling builds, -DPNNP_WINO_DEBUG=1: the shipped
  * library exports no debug hook, reads no environment variable and keeps no state between calls besides idempotent per-device
  * caches of device facts.) */

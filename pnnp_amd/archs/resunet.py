@@ -271,6 +271,9 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             elif taps == 9 and self._pol.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+            elif taps == 1 and self._pol.use_x3g_wgrad(ops.X3G_PW, cout, c1 + c2, gpre.shape[0], gpre.shape[1], gpre.shape[2], gpre.shape[1], gpre.shape[2],
+                                                       max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
+                ops.conv1x1_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             else:
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
 
@@ -298,7 +301,9 @@ class ResUnetEngine(_EngineBase):
             else:
                 ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
-            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
+            ct_wgrad = ops.convt_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_CT, below.shape[3], g_u.shape[3], B, below.shape[1], below.shape[2],
+                                                                           g_u.shape[1], g_u.shape[2], max(below.shape[3], g_u.shape[3])) else ops.convt_bwd_weight
+            ct_wgrad(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
             if f'upv{i}' in self.WX:
@@ -326,7 +331,9 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_bwd_data_res(g_t, W[f'b{l}_0'][1], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
             if l > 1:
                 c_prev = a[f'c{l - 1}']
-                ops.conv_s2_bwd_weight(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
+                s2_wgrad = ops.conv_s2_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_S2, g_x.shape[3], c_prev.shape[3], B, g_x.shape[1], g_x.shape[2],
+                                                                                c_prev.shape[1], c_prev.shape[2], max(g_x.shape[3], c_prev.shape[3])) else ops.conv_s2_bwd_weight
+                s2_wgrad(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
                 done(f'pool{l - 1}.conv.weight')
                 g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
                 if f'pool{l - 1}' in self.WX:
@@ -352,9 +359,12 @@ class ResUnetEngine(_EngineBase):
                        ops.x3_wgrad_workspace_floats(B, h, w, c, c), ops.x3_wgrad_workspace_floats(B, h, w, c, 2 * c))
             need = max(need, ops.wgrad_workspace_floats(B, h, w, c, c, 9), ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9),
                        ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 1), ops.wgrad_workspace_floats(B, h, w, c, self.cin, 9))
+            need = max(need, ops.x3g_wgrad_workspace_floats(ops.X3G_PW, B, h, w, c, 2 * c))
             if lv < 4:
                 need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 4),
-                           ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 18))
+                           ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 18),
+                           ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, h >> 1, w >> 1, ch[lv + 1], c),
+                           ops.x3g_wgrad_workspace_floats(ops.X3G_S2, B, h >> 1, w >> 1, ch[lv + 1], c))
         need = max(need, ops.head_bwd_workspace_floats(ch[0]), ops.first_wgrad_workspace_floats(ch[0]))
         return max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
 

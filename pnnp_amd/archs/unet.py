@@ -70,6 +70,13 @@ class ConvPolicy:
             return False
         return batch is None or ops.x3_wgrad_fits(batch, h, w, cs if cs is not None else max(cout, c1, c2))
 
+    def use_x3g_wgrad(self, kind, M, N, batch, uh, uw, sh, sw, cs):
+        """backward-weight of a ConvTranspose2d / stride-2 3x3 / 1x1 layer on the bf16x3 kernel of csrc/wgrad_x3g.hip?  (M, N) must have a
+        tile configuration and both whole maps must fit 32-bit byte offsets; otherwise the fp32-MFMA kernel of csrc/wgrad.hip takes it."""
+        if not (self.x3 and ops.x3g_wgrad_supported(kind, M, N)):
+            return False
+        return ops.x3_wgrad_fits(batch, uh, uw, cs) and ops.x3_wgrad_fits(batch, sh, sw, cs)
+
     def use_wino_wgrad(self, h, w, cout, c1, c2, g_cs, x_cs):
         return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
 
@@ -440,8 +447,9 @@ class UNetEngine(_EngineBase):
             g_skip = gb(f'c{lvl + 1}', skip.shape)
             dgrad(f'conv{i}_1', g_a, g_u, dx2=g_skip, mask2=skip, mode2=LRELU)
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
-            ops.convt_bwd_weight(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc,
-                                 dbias=G(f'upv{i}.bias', (ch[lvl],)))
+            ct_wgrad = ops.convt_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_CT, below.shape[3], ch[lvl], B, below.shape[1], below.shape[2],
+                                                                           g_u.shape[1], g_u.shape[2], max(below.shape[3], g_u.shape[3])) else ops.convt_bwd_weight
+            ct_wgrad(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc, dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
             if self._x3.get(f'upv{i}', (False, False))[1]:
@@ -485,7 +493,8 @@ class UNetEngine(_EngineBase):
                        ops.wgrad_workspace_floats(B, h, w, c, 2 * c, 9), ops.wino_wgrad_workspace_floats(B, h, w, c, c),
                        ops.wino_wgrad_workspace_floats(B, h, w, c, cin), ops.wino_wgrad_workspace_floats(B, h, w, c, 2 * c))
             if lvl < 4:
-                need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lvl + 1], c, 4))
+                need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lvl + 1], c, 4),
+                           ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, h >> 1, w >> 1, ch[lvl + 1], c))
         need = max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
         need = max(need, ops.head_bwd_workspace_floats(ch[0]), ops.first_wgrad_workspace_floats(ch[0]))
         return need

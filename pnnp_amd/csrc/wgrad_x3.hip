@@ -498,6 +498,16 @@ int wx3_splits(int B, int H, int W, int M, int N) {
 
 }  // namespace
 
+// slabs [Z][taps][M][N] (+ bias slabs [Z][nb] behind them) -> dW in the parameter's layout [M][N][taps] (+ dbias), alternating signs over z
+// (also used by csrc/wgrad_x3g.hip)
+int pnnp_wx3_reduce_launch(const float* slab, float* dW, int64_t mn, int taps, int Z, int accumulate,
+                           const float* bias_slab, float* dbias, int nb, hipStream_t st) {
+    const int64_t n = mn * taps, ntot = n + (bias_slab ? nb : 0);       // n % 32 == 0 (channels in multiples of 32)
+    hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((ntot + 31) / 32 > 4096 ? 4096 : (ntot + 31) / 32)), dim3(256), 0, st,
+                       slab, dW, n, Z, accumulate, mn, taps, bias_slab, dbias, nb);
+    return pnnp_launch_status();
+}
+
 extern "C" {
 
 int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2) {

@@ -39,6 +39,7 @@ def _prep():
         L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3_weight_bytes.restype = C.c_int64
         L.pnnp_x3_wgrad_workspace_floats.restype = C.c_int64
+        L.pnnp_x3g_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3mat_bytes.restype = C.c_int64
         L.pnnp_head_bwd_workspace_floats.restype = C.c_int64
         L.pnnp_first_wgrad_workspace_floats.restype = C.c_int64
@@ -375,6 +376,45 @@ def convt_bwd_data(g, w_dgrad, dx, mask=None, mode=0):
     with _Timed('convt_dgrad', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
         check(_prep().pnnp_convt2x2_bwd_data_f32(ptr(g), g.shape[3], ptr(w_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W,
                                                  stream()), 'convt_bwd_data')
+
+
+X3G_PW, X3G_CT, X3G_S2 = 0, 1, 2        # geometry kinds of csrc/wgrad_x3g.hip: Conv2d 1x1, ConvTranspose2d 2x2 s2, Conv2d 3x3 s2
+
+
+def x3g_wgrad_supported(kind, M, N):
+    """Does the bf16x3 backward-weight kernel of the pointwise / strided layers have a tile configuration for (M, N)?"""
+    return bool(_prep().pnnp_x3g_wgrad_supported(int(kind), int(M), int(N)))
+
+
+def x3g_wgrad_workspace_floats(kind, B, UH, UW, M, N):
+    return int(_prep().pnnp_x3g_wgrad_workspace_floats(int(kind), int(B), int(UH), int(UW), int(M), int(N)))
+
+
+def convt_x3_bwd_weight(x, g, dW, ws, accumulate=0, dbias=None):
+    """convt_bwd_weight on the bf16 matrix cores (fp32 operands split in three, csrc/wgrad_x3g.hip): Cin = M, Cout = N."""
+    require_cuda(x, g, dW, ws, dbias)
+    B, H, W, Cin = x.shape
+    with _Timed('convt_wgrad_x3', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_x3_bwd_weight_f32(ptr(x), Cin, ptr(g), g.shape[3], ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                      ptr(ws), _i64(ws.numel()), stream()), 'convt_x3_bwd_weight')
+
+
+def conv_s2_x3_bwd_weight(g, x, dW, dbias, ws, accumulate=0):
+    require_cuda(g, x, dW, ws)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_wgrad_x3', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_x3_bwd_weight_f32(ptr(g), g.shape[3], ptr(x), Cin, ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                       ptr(ws), _i64(ws.numel()), stream()), 'conv3x3s2_x3_bwd_weight')
+
+
+def conv1x1_x3_bwd_weight(g, cout, x1, c1, x2, dW, dbias, ws, accumulate=0):
+    """conv_bwd_weight(taps=1) on the bf16 matrix cores."""
+    require_cuda(g, x1, dW, ws)
+    B, H, W, gcs = g.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv1_wgrad_x3', 2.0 * B * H * W * cout * (c1 + C2), 4.0 * B * H * W * (c1 + C2 + cout)):
+        check(_prep().pnnp_conv1x1_x3_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), C2, C2, ptr(dW), ptr(dbias),
+                                                     B, H, W, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv1x1_x3_bwd_weight')
 
 
 def convt_bwd_weight(x, g, dW, ws, accumulate=0, dbias=None):

@@ -418,3 +418,87 @@ def test_x3_forward_signed_mean_error_is_bounded(positive):
     print(f'K=4608 {"positive" if positive else "rnd-sign"}: bf16x3 L2 {l3:.2e} signed mean {b3:+.2e} | fp32-MFMA L2 {l32:.2e} signed mean {b32:+.2e}')
     assert l3 < 2.0 * l32 + 1e-8
     assert abs(b3) < (5e-7 if positive else 4e-6)
+
+
+# ---- round 4: weight gradients of the pointwise / strided layers on the bf16 matrix cores (csrc/wgrad_x3g.hip)
+@pytest.mark.parametrize('case', [(2, 8, 16, 256, 64), (1, 5, 19, 512, 256), (2, 6, 24, 128, 64), (1, 3, 35, 128, 64), (1, 16, 32, 64, 32),
+                                  (2, 9, 40, 64, 32), (1, 7, 9, 256, 128), (1, 4, 34, 64, 64)])
+def test_x3_convt_bwd_weight(case):
+    """dW [Cin][Cout][2][2] and dbias of ConvTranspose2d(k2, s2) (archs/Unet.py:35-47) vs autograd, for every tile configuration
+    (256 x 64, 128 x 64, 64 x 32 output tiles), maps that do not fill their pixel tiles, and `accumulate`."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = case
+    assert ops.x3g_wgrad_supported(ops.X3G_CT, Ci, Co)
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Ci, Co, 2, 2, seed=2, scale=0.2).requires_grad_(True); b = _rand(Co, seed=3).requires_grad_(True)
+    g = _rand(B, Co, 2 * H, 2 * W, seed=4)
+    F.conv_transpose2d(x, w, b, stride=2).backward(g)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, H, W, Ci, Co), device='cuda')
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.convt_x3_bwd_weight(nhwc(x).cuda(), nhwc(g).cuda(), dW, ws, dbias=db)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'x3 convT wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'x3 convT dbias {case}')
+    ops.convt_x3_bwd_weight(nhwc(x).cuda(), nhwc(g).cuda(), dW, ws, accumulate=1, dbias=db)
+    close(dW, 2 * w.grad, rtol=2e-4, atol=4e-5, what='x3 convT wgrad accumulate')
+    close(db, 2 * b.grad, rtol=2e-4, atol=4e-5, what='x3 convT dbias accumulate')
+    dW2 = torch.full(w.shape, float('nan'), device='cuda')
+    ops.convt_x3_bwd_weight(nhwc(x).cuda(), nhwc(g).cuda(), dW2, ws)
+    close(dW2, w.grad, rtol=2e-4, atol=2e-5, what='x3 convT wgrad without dbias')
+
+
+@pytest.mark.parametrize('case', [(2, 16, 64, 32, 128), (1, 12, 40, 64, 128), (1, 6, 70, 128, 256), (1, 4, 4, 256, 512), (1, 34, 66, 32, 128), (2, 2, 6, 64, 256)])
+def test_x3_conv3x3_stride2_bwd_weight(case):
+    """dW [Cout][Cin][3][3] and dbias of the ResUnet's down-sampling conv (archs/modules.py:130-138) vs autograd: Cout in multiples of
+    128 run on the bf16x3 kernel (halo rows / columns outside the map, odd tile counts); others are refused (the fp32 kernel takes them)."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = case
+    assert ops.x3g_wgrad_supported(ops.X3G_S2, Co, Ci) and not ops.x3g_wgrad_supported(ops.X3G_S2, 64, 32)
+    x = _rand(B, Ci, H, W, seed=1)
+    w = _rand(Co, Ci, 3, 3, seed=2, scale=0.2).requires_grad_(True); b = _rand(Co, seed=3).requires_grad_(True)
+    g = _rand(B, Co, H // 2, W // 2, seed=4)
+    F.conv2d(x, w, b, stride=2, padding=1).backward(g)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_S2, B, H // 2, W // 2, Co, Ci), device='cuda')
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_s2_x3_bwd_weight(nhwc(g).cuda(), nhwc(x).cuda(), dW, db, ws)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'x3 s2 wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'x3 s2 dbias {case}')
+    ops.conv_s2_x3_bwd_weight(nhwc(g).cuda(), nhwc(x).cuda(), dW, None, ws, accumulate=1)
+    close(dW, 2 * w.grad, rtol=2e-4, atol=4e-5, what='x3 s2 wgrad accumulate')
+
+
+@pytest.mark.parametrize('case', [(2, 8, 32, 64, 64, 128), (1, 12, 40, 128, 128, 128), (1, 5, 17, 128, 0, 64), (1, 16, 33, 64, 64, 64), (2, 9, 20, 256, 0, 128)])
+def test_x3_conv1x1_bwd_weight(case):
+    """dW [Cout][C1 + C2] of the ResidualBlock shortcut (archs/modules.py:184-187), input = the un-materialised cat of two tensors."""
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    assert ops.x3g_wgrad_supported(ops.X3G_PW, Co, C1 + C2)
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    w = _rand(Co, C1 + C2, 1, 1, seed=3, scale=0.2).requires_grad_(True); b = _rand(Co, seed=4).requires_grad_(True)
+    g = _rand(B, Co, H, W, seed=5)
+    F.conv2d(torch.cat([x1, x2], 1) if C2 else x1, w, b).backward(g)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_PW, B, H, W, Co, C1 + C2), device='cuda')
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv1x1_x3_bwd_weight(nhwc(g).cuda(), Co, nhwc(x1).cuda(), C1, nhwc(x2).cuda() if C2 else None, dW, db, ws)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'x3 1x1 wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'x3 1x1 dbias {case}')
+
+
+def test_x3_convt_wgrad_is_as_accurate_as_the_fp32_mfma_kernel():
+    """float64 yardstick at the benchmark's second decoder level (upv7: 64 x 64 -> 128 x 128, 256 -> 128 channels, B = 4: K = 16 384 pixels
+    per weight): relative L2 error of the bf16x3 kernel within 2x of the fp32-MFMA kernel's (alternating signs over the pixel splits)."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 4, 64, 64, 256, 128
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen); g = torch.randn(B, 2 * H, 2 * W, Co, device='cuda', generator=gen)
+    ref = torch.zeros(Ci, Co, 2, 2, dtype=torch.float64, device='cuda')
+    xd = x.double().reshape(-1, Ci)
+    for a_ in range(2):
+        for c_ in range(2):
+            ref[:, :, a_, c_] = xd.t() @ g[:, a_::2, c_::2].double().reshape(-1, Co)
+    ws = torch.empty(max(ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, H, W, Ci, Co), ops.wgrad_workspace_floats(B, H, W, Ci, Co, 4)), device='cuda')
+    d3 = torch.empty(Ci, Co, 2, 2, device='cuda'); d32 = torch.empty_like(d3)
+    ops.convt_x3_bwd_weight(x, g, d3, ws)
+    ops.convt_bwd_weight(x, g, d32, ws)
+    e3 = float((d3.double() - ref).norm() / ref.norm()); e32 = float((d32.double() - ref).norm() / ref.norm())
+    print(f'convT wgrad K = {B * H * W}: rel L2 vs float64: bf16x3 {e3:.2e}, fp32-MFMA {e32:.2e}')
+    assert e3 < 2.0 * e32 + 1e-8 and e3 < 2e-6
