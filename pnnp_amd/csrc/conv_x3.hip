@@ -175,6 +175,19 @@ igemm_x3_kernel(const IgemmArgs a) {
         o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN;
         return o;
     };
+    // A workgroup's tiles are t, t + G, t + 2 G, ...: the step G is decoded ONCE and the next tile is a mixed-radix addition with carries
+    // (a dozen scalar instructions) instead of three integer divisions by run-time values (cycle stamps of round 4: with decode() reachable
+    // from the top of the chunk loop that top took 1100 cycles per chunk in the BN = 32 kernel, 8 % of a chunk).
+    // (Tiles are picked FIELD BY FIELD: `c ? tileA : tileB` on whole structs becomes a select of ADDRESSES, which parks them in scratch memory.)
+    auto pick = [](bool c, const Tile& x, const Tile& y) { Tile o; o.b = c ? x.b : y.b; o.y0 = c ? x.y0 : y.y0; o.x0 = c ? x.x0 : y.x0; o.n0 = c ? x.n0 : y.n0; return o; };
+    const Tile gstep = decode(G);
+    auto advance = [&](Tile o) {
+        o.n0 += gstep.n0; if (o.n0 >= n_tiles * BN) { o.n0 -= n_tiles * BN; o.x0 += 32; }
+        o.x0 += gstep.x0; if (o.x0 >= tiles_x * 32) { o.x0 -= tiles_x * 32; o.y0 += TH; }
+        o.y0 += gstep.y0; if (o.y0 >= tiles_y * TH) { o.y0 -= tiles_y * TH; o.b += 1; }
+        o.b += gstep.b;
+        return o;
+    };
 
 #ifdef X3_STAMPS                  // debug build: where does an item's time go?  (cycle sums per wave, dumped into dst[0] at the end)
     long long tw = 0, tb = 0, tm = 0, tm1 = 0, tm2 = 0, te = 0, tea = 0, teb = 0, tall = clock64();
@@ -685,21 +698,24 @@ igemm_x3_kernel(const IgemmArgs a) {
     // reads weight stage it % NSTAGE and, right after its barrier, requests the weights of item it + AHEAD.
     int t = xcd_remap(blockIdx.x, G);
     if (t >= total) return;
-    Tile cur = decode(t), nxt = decode(t + G < total ? t + G : t);       // nxt: the tile this workgroup takes after cur
+    Tile cur = decode(t), nxt = pick(t + G < total, advance(cur), cur);  // nxt: the tile this workgroup takes after cur
+    Tile nxt2 = pick(t + 2 * G < total, advance(nxt), nxt);              // ... and the one after that (a chunk two ahead may belong to it when K is one chunk)
     int g = 0, img = 0;
     constexpr int D = Cfg::DPW, HL = 2 * NSLOT;                          // vmcnt units: weight requests of one item, halo loads of one chunk
-    // the k-th chunk after the current one: (tile, chunk, exists); past the end of this workgroup's work it falls back to the
+    // the k-th chunk after the current one, k = 1, 2: (tile, chunk, exists); past the end of this workgroup's work it falls back to the
     // current chunk (requests stay branch-free and the instruction counts exact; weights are then requested with valid = false)
     struct Ck { Tile tile; int g; bool ok; };
     auto chunk_at = [&](int k) {
-        int gk = g + k, tk = t;
-        while (gk >= nchunks) { gk -= nchunks; tk += G; }
+        int gk = g + k, hop = 0;
+        if (gk >= nchunks) { gk -= nchunks; hop = 1; }
+        if (gk >= nchunks) { gk -= nchunks; hop = 2; }                   // (k <= 2: at most two tile changes, and only when nchunks == 1)
         Ck c;
-        c.ok = tk < total;
+        c.ok = t + hop * G < total;
         c.g = c.ok ? gk : g;
-        c.tile = !c.ok || tk == t ? cur : (tk == t + G ? nxt : decode(tk));
+        c.tile = pick(!c.ok || hop == 0, cur, pick(hop == 1, nxt, nxt2));
         return c;
     };
+    auto next_tile = [&]() { t += G; cur = nxt; nxt = nxt2; nxt2 = pick(t + 2 * G < total, advance(nxt), nxt); g = 0; };
     dma_weights(cur, 0, 0, 0);
     load_halo(cur, 0);
     __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -753,7 +769,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 X3_T(te)
             }
             if (!n1.ok) break;
-            if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
+            if (g == nchunks - 1) next_tile(); else ++g;
             st ^= 1; img ^= 1;
         }
         };
@@ -810,7 +826,7 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_T(tm2)
             if (g == nchunks - 1) epilogue(cur, epi_sep);
             if (!n1.ok) break;
-            if (g == nchunks - 1) { t += G; cur = nxt; nxt = decode(t + G < total ? t + G : t); g = 0; } else ++g;
+            if (g == nchunks - 1) next_tile(); else ++g;
             img ^= 1;
         }
 #ifdef X3_STAMPS
