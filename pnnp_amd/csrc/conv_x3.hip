@@ -52,6 +52,9 @@ constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row
 #else
 #define X3_SYNC() __syncthreads()
 #endif
+#ifndef X3_DEFER32
+#define X3_DEFER32 0               // experiment (measured neutral, costs 40 registers): BN = 32: a tile's output stores go out between the next chunk's MFMAs (see `pend`)
+#endif
 #ifndef X3_M16
 #define X3_M16 1                   // 1: v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (see mfma_row16); 0: v_mfma_f32_32x32x16_bf16
 #endif
@@ -190,7 +193,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     };
 
 #ifdef X3_STAMPS                  // debug build: where does an item's time go?  (cycle sums per wave, dumped into dst[0] at the end)
-    long long tw = 0, tb = 0, tm = 0, tm1 = 0, tm2 = 0, te = 0, tea = 0, teb = 0, tall = clock64();
+    long long tw = 0, tb = 0, tm = 0, tm1 = 0, tm2 = 0, te = 0, tea = 0, teb = 0, ter[5] = {0, 0, 0, 0, 0}, tall = clock64();
 #define X3_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
     long long tlast_ = clock64();
     auto dump_stamps = [&]() {
@@ -198,7 +201,7 @@ igemm_x3_kernel(const IgemmArgs a) {
         if (lane == 0) {
             float* d = a.dst[0] + ((int64_t)blockIdx.x * NWAVE + wave) * 16;
             d[0] = (float)tw; d[1] = (float)tb; d[2] = (float)tm; d[3] = (float)te; d[4] = (float)(clock64() - tall); d[5] = (float)tm1; d[6] = (float)tm2;
-            d[7] = (float)tea; d[8] = (float)teb;
+            d[7] = (float)tea; d[8] = (float)teb; for (int i = 0; i < 5; ++i) d[9 + i] = (float)ter[i];
         }
     };
 #else
@@ -349,7 +352,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     // sits in the gaps between MFMAs, one or two instructions per gap, fenced (as in the 32x32x16 version below):
     //   reads as just described; FILL: the 72 (slice, step) units of the next chunk's halo staging (one per gap at BN = 32, every
     //   other gap at BN = 64); `requests`: the item's LDS-DMA / halo-load pieces in read-free gaps of pass 1 (BN = 64) or 0.
-    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests) {
+    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests, auto&& hook) {
         constexpr bool FILL = decltype(fill_tag)::value;
         // halo requests of the row: 0 none; 1 all NSLOT + 1 pieces in tap 1 (BN = 64, filter row 0: the registers are free);
         // 2 LATE (BN = 32, filter row 2, whose gaps also carry the staging that empties those registers slot by slot): the scalar part and
@@ -413,6 +416,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 if constexpr (tp == 1 && rp < NHP) requests(Cfg::DPW + rp);
                 if constexpr (HM == 2 && tp == 2 && rp == 0) requests(Cfg::DPW + 2);
             }
+            hook(G);                                                 // (deferred output stores of the previous tile: BN = 32, see `pend`)
             __builtin_amdgcn_sched_barrier(0);
         });
     };
@@ -421,7 +425,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     // chunk's halo (into image img ^ 1) are dealt over the 3 * MT * NT groups of six MFMAs.  `requests` (the LDS-DMA / halo
     // loads this item has to issue: ~200 scalar + vector instructions of address arithmetic) runs right after the first group
     // of MFMAs has been issued rather than in front of the item's first LDS reads.
-    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests) {
+    auto mfma_row = [&](int tr, int st, int img, auto fill_tag, auto halo_tag, auto&& requests, auto&&) {
         constexpr bool FILL = decltype(fill_tag)::value;
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
@@ -530,10 +534,86 @@ igemm_x3_kernel(const IgemmArgs a) {
 
 #endif      // X3_M16
 
+    // ---- the epilogue's kernel arguments, cached in ONE vector register (lane i = argument i) and fetched with v_readlane.
+    // Round 4 (ISA + cycle stamps): the main loop leaves no scalar registers for them, so the compiler RE-LOADED them from the kernel-argument
+    // segment wherever the epilogue used one -- ~25 `s_load` + `s_waitcnt lgkmcnt(0)` chains of 150-300 cycles each per tile, with the matrix
+    // pipe idle: 3400 cycles of a BN = 32 tile's 29 000, 7000 of a BN = 64 tile.  A value that comes out of a v_readlane cannot be
+    // re-materialised from memory; if it has to leave its scalar register it goes into a spill lane (a v_readlane again).
+    enum { E_OH, E_OW, E_DH, E_DW, E_NTOT, E_NSPLIT, E_ACT, E_POOLCS, E_CS0, E_CS1, E_MM0, E_MM1, E_AC0, E_AC1,
+           E_DST0, E_DST1 = E_DST0 + 2, E_MASK0 = E_DST1 + 2, E_MASK1 = E_MASK0 + 2, E_ADD = E_MASK1 + 2, E_BIAS = E_ADD + 2, E_PDST = E_BIAS + 2,
+           E_PCODE = E_PDST + 2, E_COUNT = E_PCODE + 2 };
+    static_assert(E_COUNT <= 64, "one lane per cached argument");
+    unsigned argv = 0;
+    {
+        auto put = [&](int idx, unsigned v) { argv = lane == idx ? v : argv; };
+        auto putp = [&](int idx, const void* q) { put(idx, (unsigned)(uintptr_t)q); put(idx + 1, (unsigned)((uintptr_t)q >> 32)); };
+        put(E_OH, a.OH); put(E_OW, a.OW); put(E_DH, a.DH); put(E_DW, a.DW); put(E_NTOT, a.Ntot); put(E_NSPLIT, a.n_split); put(E_ACT, a.act);
+        put(E_POOLCS, a.pool_cs); put(E_CS0, a.dst_cs[0]); put(E_CS1, a.dst_cs[1]); put(E_MM0, a.mask_mode[0]); put(E_MM1, a.mask_mode[1]);
+        put(E_AC0, a.accum[0]); put(E_AC1, a.accum[1]);
+        putp(E_DST0, a.dst[0]); putp(E_DST1, a.dst[1]); putp(E_MASK0, a.mask[0]); putp(E_MASK1, a.mask[1]); putp(E_ADD, a.addsrc); putp(E_BIAS, a.bias);
+        putp(E_PDST, a.pool_dst); putp(E_PCODE, a.pool_codes);
+    }
+    struct EpiArgs {
+        int OH, OW, DH, DW, Ntot, n_split, act, pool_cs, cs0, cs1, mm0, mm1, ac0, ac1;
+        float *dst0, *dst1, *pool_dst; const float *mask0, *mask1, *addsrc, *bias; unsigned char* pool_codes;
+        __device__ int dst_cs(int du) const { return du ? cs1 : cs0; }
+        __device__ int mask_mode(int du) const { return du ? mm1 : mm0; }
+        __device__ int accum(int du) const { return du ? ac1 : ac0; }
+        __device__ float* dst(int du) const { return du ? dst1 : dst0; }
+        __device__ const float* mask(int du) const { return du ? mask1 : mask0; }
+    };
+    auto epi_args = [&]() {
+        auto rl = [&](int idx) { return (int)__builtin_amdgcn_readlane((int)argv, idx); };
+        auto rp = [&](int idx) { return (uintptr_t)(unsigned)rl(idx) | ((uintptr_t)(unsigned)rl(idx + 1) << 32); };
+        EpiArgs e;
+        e.OH = rl(E_OH); e.OW = rl(E_OW); e.DH = rl(E_DH); e.DW = rl(E_DW); e.Ntot = rl(E_NTOT); e.n_split = rl(E_NSPLIT); e.act = rl(E_ACT);
+        e.pool_cs = rl(E_POOLCS); e.cs0 = rl(E_CS0); e.cs1 = rl(E_CS1); e.mm0 = rl(E_MM0); e.mm1 = rl(E_MM1); e.ac0 = rl(E_AC0); e.ac1 = rl(E_AC1);
+        e.dst0 = (float*)rp(E_DST0); e.dst1 = (float*)rp(E_DST1); e.mask0 = (const float*)rp(E_MASK0); e.mask1 = (const float*)rp(E_MASK1);
+        e.addsrc = (const float*)rp(E_ADD); e.bias = (const float*)rp(E_BIAS); e.pool_dst = (float*)rp(E_PDST); e.pool_codes = (unsigned char*)rp(E_PCODE);
+        return e;
+    };
+
+    // ---- deferred output stores of the 32-column kernel (X3_DEFER32).  A CU's vector-memory STORE path takes ~16-19 bytes per cycle (round 4:
+    // eight 1 KB stores per wave = 64 KB per CU in 3450 cycles, whatever surrounds them), which at the end of a K = 32 tile is 12 % of the
+    // tile with the matrix pipe idle.  The epilogue therefore leaves the tile's eight full-resolution stores in registers (value + offset) and
+    // they go out ONE at a time, ~12 MFMAs apart, in gaps of the NEXT chunk's filter rows 0 and 1 (pass 1: no requests there); the staging
+    // registers are idle in those rows, so the 40 registers fit.  In front of barriers instead (tried) the stores block all waves together.
+    constexpr bool DEFER = X3_DEFER32 && BN == 32 && X3_M16;
+    constexpr int NST = NT * MT * 2 * 2;                            // full-resolution 16-byte stores per wave and tile
+    [[maybe_unused]] f32x4 pend_o[NST];
+    [[maybe_unused]] unsigned pend_ok = 0, pend_lo = 0;             // per lane: bit s = store s is inside the map; its lane offset (pixel pr, channel quad)
+    [[maybe_unused]] int pend_b = 0, pend_du = 0, pend_y = 0, pend_x = 0, pend_c = 0;     // the tile: image, destination, first row / column of this wave, channel base
+    [[maybe_unused]] bool pend = false;
+    auto nohook = [](auto) {};
+    auto pend_rsrc = [&]() {
+        const EpiArgs ea = epi_args();
+        const int cs2 = ea.dst_cs(pend_du);
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(ea.dst(pend_du) + (int64_t)pend_b * ea.OH * ea.OW * cs2), 0, ea.OH * ea.OW * cs2 * 4, 0x00020000);
+    };
+    // store s = (row i, half h2, pixel group e): scalar offset of its first pixel + the lane offset (or out of range)
+    auto pend_store = [&](int sidx, const __amdgpu_buffer_rsrc_t& prd) {
+        const int so_ow = (int)__builtin_amdgcn_readlane((int)argv, E_OW), so_cs = (int)__builtin_amdgcn_readlane((int)argv, pend_du ? E_CS1 : E_CS0);
+        const int e = sidx & 1, h2 = (sidx >> 1) & 1, i = sidx >> 2;
+        const int so = (((pend_y + i) * so_ow + pend_x + 16 * h2 + (POOL ? e : 8 * e)) * so_cs + pend_c) * 4;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, pend_o[sidx]), prd, (pend_ok >> sidx) & 1 ? pend_lo : OOB, so, 0);
+    };
+    // store hook of filter row R (0 / 1): gaps (tap tp, pass 1, w = 3 or 9) -> store number 6 R + 2 tp + (w == 9)
+    auto store_hook = [&](auto row_tag, const __amdgpu_buffer_rsrc_t& prd) {
+        return [&, prd](auto G) {
+            constexpr int R = decltype(row_tag)::value, g = decltype(G)::value;
+            constexpr int GT = (BN / 16) * (2 * MT) * 3, tp = g / GT, gt = g % GT, j = gt / (2 * MT * 3), w = gt % (2 * MT * 3);
+            if constexpr (j == 1 && (w == 3 || w == 9)) {
+                constexpr int sidx = 6 * R + 2 * tp + (w == 9 ? 1 : 0);
+                if constexpr (sidx < NST) pend_store(sidx, prd);
+            }
+        };
+    };
+
     // ---- epilogue of tile `tl` (csrc/conv_igemm.hip's fast path: n_split / n_sub are multiples of 32, so destination, mask and
     // channel base are wave-uniform per 32-column block); half a 32x32 tile (16 pixels) at a time through a 2 KB patch
     auto epilogue = [&](const Tile& tl, float* epi) __attribute__((always_inline)) {
         X3_T(te)
+        const EpiArgs ea = epi_args();
         const int b = tl.b, x0 = tl.x0, y0 = tl.y0, n0 = tl.n0;
         float* eb = epi + wave * (16 * Cfg::EPS);
         const int q4 = (lane & 7) * 4, pr = lane >> 3;
@@ -543,27 +623,27 @@ igemm_x3_kernel(const IgemmArgs a) {
             // half from the patch, so after both rows it holds a whole 2x2 window of 4 channels: it writes the pooled float4
             // and the four codes (bits 0-1 first maximum in the order (0,0) (0,1) (1,0) (1,1), bits 2-5 the signs) of
             // csrc/misc.hip maxpool_fwd_codes_kernel -- the pool kernel and its re-read of the full-resolution map go away.
-            const int cs2 = a.dst_cs[0];
-            const int64_t imgo = (int64_t)b * a.OH * a.OW * cs2;
-            const int ibytes = a.OH * a.OW * cs2 * 4;
-            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dst[0] + imgo), 0, ibytes, 0x00020000);
-            const int ph = a.OH >> 1, pw = a.OW >> 1;
-            const int64_t pimg = (int64_t)b * ph * pw * a.pool_cs;
-            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool_dst + pimg), 0, ph * pw * a.pool_cs * 4, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.pool_codes + pimg), 0, ph * pw * a.pool_cs, 0x00020000);
-            const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
+            const int cs2 = ea.dst_cs(0);
+            const int64_t imgo = (int64_t)b * ea.OH * ea.OW * cs2;
+            const int ibytes = ea.OH * ea.OW * cs2 * 4;
+            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.dst(0) + imgo), 0, ibytes, 0x00020000);
+            const int ph = ea.OH >> 1, pw = ea.OW >> 1;
+            const int64_t pimg = (int64_t)b * ph * pw * ea.pool_cs;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.pool_dst + pimg), 0, ph * pw * ea.pool_cs * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.pool_codes + pimg), 0, ph * pw * ea.pool_cs, 0x00020000);
+            const float aslope = ea.act == 1 ? 0.2f : (ea.act == 2 ? 0.f : 1.f);
             const int py0 = y0 + wave * MT;
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
-                const bool n_ok = nwv + q4 < a.Ntot;
+                const bool n_ok = nwv + q4 < ea.Ntot;
                 f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-                if (a.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nwv + q4);
+                if (ea.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(ea.bias + nwv + q4);
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     f32x4 win[2][2];
                     const int px = x0 + 16 * h2 + 2 * pr;
-                    const bool ok2 = py0 < a.DH && px < a.DW && n_ok;            // even sizes: the whole window is inside or outside
+                    const bool ok2 = py0 < ea.DH && px < ea.DW && n_ok;            // even sizes: the whole window is inside or outside
 #pragma unroll
                     for (int i = 0; i < MT; ++i) {
                         spill_half(eb, i, k, h2);
@@ -573,8 +653,9 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
                             win[i][e] = o;
-                            const unsigned vo = ok2 ? (unsigned)((((py0 + i) * a.OW + px + e) * cs2 + nwv + q4) * 4) : OOB;
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo, 0, 0);
+                            const unsigned vo = ok2 ? (unsigned)((((py0 + i) * ea.OW + px + e) * cs2 + nwv + q4) * 4) : OOB;
+                            if constexpr (DEFER) { pend_o[(i * 2 + h2) * 2 + e] = o; pend_ok |= (ok2 ? 1u : 0u) << ((i * 2 + h2) * 2 + e); }
+                            else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo, 0, 0);
                         }
                     }
                     f32x4 mx;
@@ -590,27 +671,122 @@ igemm_x3_kernel(const IgemmArgs a) {
                         mx[c] = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
                         code |= cj << (8 * c);
                     }
-                    const unsigned po = (unsigned)(((py0 >> 1) * pw + (px >> 1)) * a.pool_cs + nwv + q4);
+                    const unsigned po = (unsigned)(((py0 >> 1) * pw + (px >> 1)) * ea.pool_cs + nwv + q4);
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mx), rp, ok2 ? po * 4u : OOB, 0, 0);
                     __builtin_amdgcn_raw_buffer_store_b32(code, rc, ok2 ? po : OOB, 0, 0);
                 }
             }
+            if constexpr (DEFER) {
+                pend = true; pend_b = b; pend_du = 0; pend_y = py0; pend_x = x0; pend_c = n0;
+                pend_lo = __umul24(2 * pr, cs2 * 4) + q4 * 4;           // the pixel pair (2 pr, 2 pr + 1): + e through the scalar offset
+            }
             return;
+        }
+        // ---- the two common cases as ONE straight-line block (round 4).  Per-round cycle stamps put every 16-pixel round of the general code
+        // below at 800-900 cycles for ~80 instructions: the rounds are separated by the (wave-uniform) branches on mask / accumulate /
+        // residual, so the compiler cannot interleave them, and a wave that runs its epilogue ALONE on its SIMD (its partner waits at the
+        // barrier) executes one dependent chain -- LDS write -> read -> bias -> activation -> store -- after the other: 3400 cycles per
+        // BN = 32 tile, 7000 per BN = 64 tile, with the matrix pipe idle.  Without the branches all patch round trips are issued back to
+        // back (LDS operations of a wave execute in order: the ONE patch is rewritten right behind the reads of the previous round) and
+        // the rounds' arithmetic overlaps.
+        //   FWD: no mask, no accumulation, no residual (every forward layer)        BWD: act' mask on every destination, nothing else
+        {
+            const bool two = ea.dst1 != nullptr;
+            const bool plain = !ea.addsrc && !ea.ac0 && !(two && ea.ac1);
+            const bool is_fwd = plain && !ea.mm0 && !(two && ea.mm1), is_bwd = plain && ea.mm0 && (!two || ea.mm1);
+            auto fast = [&](auto masked_tag) __attribute__((always_inline)) {
+                constexpr bool MASKED = decltype(masked_tag)::value;
+                int du_[NT], chw_[NT], cs_[NT]; bool blk_[NT]; float msl_[NT];
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
+                    du_[k] = nwv >= ea.n_split ? 1 : 0; chw_[k] = nwv - (du_[k] ? ea.n_split : 0); cs_[k] = ea.dst_cs(du_[k]);
+                    blk_[k] = nwv < ea.Ntot; msl_[k] = ea.mask_mode(du_[k]) == 1 ? 0.2f : 0.f;
+                }
+                auto voff = [&](int k, int i, int h2, int e) {
+                    const bool ok = blk_[k] && y0 + wave * MT + i < ea.DH && x0 + 16 * h2 + pr + 8 * e < ea.DW;
+                    unsigned v = ok ? (unsigned)((((y0 + wave * MT + i) * ea.OW + x0 + 16 * h2 + pr + 8 * e) * cs_[k] + chw_[k] + q4) * 4) : OOB;
+#ifdef X3_EPI_OOB
+                    v |= OOB;
+#endif
+                    return v;
+                };
+                f32x4 mk[MASKED ? NT : 1][MT][2][2], pv[NT][MT][2][2], bias4[NT];
+                if constexpr (MASKED) {
+#pragma unroll
+                    for (int k = 0; k < NT; ++k) {
+                        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.mask(du_[k]) + (int64_t)b * ea.OH * ea.OW * cs_[k]), 0,
+                                                                                             ea.OH * ea.OW * cs_[k] * 4, 0x00020000);
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                                for (int e = 0; e < 2; ++e)
+                                    mk[k][i][h2][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff(k, i, h2, e), 0, 0));
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    bias4[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (ea.bias && blk_[k]) bias4[k] = *reinterpret_cast<const f32x4*>(ea.bias + n0 + k * 32 + q4);
+                }
+#pragma unroll
+                for (int k = 0; k < NT; ++k)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2) {
+                            spill_half(eb, i, k, h2);
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) pv[k][i][h2][e] = *reinterpret_cast<const f32x4*>(eb + (pr + 8 * e) * Cfg::EPS + q4);
+                        }
+                X3_T(tea)
+                const float aslope = ea.act == 1 ? 0.2f : (ea.act == 2 ? 0.f : 1.f);
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.dst(du_[k]) + (int64_t)b * ea.OH * ea.OW * cs_[k]), 0,
+                                                                                         ea.OH * ea.OW * cs_[k] * 4, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                f32x4 o = pv[k][i][h2][e] + bias4[k];
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+                                if constexpr (MASKED) {
+#pragma unroll
+                                    for (int c = 0; c < 4; ++c) o[c] *= (mk[k][i][h2][e][c] > 0.f) ? 1.f : msl_[k];
+                                }
+                                const unsigned vo = voff(k, i, h2, e);
+                                if constexpr (DEFER) { pend_o[(i * 2 + h2) * 2 + e] = o; pend_ok |= (vo != OOB ? 1u : 0u) << ((i * 2 + h2) * 2 + e); }
+                                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo, 0, 0);
+                            }
+                }
+                if constexpr (DEFER) {
+                    pend = true; pend_b = b; pend_y = y0 + wave * MT; pend_x = x0; pend_du = du_[0]; pend_c = chw_[0]; pend_lo = __umul24(pr, cs_[0] * 4) + q4 * 4;
+                }
+                X3_T(teb)
+            };
+            if (is_fwd) { fast(std::false_type{}); return; }
+            if (is_bwd) { fast(std::true_type{}); return; }
         }
         // act' masks of the whole tile requested up front (backward-data): one HBM round trip per tile instead of one per 16-pixel half
         // (2 MT NT of them, each waited for right after its request -- the epilogue is not overlapped with MFMAs, so that latency was
         // all exposed: the masked backward-data layers ran 5-20 % behind their forward twins)
         f32x4 mpre[NT][MT][2][2];
-        if (a.mask_mode[0] | a.mask_mode[1]) {
+        if (ea.mask_mode(0) | ea.mask_mode(1)) {
 #pragma unroll
             for (int k = 0; k < NT; ++k) {
                 const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
-                const int du = nwv >= a.n_split ? 1 : 0;
-                const int chw = nwv - (du ? a.n_split : 0);
-                const int cs2 = a.dst_cs[du];
-                if (a.mask_mode[du]) {
-                    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(a.mask[du] + (int64_t)b * a.OH * a.OW * cs2), 0,
-                                                                                         a.OH * a.OW * cs2 * 4, 0x00020000);
+                const int du = nwv >= ea.n_split ? 1 : 0;
+                const int chw = nwv - (du ? ea.n_split : 0);
+                const int cs2 = ea.dst_cs(du);
+                if (ea.mask_mode(du)) {
+                    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.mask(du) + (int64_t)b * ea.OH * ea.OW * cs2), 0,
+                                                                                         ea.OH * ea.OW * cs2 * 4, 0x00020000);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -618,9 +794,9 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                             for (int e = 0; e < 2; ++e) {
                                 const int py = y0 + wave * MT + i, px = x0 + 16 * h2 + pr + 8 * e;
-                                const bool ok2 = py < a.DH && px < a.DW && nwv + q4 < a.Ntot;
+                                const bool ok2 = py < ea.DH && px < ea.DW && nwv + q4 < ea.Ntot;
                                 mpre[k][i][h2][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                    rm, ok2 ? (unsigned)(((py * a.OW + px) * cs2 + chw + q4) * 4) : OOB, 0, 0));
+                                    rm, ok2 ? (unsigned)(((py * ea.OW + px) * cs2 + chw + q4) * 4) : OOB, 0, 0));
                             }
                 }
             }
@@ -630,23 +806,26 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int k = 0; k < NT; ++k) {
             const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
-            const bool n_ok = nwv + q4 < a.Ntot;
-            const int du = nwv >= a.n_split ? 1 : 0;
-            const int chw = nwv - (du ? a.n_split : 0);
-            const int cs2 = a.dst_cs[du], mm2 = a.mask_mode[du], acc2 = a.accum[du];
-            const int64_t imgo = (int64_t)b * a.OH * a.OW * cs2;
-            const int ibytes = a.OH * a.OW * cs2 * 4;
-            float* dstb = a.dst[du] + imgo;
+            const bool n_ok = nwv + q4 < ea.Ntot;
+            const int du = nwv >= ea.n_split ? 1 : 0;
+            const int chw = nwv - (du ? ea.n_split : 0);
+            const int cs2 = ea.dst_cs(du), mm2 = ea.mask_mode(du), acc2 = ea.accum(du);
+            const int64_t imgo = (int64_t)b * ea.OH * ea.OW * cs2;
+            const int ibytes = ea.OH * ea.OW * cs2 * 4;
+            float* dstb = ea.dst(du) + imgo;
             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc((void*)dstb, 0, ibytes, 0x00020000);
-            const bool use_add2 = a.addsrc && du == 0;
-            const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)(use_add2 ? a.addsrc + imgo : dstb), 0, ibytes, 0x00020000);
+            const bool use_add2 = ea.addsrc && du == 0;
+            const __amdgpu_buffer_rsrc_t rad = __builtin_amdgcn_make_buffer_rsrc((void*)(use_add2 ? ea.addsrc + imgo : dstb), 0, ibytes, 0x00020000);
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(a.bias + nwv + q4);
-            const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f), mslope = mm2 == 1 ? 0.2f : 0.f;
+            if (ea.bias && n_ok) bias4 = *reinterpret_cast<const f32x4*>(ea.bias + nwv + q4);
+            const float aslope = ea.act == 1 ? 0.2f : (ea.act == 2 ? 0.f : 1.f), mslope = mm2 == 1 ? 0.2f : 0.f;
+#ifdef X3_STAMPS
+            if (k == 0) X3_T(ter[0])
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const int py = y0 + wave * MT + i;
-                const bool rowok = py < a.DH;
+                const bool rowok = py < ea.DH;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     spill_half(eb, i, k, h2);
@@ -655,8 +834,8 @@ igemm_x3_kernel(const IgemmArgs a) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int p = pr + 8 * e, px = x0 + 16 * h2 + p;
-                        const bool ok2 = rowok && px < a.DW && n_ok;
-                        vo[e] = ok2 ? (unsigned)(((py * a.OW + px) * cs2 + chw + q4) * 4) : OOB;
+                        const bool ok2 = rowok && px < ea.DW && n_ok;
+                        vo[e] = ok2 ? (unsigned)(((py * ea.OW + px) * cs2 + chw + q4) * 4) : OOB;
 #ifdef X3_EPI_OOB                  // timing experiment only (wrong results): every store is dropped by the range check -- same instructions, no write traffic
                         vo[e] |= OOB;
 #endif
@@ -685,11 +864,18 @@ igemm_x3_kernel(const IgemmArgs a) {
                             for (int c = 0; c < 4; ++c) o[c] *= (m2[e][c] > 0.f) ? 1.f : mslope;
                         }
                         if (acc2) o += ad2[e];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[e], 0, 0);
+                        if constexpr (DEFER) {
+                            pend_o[(i * 2 + h2) * 2 + e] = o; pend_ok |= (vo[e] != OOB ? 1u : 0u) << ((i * 2 + h2) * 2 + e);
+                            pend_du = du; pend_c = chw; pend_lo = __umul24(pr, cs2 * 4) + q4 * 4;
+                        } else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[e], 0, 0);
                     }
+#ifdef X3_STAMPS
+                    if (k == 0) X3_T(ter[1 + i * 2 + h2])
+#endif
                 }
             }
         }
+        if constexpr (DEFER) { pend = true; pend_b = b; pend_y = y0 + wave * MT; pend_x = x0; }
         X3_T(teb)
     };
 
@@ -746,7 +932,7 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_SYNC();
             X3_T(tb)
             mfma_row(0, st, img, FillNone{}, std::true_type{}, [&](int rp) {
-                if (rp < D) dma_piece(cur, g, 1, st ^ 1, true, rp); else if (rp == D) halo_prep(n1.tile, n1.g); else halo_slot(rp - D - 1); });
+                if (rp < D) dma_piece(cur, g, 1, st ^ 1, true, rp); else if (rp == D) halo_prep(n1.tile, n1.g); else halo_slot(rp - D - 1); }, nohook);
             X3_T(tm)
             // ---- filter row 1
             if constexpr (decltype(f1)::value) __builtin_amdgcn_s_waitcnt(0x0f70);
@@ -754,14 +940,14 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_T(tw)
             X3_SYNC();
             X3_T(tb)
-            mfma_row(1, st ^ 1, img, f1, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, st, true, rp); });
+            mfma_row(1, st ^ 1, img, f1, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, st, true, rp); }, nohook);
             X3_T(tm1)
             // ---- filter row 2
             __builtin_amdgcn_s_waitcnt(0x0f70);                         // [halo loads][weights of row 2]: wait for all
             X3_T(tw)
             X3_SYNC();
             X3_T(tb)
-            mfma_row(2, st, img, f2, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); });
+            mfma_row(2, st, img, f2, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); }, nohook);
             X3_T(tm2)
             if (g == nchunks - 1) {
                 __syncthreads();                                        // every wave has finished reading stage st: it holds the epilogue patches now
@@ -799,28 +985,49 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_T(tw)
             __syncthreads();
             X3_T(tb)
-            mfma_row(0, 0, img, FillNone{}, std::false_type{}, [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); });
-            // ---- row 1: outstanding [w row 1][halo next][w row 2]
-            X3_T(tm)
-            __builtin_amdgcn_s_waitcnt(0x0f70 | (HL + D));
-            X3_T(tw)
-            __syncthreads();
-            X3_T(tb)
-            mfma_row(1, 1, img, FillNone{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); });
-            // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
-            X3_T(tm1)
-            __builtin_amdgcn_s_waitcnt(0x0f70 | D);
-            X3_T(tw)
-            __syncthreads();
+            auto req0 = [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); };
+            auto req1 = [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); };
+            if (DEFER && pend) {
+                // The previous tile's stores ride in this chunk's rows 0 (six) and 1 (two).  Waits and barriers stand INSIDE this path: the
+                // compiler waits for every LDS-DMA issued before a barrier and can count the younger operations (here: the stores) only on
+                // straight-line code -- behind a merge with the store-free path it would fall back to vmcnt(0), i.e. wait for the stores.
+                const __amdgpu_buffer_rsrc_t prd = pend_rsrc();
+                mfma_row(0, 0, img, FillNone{}, std::false_type{}, req0, store_hook(std::integral_constant<int, 0>{}, prd));
+                X3_T(tm)
+                __builtin_amdgcn_s_waitcnt(0x0f70 | ((HL + D + 6) & 15) | (((HL + D + 6) >> 4) << 14));      // [w row 1][halo next][w row 2][6 stores]
+                X3_T(tw)
+                __syncthreads();
+                X3_T(tb)
+                mfma_row(1, 1, img, FillNone{}, std::false_type{}, req1, store_hook(std::integral_constant<int, 1>{}, prd));
+                X3_T(tm1)
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (D + NST - 6));                                          // ... [w next row 0][2 stores]
+                X3_T(tw)
+                __syncthreads();
+                pend = false; pend_ok = 0;
+            } else {
+                mfma_row(0, 0, img, FillNone{}, std::false_type{}, req0, nohook);
+                // ---- row 1: outstanding [w row 1][halo next][w row 2]
+                X3_T(tm)
+                __builtin_amdgcn_s_waitcnt(0x0f70 | (HL + D));
+                X3_T(tw)
+                __syncthreads();
+                X3_T(tb)
+                mfma_row(1, 1, img, FillNone{}, std::false_type{}, req1, nohook);
+                // ---- row 2: outstanding [halo next][w row 2][w next row 0]: the halo registers and row 2's weights
+                X3_T(tm1)
+                __builtin_amdgcn_s_waitcnt(0x0f70 | D);
+                X3_T(tw)
+                __syncthreads();
+            }
             X3_T(tb)
 #if X3_M16
             // the halo of the chunk after next: its requests ride in this row's gaps as the staging frees the registers (LATE, see mfma_row);
             // same issue order as a lump behind the row -- [weights of the next row 1][halo] -- so the vmcnt counts above hold
             mfma_row(2, 2, img, FillAll{}, std::integral_constant<int, 2>{}, [&](int rp) {
-                if (rp < D) dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); else if (rp == D) halo_prep(n2.tile, n2.g); else halo_slot(rp - D - 1); });
+                if (rp < D) dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); else if (rp == D) halo_prep(n2.tile, n2.g); else halo_slot(rp - D - 1); }, nohook);
             halo_slot(2);
 #else
-            mfma_row(2, 2, img, FillAll{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); });
+            mfma_row(2, 2, img, FillAll{}, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 1, 1, n1.ok, rp); }, nohook);
             load_halo(n2.tile, n2.g);
 #endif
             X3_T(tm2)
@@ -828,6 +1035,11 @@ igemm_x3_kernel(const IgemmArgs a) {
             if (!n1.ok) break;
             if (g == nchunks - 1) next_tile(); else ++g;
             img ^= 1;
+        }
+        if (DEFER && pend) {                                            // the last tile's stores
+            const __amdgpu_buffer_rsrc_t prd = pend_rsrc();
+#pragma unroll
+            for (int i = 0; i < NST; ++i) pend_store(i, prd);
         }
 #ifdef X3_STAMPS
         X3_T(te)

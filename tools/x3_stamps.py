@@ -11,8 +11,8 @@ jobs = ops.PackJobs(); jobs.add_x3(w, wx, None, cin_pad=(Ci + 15) // 16 * 16); j
 y = torch.empty(B, S, S, Co, device='cuda')
 for _ in range(3): ops.conv_x3_fwd(x, None, wx, b, y, Co, 1)
 torch.cuda.synchronize()
-d = y.reshape(-1)[:256 * 8 * 16].reshape(256, 8, 16)[:, :, :9].cpu()
-names = ['wait', 'barrier', 'row0', 'top', 'total', 'row1', 'row2', 'epiA', 'epiB']
+d = y.reshape(-1)[:256 * 8 * 16].reshape(256, 8, 16)[:, :, :14].cpu()
+names = ['wait', 'barrier', 'row0', 'top', 'total', 'row1', 'row2', 'epiA', 'epiB', 'e_setup', 'e_r0', 'e_r1', 'e_r2', 'e_r3']
 for wv in (0, 4, 1, 5, 2, 6, 3, 7):
     m = d[:, wv].mean(0)
     print('wave', wv, ' '.join(f'{n}={float(v):.0f}' for n, v in zip(names, m)))
