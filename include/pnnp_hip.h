@@ -341,6 +341,10 @@ int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* s
                               int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream);
 int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale /*[B] or null*/, float* grad_nhwc,
                                   float* loss_out, int B, int C, int H, int W, int Cp, float* workspace, void* stream);
+/* pnnp_l1_clamp_loss_tc_f32 with dL/dpred multiplied by grad_weight: the weight B_local world / B_global of a rank's mean gradient when one
+ * global batch is split unevenly over the data-parallel ranks (base_trainer.py:115-118 scatters the batch the same way); loss and SSE unweighted. */
+int pnnp_l1_clamp_loss_w_f32(const float* pred, const float* hr, const float* scale /*[B] or null*/, float* grad_nhwc, float* loss_out,
+                             int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, float grad_weight, void* stream);
 /* torch.optim.Adam step (trainer_SID.py:44,101) over a flat parameter buffer; step is 1-based;
  * grad_scale is applied to g first (1/world_size after a sum all-reduce). */
 int pnnp_adam_step_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
@@ -440,6 +444,11 @@ int pnnp_crop_aug_f32(const float* img /* [C][h][w] */, int C, int h, int w, flo
  * quality_assess(tensor2im(.), tensor2im(.), data_range=255) (utils/visualization.py:9-31). */
 int pnnp_illuminance_correct_f32(const float* pred, const float* src, float* out, int64_t n,
                                  double* workspace /* >= 512 doubles */, void* stream);
+/* The elementwise tail of one eval iteration in one pass (trainer_SID.py:226-235: crop the reflect-padded output back, the input residual
+ * of a `res` network, `ori`: x ratio, both frames clamped to [0,1]): dn = clamp((net_out[crop] (+ lr_in)) * ratio, 0, 1),
+ * lr_out (or null) = clamp(lr_in * ratio, 0, 1).  net_out [C][HP][WP] holds the frame at (pad, pad); the others are [C][H][W]. */
+int pnnp_eval_post_f32(const float* net_out, const float* lr_in, float* dn, float* lr_out /*or null*/, int C, int H, int W, int HP, int WP,
+                       int pad, float ratio, const float* ratio_dev /*device scalar overriding ratio, or null*/, int add_residual, void* stream);
 int pnnp_psnr_ssim_f32(const float* a, const float* b, float* out2 /* {psnr, ssim} */, int C, int H, int W,
                        double* workspace /* >= 2*C*ceil(H/32)*ceil(W/32) doubles */, void* stream);
 

@@ -172,16 +172,18 @@ class ResUnetEngine(_EngineBase):
         return ops.conv_bwd_data(gsrc, self.W[name][1], dx1, **kw)
 
     # ---------------------------------------------------------------- forward
-    def forward(self, x, train, reflect_pad=0):
+    def forward(self, x, train, reflect_pad=0, add_residual=True):
         """``reflect_pad`` > 0 (eval loop, trainer_SID.py:221-226): the network runs on the frame reflect-padded by that many pixels on
-        every side -- the padding happens inside the NCHW -> NHWC layout pass, the result has the PADDED size (the caller crops)."""
+        every side -- the padding happens inside the NCHW -> NHWC layout pass, the result has the PADDED size (the caller crops).
+        ``add_residual=False``: a `res` network returns f(x) without `+ x` (the caller adds the un-padded input after cropping:
+        (f(pad x) + pad x)[crop] = f(pad x)[crop] + x; pnnp_eval_post_f32)."""
         if not x.is_cuda:
             raise PnnpError('ResUnet.forward: input must be a CUDA tensor (pnnp_amd has no CPU path)')
         x = x.contiguous().float()
         B, Cin, H, Wd = x.shape
         if reflect_pad:
-            if self.m.res or train:
-                raise PnnpError('reflect_pad is an eval-mode option of networks without the input residual')
+            if train or (self.m.res and add_residual):
+                raise PnnpError('reflect_pad is an eval-mode option; a `res` network needs add_residual=False (the caller adds the input after cropping)')
             H, Wd = H + 2 * reflect_pad, Wd + 2 * reflect_pad
         if Cin != self.cin or H % 16 or Wd % 16:
             raise PnnpError(f'input must be [B,{self.cin},H,W] with H,W multiples of 16, got {tuple(x.shape)}')
@@ -239,10 +241,10 @@ class ResUnetEngine(_EngineBase):
             cur = a[f'c{i}']
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
         if self._pol.use_thin_head(ch[0], self.cout, B * H * Wd):
-            ops.head_fwd(a['c9'], P['conv10.weight'], P['conv10.bias'], out, residual=x if self.m.res else None)
+            ops.head_fwd(a['c9'], P['conv10.weight'], P['conv10.bias'], out, residual=x if (self.m.res and add_residual) else None)
         else:
             o = ops.conv_fwd(a['c9'], None, W['conv10'][0], P['conv10.bias'], g('o', (B, H, Wd, self.cout)), self.cout, 1, 0)
-            ops.nhwc_to_nchw(o, out, residual=x if self.m.res else None)
+            ops.nhwc_to_nchw(o, out, residual=x if (self.m.res and add_residual) else None)
         if train:
             a['_pol'] = self._pol
             self.saved = (a, (B, H, Wd, dev), gen)

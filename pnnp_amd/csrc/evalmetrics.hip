@@ -42,6 +42,24 @@ illum_apply_kernel(const float* __restrict__ pred, float* __restrict__ out, cons
         out[i] = scale * fminf(fmaxf(pred[i], 0.f), 1.f);
 }
 
+// The elementwise tail of the eval iteration in ONE pass (trainer_SID.py:226-235): crop the padded network output back, add the input
+// residual of a `res` network (left out of the padded forward: (f(pad x) + pad x)[crop] = f(pad x)[crop] + x), `ori`: x ratio on both
+// frames, clamp both to [0, 1].  Plane c of the network output is [HP][WP], the frame sits at (pad, pad).
+__global__ void __launch_bounds__(256)
+eval_post_kernel(const float* __restrict__ net_out, const float* __restrict__ lr_in, float* __restrict__ dn, float* __restrict__ lr_out,
+                 int C, int H, int W, int HP, int WP, int pad, float ratio_host, const float* __restrict__ ratio_dev, int add_residual) {
+    const int64_t n = (int64_t)C * H * W;
+    const float ratio = ratio_dev ? ratio_dev[0] : ratio_host;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W); const int64_t q = i / W; const int y = (int)(q % H), c = (int)(q / H);
+        const float l = lr_in[i];
+        float d = net_out[((int64_t)c * HP + y + pad) * WP + x + pad];
+        if (add_residual) d += l;
+        dn[i] = fminf(fmaxf(d * ratio, 0.f), 1.f);              // (imgs_dn * ratio).clamp(0, 1): one rounding for the product, like the tensor op
+        if (lr_out) lr_out[i] = fminf(fmaxf(l * ratio, 0.f), 1.f);
+    }
+}
+
 // One 32x32 tile of one channel: squared error over the tile and SSIM map over the window-valid pixels.  The 7x7 window sums
 // of x, y, x^2, y^2, xy are separable: 7-tap row sums of the 38x38 halo tile into LDS (5 x 38 x 32), then 7-tap column sums
 // per pixel -- 14 + 35 LDS reads per pixel instead of 98, 77 additions instead of 245.
@@ -155,6 +173,18 @@ int pnnp_psnr_ssim_f32(const float* a, const float* b, float* out, int C, int H,
     const float c1 = (0.01f * 255.f) * (0.01f * 255.f), c2 = (0.03f * 255.f) * (0.03f * 255.f);
     hipLaunchKernelGGL(psnr_ssim_partial_kernel, grid, dim3(256), 0, as_stream(stream), a, b, workspace, H, W, c1, c2);
     hipLaunchKernelGGL(psnr_ssim_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), workspace, out, (int)(grid.x * grid.y), C, H, W);
+    return pnnp_launch_status();
+}
+
+// dn = clamp((net_out[crop] (+ lr_in)) * ratio, 0, 1), lr_out (or null) = clamp(lr_in * ratio, 0, 1): the elementwise tail of one eval
+// iteration (trainer_SID.py:226-235).  net_out: [C][HP][WP] with the frame at (pad, pad) (pad = 0, HP = H, WP = W: no crop);
+// lr_in, dn, lr_out: [C][H][W].  ratio_dev (device scalar) overrides ratio when not null.  NaN stays NaN (fminf / fmaxf order as torch.clamp).
+int pnnp_eval_post_f32(const float* net_out, const float* lr_in, float* dn, float* lr_out, int C, int H, int W, int HP, int WP, int pad,
+                       float ratio, const float* ratio_dev, int add_residual, void* stream) {
+    if (!net_out || !lr_in || !dn || C <= 0 || H <= 0 || W <= 0 || pad < 0 || HP < H + 2 * pad || WP < W + 2 * pad) return PNNP_E_INVALID;
+    const int64_t n = (int64_t)C * H * W;
+    hipLaunchKernelGGL(eval_post_kernel, dim3((unsigned)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256)), dim3(256), 0, as_stream(stream),
+                       net_out, lr_in, dn, lr_out, C, H, W, HP, WP, pad, ratio, ratio_dev, add_residual);
     return pnnp_launch_status();
 }
 

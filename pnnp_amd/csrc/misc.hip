@@ -251,10 +251,10 @@ rows_sum_kernel(const float* __restrict__ partial, float* __restrict__ out, int 
 __global__ void __launch_bounds__(256)
 l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, const float* __restrict__ scale,
                 float* __restrict__ grad_nhwc, float* __restrict__ partial, int C, int64_t hw, int Cp, float inv_n, int blocks_per_crop,
-                int clamp_target) {
+                int clamp_target, float grad_weight) {
     const int b = blockIdx.x / blocks_per_crop, blk = blockIdx.x % blocks_per_crop;
     const float sc = scale ? scale[b] : 1.f;            // `ori`: pred * ratio before the loss (trainer_SID.py:97-98)
-    const float gsc = inv_n * sc;
+    const float gsc = inv_n * sc * grad_weight;     // grad_weight: this rank's share of a global batch (uneven data-parallel shards), 1 otherwise
     float l1 = 0.f, sse = 0.f;
     for (int64_t s = (int64_t)blk * 256 + threadIdx.x; s < hw; s += (int64_t)blocks_per_crop * 256) {
         float g[8];
@@ -402,8 +402,8 @@ int pnnp_channel_sum_f32(const float* x, float* out, int64_t npix, int C, int ac
 // loss_out[0] = mean |clamp(pred,0,1) - hr| (trainer_SID.py:99); loss_out[1+b] = sum_b (clamp(pred)-clamp(hr))^2
 // (PSNR_b = -10 log10(SSE_b / (C*H*W)), losses/__init__.py:4-15).  grad_nhwc (optional): dL/dpred laid out
 // [B][H][W][Cp] for the backward pass.  workspace >= 2 * B * 64 floats.
-int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
-                              int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream);
+int pnnp_l1_clamp_loss_w_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
+                             int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, float grad_weight, void* stream);
 
 int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
                                   int B, int C, int H, int W, int Cp, float* workspace, void* stream) {
@@ -412,15 +412,20 @@ int pnnp_l1_clamp_loss_scaled_f32(const float* pred, const float* hr, const floa
 
 // the same with the target clamped to [0,1] inside the kernel (the trainer's `imgs_hr.clamp(0, 1)` of preprocess, trainer_SID.py:485,
 // without a separate elementwise pass over the clean crops)
-// the same with the target clamped to [0,1] inside the kernel (the trainer's `imgs_hr.clamp(0, 1)` of preprocess, trainer_SID.py:485,
-// without a separate elementwise pass over the clean crops)
 int pnnp_l1_clamp_loss_tc_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
                               int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, void* stream) {
+    return pnnp_l1_clamp_loss_w_f32(pred, hr, scale, grad_nhwc, loss_out, B, C, H, W, Cp, workspace, clamp_target, 1.0f, stream);
+}
+
+// ... and dL/dpred multiplied by grad_weight (a rank's mean-gradient weight B_local world / B_global when a global batch is split
+// unevenly over data-parallel ranks; the loss and the SSE are not weighted): no elementwise pass over the gradient map
+int pnnp_l1_clamp_loss_w_f32(const float* pred, const float* hr, const float* scale, float* grad_nhwc, float* loss_out,
+                             int B, int C, int H, int W, int Cp, float* workspace, int clamp_target, float grad_weight, void* stream) {
     if (!pred || !hr || !loss_out || !workspace || B <= 0 || C <= 0 || C > 8 || (grad_nhwc && (Cp < C || (Cp != 4 && Cp != 8)))) return PNNP_E_INVALID;
     const int bpc = 64;
     const float inv_n = 1.0f / ((float)B * C * H * W);
     hipLaunchKernelGGL(l1_clamp_kernel, dim3(B * bpc), dim3(256), 0, as_stream(stream), pred, hr, scale, grad_nhwc, workspace, C,
-                       (int64_t)H * W, Cp, inv_n, bpc, clamp_target);
+                       (int64_t)H * W, Cp, inv_n, bpc, clamp_target, grad_weight);
     hipLaunchKernelGGL(l1_finish_kernel, dim3(1), dim3(64), 0, as_stream(stream), workspace, loss_out, B, bpc, inv_n);
     return pnnp_launch_status();
 }

@@ -13,9 +13,12 @@ denoised frame, or (psnr_dn, ssim_dn) when plots are on) and the log line (:309-
 checkpoint selection stay outside (out of scope).  The IMX686 frame 4x1736x2312 takes the padded branch
 (2312 % 16 = 8 -> 4x1744x2320).
 """
+import ctypes as C
+
 import torch
 import torch.nn.functional as F
 
+from . import _lib
 from ._lib import PnnpError
 from .metrics import IlluminanceCorrect, quality_assess
 
@@ -30,24 +33,29 @@ def evaluate(net, imgs_lr, imgs_hr, ratio=None, ori=False, brightness_correct=Tr
     if imgs_lr.dim() != 4 or imgs_lr.shape[0] != 1:
         raise PnnpError('evaluate expects one frame per call: [1,C,H,W] (DataLoader batch_size 1, trainer_SID.py:52)')
     with torch.no_grad():
-        if imgs_lr.shape[-1] % 16 != 0:                       # :221 -- the reference tests the width only
-            eng = getattr(net, 'engine', None)
-            if eng is not None and hasattr(eng, 'forward') and not getattr(net, 'res', False):
-                # the reflection is folded into the layout pass the input goes through anyway (no F.pad kernel, no padded copy)
-                dn = eng.forward(imgs_lr, False, reflect_pad=4)[..., 4:-4, 4:-4]
-            else:
-                dn = net(F.pad(imgs_lr, (4, 4, 4, 4), mode='reflect'))[..., 4:-4, 4:-4]
+        lr_in = imgs_lr.contiguous().float()
+        _, Cc, H, W = lr_in.shape
+        pad = 4 if W % 16 != 0 else 0                         # :221 -- the reference tests the width only
+        eng = getattr(net, 'engine', None)
+        res = bool(getattr(net, 'res', False))
+        if eng is not None and hasattr(eng, 'forward'):
+            # the reflection is folded into the layout pass the input goes through anyway (no F.pad kernel, no padded copy); a `res` network
+            # runs without its input residual, which the tail kernel adds after the crop
+            out = eng.forward(lr_in, False, reflect_pad=pad, add_residual=not res)
+            add_res = res
         else:
-            dn = net(imgs_lr)
-        lr = imgs_lr
-        if ori:
-            if ratio is None:
-                raise PnnpError('ori=True needs the ratio (trainer_SID.py:231-233)')
-            r = torch.as_tensor(ratio, dtype=torch.float32, device=dn.device).reshape(-1, 1, 1, 1)
-            lr = lr * r
-            dn = dn * r
-        lr = lr.clamp(0, 1)
-        dn = dn.clamp(0, 1)
+            out = net(F.pad(lr_in, (4, 4, 4, 4), mode='reflect')) if pad else net(lr_in)
+            add_res = False
+        if ori and ratio is None:
+            raise PnnpError('ori=True needs the ratio (trainer_SID.py:231-233)')
+        # (one frame per call: one scalar; a device tensor stays on the device -- nothing here synchronises)
+        r_dev = ratio.reshape(-1)[:1].float().contiguous() if (ori and torch.is_tensor(ratio) and ratio.is_cuda) else None
+        r = 1.0 if (not ori or r_dev is not None) else float(torch.as_tensor(ratio).reshape(-1)[0])
+        # crop, residual, x ratio and both clamps (:226-235) in one pass
+        out = out.contiguous()
+        dn = torch.empty_like(lr_in); lr = torch.empty_like(lr_in)
+        _lib.check(_lib.lib().pnnp_eval_post_f32(_lib.ptr(out), _lib.ptr(lr_in), _lib.ptr(dn), _lib.ptr(lr), Cc, H, W, out.shape[-2], out.shape[-1], pad,
+                                                 C.c_float(r), _lib.ptr(r_dev), int(add_res), _lib.stream()), 'eval_post')
         if brightness_correct and epoch < 0:
             dn = (corrector or IlluminanceCorrect())(dn.contiguous(), imgs_hr)
         m_dn = quality_assess(dn, imgs_hr)

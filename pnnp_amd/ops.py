@@ -556,14 +556,15 @@ def channel_sum(x, out, ws, accumulate=0):
     check(_prep().pnnp_channel_sum_f32(ptr(x), ptr(out), _i64(x.numel() // Cc), Cc, accumulate, ptr(ws), stream()), 'channel_sum')
 
 
-def l1_clamp_loss(pred, hr, grad_nhwc, loss_out, ws, scale=None, clamp_target=False):
+def l1_clamp_loss(pred, hr, grad_nhwc, loss_out, ws, scale=None, clamp_target=False, grad_weight=1.0):
     """``scale`` [B] (or None): the `ori` branch of the train loop, pred * ratio before the loss (trainer_SID.py:97-99).
-    ``clamp_target``: clamp ``hr`` to [0,1] inside the kernel (preprocess's imgs_hr.clamp(0,1) under dst.clip, trainer_SID.py:485)."""
+    ``clamp_target``: clamp ``hr`` to [0,1] inside the kernel (preprocess's imgs_hr.clamp(0,1) under dst.clip, trainer_SID.py:485).
+    ``grad_weight`` multiplies dL/dpred only (uneven data-parallel shards of a global batch)."""
     require_cuda(pred, hr, loss_out, ws, scale)
     B, Cc, H, W = pred.shape
     cp = grad_nhwc.shape[3] if grad_nhwc is not None else 0
-    check(_prep().pnnp_l1_clamp_loss_tc_f32(ptr(pred), ptr(hr), ptr(scale), ptr(grad_nhwc), ptr(loss_out), B, Cc, H, W, cp, ptr(ws),
-                                            int(bool(clamp_target)), stream()), 'l1_clamp_loss')
+    check(_prep().pnnp_l1_clamp_loss_w_f32(ptr(pred), ptr(hr), ptr(scale), ptr(grad_nhwc), ptr(loss_out), B, Cc, H, W, cp, ptr(ws),
+                                           int(bool(clamp_target)), C.c_float(grad_weight), stream()), 'l1_clamp_loss')
 
 
 def adam_step(p, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):

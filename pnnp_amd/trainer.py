@@ -314,10 +314,9 @@ class HipTrainStep:
         g8 = bufs.get('g_out8', (B, H, W, e.cout_pad), dev)
         loss = bufs.get('loss_out', (1 + B,), dev)
         lws = bufs.get('loss_ws', (128 * B,), dev)
-        ops.l1_clamp_loss(pred, hr, g8, loss, lws, scale=scale, clamp_target=bool(self.clip))      # trainer_SID.py:485: the target is clamped under dst.clip, in the kernel
-        weight = self.shard(B)[1]
-        if weight != 1.0:                                    # uneven shards of a global batch: this rank's mean counts B_local / B_global
-            g8.mul_(weight)
+        # trainer_SID.py:485: the target is clamped under dst.clip, in the kernel; uneven shards of a global batch: this rank's mean
+        # gradient counts B_local / B_global (x world: Adam divides the all-reduced sum by world) -- folded into the kernel's gradient scale
+        ops.l1_clamp_loss(pred, hr, g8, loss, lws, scale=scale, clamp_target=bool(self.clip), grad_weight=self.shard(B)[1])
         if self.reducer is not None:
             self.reducer.reset()
         e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)

@@ -84,3 +84,26 @@ def test_evaluate_product_function_on_the_imx686_frame_vs_cpu_oracle():
     assert re.fullmatch(r'ssims_lr=\d\.\d{4}, ssims_dn=\d\.\d{4}', lines[2])
     nums = [float(v) for v in re.findall(r'=(-?\d+\.\d+)', text)]
     assert np.allclose(nums, [ref[0], ref[2], ref[0], ref[3], ref[1]], atol=6e-3)
+
+
+@pytest.mark.parametrize('res', [False, True])
+def test_eval_tail_kernel_equals_the_tensor_ops_bit_for_bit(res):
+    """`evaluate` crops the reflect-padded output, adds the input residual of a `res` network, multiplies by the ratio (`ori`) and
+    clamps both frames in ONE kernel (pnnp_eval_post_f32): against the reference's sequence of tensor ops (trainer_SID.py:226-235)
+    on the same network output the result must be identical, with a host ratio and with a device ratio (no synchronisation)."""
+    import torch.nn.functional as F
+    from pnnp_amd.archs import UNetSeeInDark, initialize_weights
+    from pnnp_amd.evaluate import evaluate
+    torch.manual_seed(4)
+    net = UNetSeeInDark(dict(nframes=1, res=res, nf=8, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda().eval()
+    g = torch.Generator(device='cuda').manual_seed(5)
+    hr = torch.rand(1, 4, 48, 72, device='cuda', generator=g)                      # 72 % 16 = 8: the padded branch
+    lr = hr / 5.0 + torch.randn(1, 4, 48, 72, device='cuda', generator=g) * 0.02
+    with torch.no_grad():
+        ref_dn = net(F.pad(lr, (4, 4, 4, 4), mode='reflect'))[..., 4:-4, 4:-4]          # the module's own forward (residual inside)
+        ref_dn = (ref_dn * 5.0).clamp(0, 1); ref_lr = (lr * 5.0).clamp(0, 1)
+    for ratio in (5.0, torch.tensor([5.0], device='cuda')):
+        out = evaluate(net, lr, hr, ratio=ratio, ori=True, brightness_correct=False)
+        # (a `res` network: f(pad x)[crop] + x here, (f(pad x) + pad x)[crop] in the module -- the same float32 sum)
+        assert torch.equal(out['lr'], ref_lr)
+        assert torch.equal(out['dn'], ref_dn), float((out['dn'] - ref_dn).abs().max())
