@@ -35,6 +35,13 @@ int pnnp_version(void);
 const char* pnnp_error_string(int code);
 /* Number of compute units etc. of the current device (0 on failure). */
 int pnnp_device_cus(void);
+/* Workgroups per CU of the persistent forward / backward-data convolution kernels (default 1: one per CU with an equal static share of
+ * the tiles).  n > 1 launches n per CU with 1/n share each; the surplus waits in the hardware dispatcher and goes to whichever CU frees up
+ * first, so a kernel resident on some CUs beside the convolution (an RCCL collective overlapping the backward pass: replaces what
+ * nn.DataParallel's reduce did behind autograd, base_trainer.py:115-118) stretches a layer by ~CUs / (CUs - k) instead of doubling it.
+ * Process-wide setting, 1 <= n <= 16; the only state the library keeps. */
+void pnnp_set_persistent_split(int n);
+int pnnp_get_persistent_split(void);
 
 /* ---------------------------------------------------------------- Bayer pack / unpack
  * raw2bayer  utils/isp_ops.py:84-96     u16|f32 [B][H][W] -> f32 [B][4][H/2][W/2]

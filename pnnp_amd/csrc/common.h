@@ -48,3 +48,13 @@ static inline int pnnp_allow_lds(PnnpPerDevice& once, K kern, int bytes) {
     });
     return ok > 0 ? PNNP_OK : PNNP_E_LAUNCH;
 }
+
+// grid of a persistent kernel with `tiles` work items: pnnp_get_persistent_split() workgroups per CU (csrc/capi.hip), at most one per tile
+extern "C" int pnnp_get_persistent_split(void);
+extern "C" int pnnp_device_cus(void);
+static inline int pnnp_persistent_grid(int64_t tiles) {
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int64_t wgs = (int64_t)cus * pnnp_get_persistent_split();
+    return (int)(wgs < tiles ? wgs : tiles);
+}

@@ -1054,13 +1054,10 @@ int launch_x3(const IgemmArgs& a, hipStream_t s) {
     auto kern = igemm_x3_kernel<BN, POOL>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
-    const int per_cu = 1;                                           // ~150 KB of LDS: one 8-wave workgroup per CU
-    int cus = pnnp_device_cus();
-    if (cus < 1) cus = 256;
+    // ~150 KB of LDS: one 8-wave workgroup per CU resident; pnnp_set_persistent_split(n) launches n per CU with 1/n share each
     const int tiles = ((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + BN - 1) / BN);
     if (tiles <= 0) return PNNP_OK;
-    int wgs = per_cu * cus;
-    if (wgs > tiles) wgs = tiles;
+    const int wgs = pnnp_persistent_grid(tiles);
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();
 }

@@ -386,11 +386,9 @@ int launch_gx(const IgemmArgs& a, hipStream_t s) {
     auto kern = gemm_x3_kernel<NT>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
-    int cus = pnnp_device_cus();
-    if (cus < 1) cus = 256;
     const int tiles = ((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + Cfg::BN - 1) / Cfg::BN);
     if (tiles <= 0) return PNNP_OK;
-    const int wgs = cus < tiles ? cus : tiles;
+    const int wgs = pnnp_persistent_grid(tiles);                     // one workgroup per CU, or n of 1/n share (pnnp_set_persistent_split)
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), Cfg::LDS_BYTES, s, a);
     return pnnp_launch_status();
 }

@@ -378,6 +378,20 @@ def convt_bwd_data(g, w_dgrad, dx, mask=None, mode=0):
                                                  stream()), 'convt_bwd_data')
 
 
+def set_persistent_split(n):
+    """Workgroups per CU of the persistent forward / backward-data convolution kernels (include/pnnp_hip.h: pnnp_set_persistent_split):
+    1 = one per CU with a static share (default, fastest alone), 4 = quarter shares handed out by the dispatcher (safe beside a
+    collective kernel that occupies CUs: tests/test_gpu_overlap.py)."""
+    L = _prep()
+    L.pnnp_set_persistent_split.argtypes = [C.c_int]
+    L.pnnp_set_persistent_split.restype = None
+    L.pnnp_set_persistent_split(int(n))
+
+
+def get_persistent_split():
+    return int(_prep().pnnp_get_persistent_split())
+
+
 X3G_PW, X3G_CT, X3G_S2 = 0, 1, 2        # geometry kinds of csrc/wgrad_x3g.hip: Conv2d 1x1, ConvTranspose2d 2x2 s2, Conv2d 3x3 s2
 
 

@@ -46,7 +46,12 @@ class BucketedAllReduce:
     whole share after the others have finished: the layer takes up to twice as long.  With the gradient traffic this small (31 MB:
     ~0.4-0.5 ms of ring time against a ~23 ms step, i.e. 2 %) hiding it is worth less than that risk, so by default the all-reduce is
     ONE collective over the whole flat buffer, issued when the backward pass has finished; ``overlap=True`` launches the buckets
-    from the backward pass as described above (bench.py --overlap-allreduce; measure before relying on it)."""
+    from the backward pass as described above (bench.py --overlap-allreduce; measure before relying on it).  Round 4 removed the
+    hazard itself for the forward / backward-data kernels: with ``ops.set_persistent_split(4)`` (HipTrainStep does it when
+    ``overlap_allreduce`` is on) they launch quarter shares that the hardware dispatcher hands to whichever CU is free -- measured with a
+    kernel squatting on 8 / 32 / 64 CUs beside conv2_2: x 1.05 / 1.04 / 1.21 instead of x 1.45 (tests/test_gpu_overlap.py,
+    tools/squat_test.py); alone on the chip the split costs 6-14 % of a layer, hence not the default.  The backward-weight kernels keep
+    their static pixel splits (their summation order is part of the bit-reproducibility contract)."""
 
     def __init__(self, flat, bucket_bytes=8 << 20, group=None, force=False, overlap=False):
         import torch.distributed as dist
@@ -162,6 +167,10 @@ class HipTrainStep:
         all-reduced sum is the mean over the global batch."""
         self.global_batch = global_batch
         self.overlap_allreduce = overlap_allreduce      # BucketedAllReduce(overlap=): buckets from inside the backward pass (see its docstring)
+        if overlap_allreduce and (world > 1 or force_reducer):
+            # collectives will be resident on some CUs while convolution grids are dispatched: quarter shares handed out by the hardware
+            # dispatcher instead of one static share per CU (tests/test_gpu_overlap.py: x 1.05 instead of x 1.45 beside a kernel on 32 CUs)
+            ops.set_persistent_split(4)
         self.proxy_check_every = 50          # steps between reads of the NoiseFlow proxy's `scale >= 0` flag (a host sync each)
         self.net = net
         self.engine = net.engine
