@@ -19,6 +19,7 @@
 // split and written to the OTHER image between the MFMAs of the late part of tile i+1; one barrier per tile.
 // Partial results go to per-workgroup slabs that a second kernel sums in a fixed order (deterministic, no float atomics).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -41,6 +42,11 @@ struct Wx3Args {
 
 constexpr int NTHR = 512, NWAVE = 8;
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {                  // f(integral_constant<int, I>) ... for I .. N - 1: every index a constant
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
 // Alternating signs over the pixel splits.  What was measured (tools/ubench/mfma_round.hip -> profiles/r3/mfma_round.txt, one MFMA with
 // C = +-2^24, ulp 2; tools/x3_bias_probe.py -> profiles/r3/x3_bias_probe.txt), per instruction shape and operand case:
 //   * equal small products (v_mfma_f32_32x32x16_bf16: 16 x v/16; v_mfma_f32_16x16x32_bf16: 32 x v/32): every PRODUCT is first rounded
@@ -61,6 +67,14 @@ constexpr int NTHR = 512, NWAVE = 8;
 #ifndef WX3_ALT_SIGN
 #define WX3_ALT_SIGN 1
 #endif
+#ifndef WX3_M16
+// Experiment of round 4, parity-green but 15-40 % SLOWER than the 32 x 32 x 16 path, so off: the 16 x 16 x 32
+// shape needs twice the transposed reads (116 instead of 60 per k-step) and the 64 x 64 configuration has no registers for a deeper
+// operand prefetch (256 with 16 spilled; B operands one 6-MFMA step = 96 cycles ahead): PMC on conv2_2 / conv4_2 -- matrix pipe busy
+// 0.70 -> 0.42-0.50, SQ_WAIT_ANY 0.28 -> 0.43-0.52 of the wave cycles (waves parked on LDS latency), LDS bank conflicts 13 % of the active
+// cycles (two-way on the staging writes of the split-half layout), LDS active 0.27 -> 0.32-0.37 (profiles/r4/wgrad_m16.txt).
+#define WX3_M16 0
+#endif
 
 template <int WM, int WN, int TH>
 struct Wx3Cfg {
@@ -76,6 +90,14 @@ struct Wx3Cfg {
     // the 32 x 32 output tile (one k-step of 9 groups per tile, six staging slices) measured 5 % faster with its staging slices as lumps
     // behind the MFMA groups than with everything placed between the individual MFMAs; the larger tiles 4-8 % slower
     static constexpr bool LUMPS = WM * WN == 1;
+    // v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (the trick of csrc/conv_x3.hip, X3_M16): the same multiply-adds per
+    // cycle at less energy per FLOP, and the chip is power-limited in these loops (round 4: a kernel squatting on 32 of the 256 CUs costs a
+    // convolution layer nothing -- the other 224 clock higher).  K = 32 of one instruction = 16 pixels of piece X ++ the same 16 pixels of
+    // piece Y; a 32 x 32 block is four 16 x 16 blocks x three instructions.  The LDS images then keep the two 16-channel halves of a
+    // 32-channel block in SEPARATE planes, [block][piece][half][pixel][32 B]: one ds_read_b64_tr_b16 instruction covers, in each 32-lane
+    // half, 8 consecutive pixel rows of ONE 16-channel half -- 256 contiguous bytes, conflict-free (on 64-byte rows, pixel rows 4 apart
+    // share their banks) -- by giving k-block (lane >> 4) & 1 the pixels {0-3, 8-11} or {4-7, 12-15} of the k-step (A and B agree on it).
+    static constexpr bool M16 = WX3_M16 && !LUMPS;
     static_assert(WM * WN * WK == NWAVE && KS >= 1 && KS * WK == TH * 2, "wave layout");
     static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NWAVE * 16 * 64 * 4, "LDS budget (images; reduction scratch aliases them)");
 };
@@ -125,7 +147,8 @@ wgrad_x3_kernel(const Wx3Args a) {
         const int pix = j >> 3;
         g_r[k] = pix >> 5; g_c[k] = pix & 31;
         g_off[k] = (unsigned)((g_r[k] * a.W + g_c[k]) * a.Gcs + q8 * 4) * 4u;
-        g_dst[k] = (gb * 3 * GPIX + pix) * 64 + q8 * 8;             // byte offset in an image; + piece * GPIX * 64
+        g_dst[k] = Cfg::M16 ? gb * 3 * GPIX * 64 + ((q8 >> 2) * GPIX + pix) * 32 + (q8 & 3) * 8      // [piece][half][pixel][32 B]
+                            : (gb * 3 * GPIX + pix) * 64 + q8 * 8;                                    // byte offset in an image; + piece * GPIX * 64
     }
     const int xd = (n0 + 32 * xb >= a.n_split) ? 1 : 0;             // wave-uniform source of this wave's X block
     const int xch0 = n0 + 32 * xb - (xd ? a.n_split : 0);
@@ -138,7 +161,7 @@ wgrad_x3_kernel(const Wx3Args a) {
         const int pix = j >> 3;
         x_r[k] = pix / XC; x_c[k] = pix - x_r[k] * XC;              // halo coordinates, 0-based: image pixel (y0 - 1 + r, x0 - 1 + c)
         x_off[k] = (unsigned)((x_r[k] * a.W + x_c[k]) * xcs + q8 * 4) * 4u;
-        x_dst[k] = Cfg::G_BYTES + (xb * 3 * XPIX + pix) * 64 + q8 * 8;
+        x_dst[k] = Cfg::G_BYTES + (Cfg::M16 ? xb * 3 * XPIX * 64 + ((q8 >> 2) * XPIX + pix) * 32 + (q8 & 3) * 8 : (xb * 3 * XPIX + pix) * 64 + q8 * 8);
     }
     const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * gb), 0, 0x7fffffff, 0x00020000);
     // (the X resource starts one row + one pixel BEFORE the tensor so that the scalar offset of a halo tile is never negative)
@@ -221,6 +244,8 @@ wgrad_x3_kernel(const Wx3Args a) {
         }
     };
 
+    // accumulators of the wave's 32 x 32 x 9 block: 32 x 32 x 16 shape: acc[t][r]; 16 x 16 x 32 shape: acc[t][4 (2 mh + nh) + r] = the
+    // 16 x 16 block (rows 16 mh .., columns 16 nh ..): lane l holds rows 4 (l >> 4) + r, column l & 15
     f32x16 acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -272,6 +297,62 @@ wgrad_x3_kernel(const Wx3Args a) {
         const char* gimg = smem + img * Cfg::IMG_BYTES;
         const char* ximg = gimg + Cfg::G_BYTES;
         const bool have_next = tile + a.Z < ntile, have_next2 = tile + 2 * a.Z < ntile;
+        if constexpr (Cfg::M16) {
+        // lane geometry of the transposed reads: 16-lane group g = lane >> 4 is k-block g: piece X (g < 2) or Y, pixels {0-3, 8-11} (g even)
+        // or {4-7, 12-15} of the k-step; inside a group lane 4 q + p supplies the address of pixel row q, channel chunk 4 p
+        const int lb = ((((lane >> 4) & 1) * 4 + ((lane & 15) >> 2)) * 32) + (lane & 3) * 8, hi2 = lane >> 5;
+        constexpr int PSG = GPIX * 64, PSX = XPIX * 64;             // piece strides
+        // operand forms: A0 = [hi | mid], A1 = [hi | lo];  B0 = [hi' | hi'], B1 = [mid' | mid'], B2 = [lo' | hi']
+        //   A1 B2 = hi lo' + lo hi',  A0 B1 = hi mid' + mid mid',  A0 B0 = hi hi' + mid hi'   (smallest terms first)
+        const int la0 = lb + hi2 * PSG, la1 = lb + hi2 * 2 * PSG, lb2 = lb + (1 - hi2) * 2 * PSX;
+        auto half_read = [&](const char* base) {                     // 4 pixels x 1 channel per lane: one transposed read
+            return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
+        };
+        auto a_base = [&](int ks, int mh, int f) {
+            const int kk = wk * KS + ks;
+            return gimg + (wmo * 3) * PSG + (mh * GPIX + (kk >> 1) * 32 + (kk & 1) * 16) * 32 + (f ? la1 : la0);
+        };
+        auto b_base = [&](int ks, int t, int nh, int f) {
+            const int kk = wk * KS + ks, dy = t / 3, dx = t - 3 * dy;
+            return ximg + (wno * 3) * PSX + (nh * XPIX + ((kk >> 1) + dy) * XC + (kk & 1) * 16 + dx) * 32 + (f == 0 ? lb : (f == 1 ? lb + PSX : lb2));
+        };
+        bmul = have_next ? 1.f : 0.f;                                // (without a next tile the staging below rewrites the idle image from stale registers: harmless)
+        u32x4 Av[2][2][2], Bv[2][3];                                 // [k-step parity][mh][form], [step parity][form]
+        auto put_half = [](u32x4& d, int h, u32x2 v) { if (h == 0) { d.x = v.x; d.y = v.y; } else { d.z = v.x; d.w = v.y; } };
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int f = 0; f < 2; ++f) { put_half(Av[0][mh][f], 0, half_read(a_base(0, mh, f))); put_half(Av[0][mh][f], 1, half_read(a_base(0, mh, f) + 256)); }
+#pragma unroll
+        for (int f = 0; f < 3; ++f) { put_half(Bv[0][f], 0, half_read(b_base(0, 0, 0, f))); put_half(Bv[0][f], 1, half_read(b_base(0, 0, 0, f) + 256)); }
+        constexpr int NSTEP = KS * 18;                               // steps (tap, n-half) of six MFMAs per tile and wave
+        constexpr int SL0M = NSTEP - 1 - NSL;                        // first step that carries a staging slice
+        static_assert(SL0M >= 0, "more staging slices than steps");
+        static_for<0, NSTEP * 6>([&](auto GI) {
+            constexpr int gi = decltype(GI)::value, S = gi / 6, G = gi % 6, ks = S / 18, st = S % 18, t = st / 2, nh = st % 2, mh = G / 3, pr = G % 3;
+            constexpr int cur = S & 1;
+            if constexpr (G == 0 && S == SL0M) __builtin_amdgcn_s_waitcnt(0x0f70);   // the next tile's loads were issued a full tile ago
+            if constexpr (G == 0) __builtin_amdgcn_sched_barrier(0);
+            f32x4 c4 = {acc[t][4 * (2 * mh + nh)], acc[t][4 * (2 * mh + nh) + 1], acc[t][4 * (2 * mh + nh) + 2], acc[t][4 * (2 * mh + nh) + 3]};
+            if constexpr (pr == 0) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][1]), __builtin_bit_cast(bf16x8, Bv[cur][2]), c4, 0, 0, 0);
+            else if constexpr (pr == 1) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][0]), __builtin_bit_cast(bf16x8, Bv[cur][1]), c4, 0, 0, 0);
+            else c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][0]), __builtin_bit_cast(bf16x8, Bv[cur][0]), c4, 0, 0, 0);
+            acc[t][4 * (2 * mh + nh)] = c4.x; acc[t][4 * (2 * mh + nh) + 1] = c4.y; acc[t][4 * (2 * mh + nh) + 2] = c4.z; acc[t][4 * (2 * mh + nh) + 3] = c4.w;
+            // the next step's B operand: one transposed read per gap (form G / 2, half G % 2)
+            if constexpr (S + 1 < NSTEP) {
+                constexpr int S1 = S + 1, ks1 = S1 / 18, t1 = (S1 % 18) / 2, nh1 = S1 % 2;
+                put_half(Bv[cur ^ 1][G >> 1], G & 1, half_read(b_base(ks1, t1, nh1, G >> 1) + (G & 1) * 256));
+            }
+            // the next k-step's A operands: eight reads in the gaps of its predecessor's last two steps
+            if constexpr (ks + 1 < KS && st >= 16) {
+                constexpr int j = (st - 16) * 6 + G;
+                if constexpr (j < 8) put_half(Av[(ks + 1) & 1][j >> 2][(j >> 1) & 1], j & 1, half_read(a_base(ks + 1, j >> 2, (j >> 1) & 1) + (j & 1) * 256));
+            }
+            if constexpr (S >= SL0M && S < SL0M + NSL) { stage_piece(S - SL0M, 2 * G, img ^ 1); if constexpr (2 * G + 1 < 11) stage_piece(S - SL0M, 2 * G + 1, img ^ 1); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (have_next2) load_tile(tile + 2 * a.Z);                  // registers are free again: the tile after next
+        } else
         if constexpr (!Cfg::LUMPS) {
         // Operand reads and the staging pieces sit BETWEEN the individual MFMAs (fenced).  The SIMD's vector issue is the shared
         // resource: an MFMA holds it for 8 of its 32 cycles, a VALU instruction for 4-5, and DEPENDENT VALU instructions back to back
@@ -400,10 +481,12 @@ wgrad_x3_kernel(const Wx3Args a) {
             }
         }
         if (wk == 0) {
-            const int n = n0 + wno * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wmo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                // 32 x 32 x 16 shape: column l31, row (r & 3) + 8 (r >> 2) + 4 half;  16 x 16 x 32 shape: block (mh, nh) = (r >> 3, (r >> 2) & 1),
+                // column 16 nh + (lane & 15), row 16 mh + 4 (lane >> 4) + (r & 3)
+                const int n = n0 + wno * 32 + (Cfg::M16 ? 16 * ((r >> 2) & 1) + (lane & 15) : l31);
+                const int m = m0 + wmo * 32 + (Cfg::M16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half);
                 a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = v[r];
             }
         }
