@@ -23,6 +23,11 @@ def run(cls, gf, B, H, W, reps=10):
     print(f'{cls.__name__:14s} B={B} {H}x{W}: {dt*1e3:7.2f} ms/forward  {fl/dt/1e12:6.1f} TFLOP/s  {B*H*W/(512*512)/dt:7.1f} crop-equiv/s')
 
 if __name__ == '__main__':
+    from pnnp_amd import ops
+    split = int(os.environ.get('PNNP_SPLIT', '0'))          # > 0: force pnnp_set_persistent_split (0 = what the engine chooses)
+    if split:
+        ops.set_persistent_split(split)
+        print(f'persistent split forced to {split}')
     run(UNetSeeInDark, 96.771, 1, 1424, 2128)
     run(UNetSeeInDark, 96.771, 16, 512, 512)
     run(UNetSeeInDark, 96.771, 1, 512, 512)
