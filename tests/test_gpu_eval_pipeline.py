@@ -97,8 +97,8 @@ def test_eval_tail_kernel_equals_the_tensor_ops_bit_for_bit(res):
     torch.manual_seed(4)
     net = UNetSeeInDark(dict(nframes=1, res=res, nf=8, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda().eval()
     g = torch.Generator(device='cuda').manual_seed(5)
-    hr = torch.rand(1, 4, 48, 72, device='cuda', generator=g)                      # 72 % 16 = 8: the padded branch
-    lr = hr / 5.0 + torch.randn(1, 4, 48, 72, device='cuda', generator=g) * 0.02
+    hr = torch.rand(1, 4, 56, 72, device='cuda', generator=g)                      # 72 % 16 = 8: the padded branch (64 x 80 through the net)
+    lr = hr / 5.0 + torch.randn(1, 4, 56, 72, device='cuda', generator=g) * 0.02
     with torch.no_grad():
         ref_dn = net(F.pad(lr, (4, 4, 4, 4), mode='reflect'))[..., 4:-4, 4:-4]          # the module's own forward (residual inside)
         ref_dn = (ref_dn * 5.0).clamp(0, 1); ref_lr = (lr * 5.0).clamp(0, 1)
