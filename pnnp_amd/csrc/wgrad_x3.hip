@@ -532,13 +532,20 @@ wx3_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int64
         const bool isb = i >= n;                                    // (n is a multiple of 32: a 32-wide group never straddles the two parts)
         const float* src = isb ? bias_slab + (i - n) : slab + i;
         const int64_t zs = isb ? nb : n;
-        float s0 = 0.f, s1 = 0.f;
+        // (eight independent loads in flight per thread: with two, a layer with few weights and many slabs -- conv1_2: 9216 x 256 --
+        //  was one memory latency per pair, 11 us for 9 MB)
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (i < ntot) {
             int zz = ty;
+            for (; zz + 56 < Z; zz += 64) {
+                const float v0 = src[(int64_t)zz * zs], v1 = src[(int64_t)(zz + 8) * zs], v2 = src[(int64_t)(zz + 16) * zs], v3 = src[(int64_t)(zz + 24) * zs];
+                const float v4 = src[(int64_t)(zz + 32) * zs], v5 = src[(int64_t)(zz + 40) * zs], v6 = src[(int64_t)(zz + 48) * zs], v7 = src[(int64_t)(zz + 56) * zs];
+                s0 += v0; s1 += v1; s2 += v2; s3 += v3; s0 += v4; s1 += v5; s2 += v6; s3 += v7;
+            }
             for (; zz + 8 < Z; zz += 16) { s0 += src[(int64_t)zz * zs]; s1 += src[(int64_t)(zz + 8) * zs]; }
             for (; zz < Z; zz += 8) s0 += src[(int64_t)zz * zs];
         }
-        red[ty][tx] = sg * (s0 + s1);
+        red[ty][tx] = sg * ((s0 + s1) + (s2 + s3));
         __syncthreads();
         if (ty == 0 && i < ntot) {
             float s = 0.f;
