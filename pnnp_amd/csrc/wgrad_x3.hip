@@ -67,6 +67,9 @@ __device__ __forceinline__ void static_for(F&& f) {                  // f(integr
 #ifndef WX3_ALT_SIGN
 #define WX3_ALT_SIGN 1
 #endif
+#ifndef WX3_WIDE
+#define WX3_WIDE 1               // 128 x 64 output tiles where the channel counts allow (round 4: -2 ... -3 % on those layers)
+#endif
 #ifndef WX3_M16
 // Experiment of round 4, parity-green but 15-40 % SLOWER than the 32 x 32 x 16 path, so off: the 16 x 16 x 32
 // shape needs twice the transposed reads (116 instead of 60 per k-step) and the 64 x 64 configuration has no registers for a deeper
@@ -570,12 +573,19 @@ int launch_wx3(const Wx3Args& a, hipStream_t s) {
 }
 
 // output-tile shape: 64 x 64 (two pixel splits inside the workgroup), 64 x 32 / 32 x 64 (four), 32 x 32 (eight)
-int wx3_shape(int M, int N) { return (M % 64 == 0 ? 1 : 0) + (N % 64 == 0 ? 2 : 0); }
-int wx3_th(int shape) { return shape == 0 ? 4 : 2; }
+// shape 4 (WX3_WIDE, round 4): 128 x 64 with no pixel split inside the workgroup and one-row pixel tiles -- six staging slices instead of seven
+// per 108 MFMAs, 253 registers without a spill (the 64 x 64 configuration: 256 with three): -2 ... -3 % on conv3 .. conv8 (profiles/r4/wgrad_wide.txt)
+int wx3_shape(int M, int N) {
+#if WX3_WIDE
+    if (M % 128 == 0 && N % 64 == 0) return 4;
+#endif
+    return (M % 64 == 0 ? 1 : 0) + (N % 64 == 0 ? 2 : 0);
+}
+int wx3_th(int shape) { return shape == 4 ? 1 : (shape == 0 ? 4 : 2); }
 
 int wx3_splits(int B, int H, int W, int M, int N) {
     const int shape = wx3_shape(M, N);
-    const int bm = (shape & 1) ? 64 : 32, bn = (shape & 2) ? 64 : 32;
+    const int bm = shape == 4 ? 128 : ((shape & 1) ? 64 : 32), bn = shape == 4 ? 64 : ((shape & 2) ? 64 : 32);
     const int th = wx3_th(shape);
     const int tiles = ((W + 31) / 32) * ((H + th - 1) / th) * B;
     const int out_tiles = (M / bm) * (N / bn);
@@ -638,6 +648,7 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
     a.bias_slab = dbias ? workspace + (int64_t)a.Z * 9 * Cout * N : nullptr;
     int rc;
     switch (wx3_shape(Cout, N)) {
+        case 4: rc = launch_wx3<4, 2, 1>(a, st); break;
         case 3: rc = launch_wx3<2, 2, 2>(a, st); break;
         case 1: rc = launch_wx3<2, 1, 2>(a, st); break;
         case 2: rc = launch_wx3<1, 2, 2>(a, st); break;
