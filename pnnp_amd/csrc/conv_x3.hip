@@ -36,6 +36,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
+int pnnp_igemm_x3s_launch(const IgemmArgs& a, int wide, hipStream_t s);      // csrc/conv_x3s.hip: the same tile with specialised waves
+#ifndef X3_SPEC
+#define X3_SPEC 1                  // 1: the 3x3 layers run on csrc/conv_x3s.hip (producer / consumer waves); 0: on the kernel below
+#endif
 
 namespace {
 
@@ -47,6 +51,7 @@ constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row
 #ifndef X3_FILLMODE
 #define X3_FILLMODE 0              // BN = 64: which waves stage the next chunk's halo in which filter row (see the main loop)
 #endif
+#define X3_VMCNT(N) (0x0f70 | ((N) & 15) | (((N) >> 4) << 14))      // s_waitcnt vmcnt(N) alone (N <= 63: the counter's high bits sit at 15:14)
 #ifdef X3_NOBAR                    // timing experiment only (racy, wrong results): no per-item barriers -- what would ANY relaxation of them buy?
 #define X3_SYNC()
 #else
@@ -57,6 +62,12 @@ constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row
 #endif
 #ifndef X3_M16
 #define X3_M16 1                   // 1: v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (see mfma_row16); 0: v_mfma_f32_32x32x16_bf16
+#endif
+#ifndef X3_DIRECT
+#define X3_DIRECT 1                // 1: the epilogue stores straight from the accumulators (operands swapped in the MFMA: see `epilogue`); 0: rounds 2-4's LDS patch
+#endif
+#if X3_DIRECT && !X3_M16
+#error "X3_DIRECT reads the 16x16 accumulator layout"
 #endif
 #if X3_M16
 // halo image in 16-byte words: [piece 3][k-octet 2][pixel, plane padded to a multiple of 16 words].  A 16x16x32 operand read takes
@@ -95,7 +106,11 @@ template <int BN> struct X3Cfg {
     static constexpr int EPI = NWAVE * 16 * EPS * 4;               // per wave: (16 pixels x 32 channels) floats
     // BN = 64: the epilogue patches live in the weight stage the tile's last item has just consumed (a barrier in between)
     static constexpr bool EPI_ALIAS = WS_STAGE >= EPI;
+#if X3_DIRECT
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE;                               // no epilogue patch: 156672 (BN = 64) / 147456 (BN = 32)
+#else
     static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (EPI_ALIAS ? 0 : EPI);      // X3_M16 (padded planes): 156672 (BN = 64) / 163840 (BN = 32: ALL of the LDS)
+#endif
     static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS: 160 KB on gfx950 (BN = 32 uses every byte: any growth must come out of something else)");
 };
 
@@ -127,15 +142,20 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int BN, bool POOL>
+// EK: which epilogue the kernel carries -- ONE straight-line path per instantiation, so that the waits behind it can count its stores (see
+// `epilogue`): 0 forward (bias + activation), 1 backward-data (act' mask on every destination), 2 anything else (residual, accumulation,
+// a mask on one destination only), 3 forward + the fused MaxPool2d(2)
+enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3 };
+template <int BN, int EK>
 __global__ void __launch_bounds__(NTHR, 1)
 igemm_x3_kernel(const IgemmArgs a) {
+    constexpr bool POOL = EK == EK_POOL;
     using Cfg = X3Cfg<BN>;
     constexpr int NT = Cfg::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* xs = reinterpret_cast<u32x4*>(smem);                     // two halo images
     char* wsb = smem + 2 * XS_BYTES;                                // two weight stages
-    float* epi_sep = reinterpret_cast<float*>(smem + 2 * XS_BYTES + Cfg::NSTAGE * Cfg::WS_STAGE);
+    [[maybe_unused]] float* epi_sep = reinterpret_cast<float*>(smem + 2 * XS_BYTES + Cfg::NSTAGE * Cfg::WS_STAGE);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform (the LDS-DMA pieces depend on it)
@@ -313,7 +333,7 @@ igemm_x3_kernel(const IgemmArgs a) {
     const int boff0 = ((oct16 * 3 + 0) * 32 + r16) * 16, boff1 = ((oct16 * 3 + 1) * 32 + r16) * 16,
               boff2 = ((oct16 * 3 + (ps16 ? 0 : 2)) * 32 + r16) * 16;                                            // bytes inside one tap
     // the 8 accumulator values of a lane for (pixel row i, 32-column block k, 16-pixel half h2) -> the wave's patch [16 px][EPS]
-    auto spill_half = [&](float* eb, int i, int k, int h2) {
+    [[maybe_unused]] auto spill_half = [&](float* eb, int i, int k, int h2) {
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -387,7 +407,11 @@ igemm_x3_kernel(const IgemmArgs a) {
                 if (((turn + tr) & 1) == (wave >= NWAVE / 2 ? 1 : 0)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
             }
 #endif
+#if X3_DIRECT                      // weights as the instruction's FIRST operand: D = channels x pixels, a lane holds 4 consecutive channels of ONE pixel (see `epilogue`)
+#define X3_MFMA16(FA, FB) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Bv[buf][FB]), __builtin_bit_cast(bf16x8, A[mb][FA]), acc[mb][j], 0, 0, 0)
+#else
 #define X3_MFMA16(FA, FB) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, A[mb][FA]), __builtin_bit_cast(bf16x8, Bv[buf][FB]), acc[mb][j], 0, 0, 0)
+#endif
             if constexpr (sp == 0) X3_MFMA16(1, 2);                 // hi lo' + lo hi'
             else if constexpr (sp == 1) X3_MFMA16(0, 1);            // hi mid' + mid mid'
             else X3_MFMA16(0, 0);                                   // hi hi' + mid hi'
@@ -573,6 +597,188 @@ igemm_x3_kernel(const IgemmArgs a) {
         return e;
     };
 
+#if X3_DIRECT
+    // ---- epilogue of tile `tl`, straight from the accumulators (round 4).  With the WEIGHTS as the first operand of the 16x16x32 instruction the
+    // accumulator block is channels x pixels: lane l holds channels 4 (l >> 4) .. + 3 of pixel l & 15 -- sixteen contiguous bytes of the NHWC
+    // destination.  So bias, activation, act' mask, residual and accumulation are plain float4 arithmetic on the accumulator registers and every
+    // block goes out as ONE 16-byte store per lane (16 pixels x 64 bytes per instruction; a CU's store path takes ~12 cycles per store
+    // instruction whatever its width: tools/ubench/store_rate.hip): no LDS patch, no transposition through it (rounds 2-4: 64 ds_write_b32 +
+    // 16 ds_read_b128 per wave and tile, each round a dependent chain behind `s_waitcnt lgkmcnt`), no barrier in front of the epilogue, and the
+    // stores drain while the next tile's first filter row runs (the waits behind an epilogue count them: `run` / the 32-column loop below).
+    // The fused MaxPool2d(2) takes the other pixel of a pair from the neighbouring lane (DPP quad_perm) and the other row from the wave's
+    // second accumulator row.
+    constexpr int NST = POOL ? NB * 2 * 4 : MB * NB;                // vector-memory stores of one epilogue per wave (the vmcnt units behind it)
+    static_assert(NST + 2 * NSLOT + 2 * Cfg::DPW <= 63, "the waits behind an epilogue count its stores");
+    auto nohook = [](auto) {};
+    auto epilogue = [&](const Tile& tl, float*) __attribute__((always_inline)) {
+        X3_T(te)
+        const EpiArgs ea = epi_args();
+        const int b = tl.b, n0 = tl.n0;
+        const int p16 = lane & 15, c4 = (lane >> 4) * 4;
+        const int py0 = tl.y0 + wave * MT, px0 = tl.x0 + p16;
+        int du_[NT], chw_[NT], cs_[NT]; bool blk_[NT];
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int nwv = __builtin_amdgcn_readfirstlane(n0 + k * 32);
+            du_[k] = nwv >= ea.n_split ? 1 : 0; chw_[k] = nwv - (du_[k] ? ea.n_split : 0); cs_[k] = ea.dst_cs(du_[k]); blk_[k] = nwv < ea.Ntot;
+        }
+        // byte offset of this lane's pixel (row i, 16-pixel half h) and channel quad in the destination of 32-column block k, or out of range;
+        // the 16-column block inside it (+ 64 bytes) goes through the instruction's scalar offset
+        unsigned vo[NT][MT][2];
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const bool ok = blk_[k] && py0 + i < ea.DH && px0 + 16 * h < ea.DW;
+                    vo[k][i][h] = ok ? (unsigned)((((py0 + i) * ea.OW + px0 + 16 * h) * cs_[k] + chw_[k] + c4) * 4) : OOB;
+                }
+        auto rsrc = [&](const float* base, int k) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)b * ea.OH * ea.OW * cs_[k]), 0, ea.OH * ea.OW * cs_[k] * 4, 0x00020000);
+        };
+        const float aslope = ea.act == 1 ? 0.2f : (ea.act == 2 ? 0.f : 1.f);
+        f32x4 bias4[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ea.bias && blk_[j >> 1]) bias4[j] = *reinterpret_cast<const f32x4*>(ea.bias + n0 + 16 * j + c4);
+        }
+        auto act4 = [&](f32x4 o) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+            return o;
+        };
+        auto take = [&](int mb, int j) { const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; return v; };
+        if constexpr (POOL) {
+            // Forward layer in front of MaxPool2d(2) (archs/Unet.py:35,41,47,53): single destination, bias + activation only.  A wave owns rows
+            // 2w, 2w + 1 of its 32 columns: a lane's two accumulator rows + the same two of lane ^ 1 are one 2x2 window of 4 channels; the even
+            // lane writes the pooled float4 and the four codes (bits 0-1 first maximum in the order (0,0) (0,1) (1,0) (1,1), bits 2-5 the signs)
+            // of csrc/misc.hip maxpool_fwd_codes_kernel.
+            static_assert(MT == 2, "a wave owns one row pair");
+            const __amdgpu_buffer_rsrc_t rd = rsrc(ea.dst(0), 0);
+            const int ph = ea.OH >> 1, pw = ea.OW >> 1;
+            const int64_t pimg = (int64_t)b * ph * pw * ea.pool_cs;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.pool_dst + pimg), 0, ph * pw * ea.pool_cs * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(ea.pool_codes + pimg), 0, ph * pw * ea.pool_cs, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x4 win[2], nbr[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        win[i] = act4(take(2 * i + h, j) + bias4[j]);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, win[i]), rd, vo[j >> 1][i][h], (j & 1) * 64, 0);
+                        // the pixel to the right (even lanes) / left (odd lanes): quad_perm [1, 0, 3, 2].  As inline assembly (with the two wait
+                        // states a DPP read needs behind the VALU write of its source): through __builtin_amdgcn_update_dpp the compiler's DPP
+                        // combiner folded the four moves of a float4 into consumers reading element 0 (ROCm 7.2, caught by the pool parity test)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            float nv; const float sv = win[i][c];
+                            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(nv) : "v"(sv));
+                            nbr[i][c] = nv;
+                        }
+                    }
+                    f32x4 mx;
+                    unsigned code = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float w0 = win[0][c], w1 = nbr[0][c], w2 = win[1][c], w3 = nbr[1][c];
+                        unsigned arg = 0; float best = w0;
+                        if (w1 > best) { best = w1; arg = 1; }                  // first maximum wins
+                        if (w2 > best) { best = w2; arg = 2; }
+                        if (w3 > best) { best = w3; arg = 3; }
+                        const unsigned cj = arg | (w0 > 0.f ? 4u : 0u) | (w1 > 0.f ? 8u : 0u) | (w2 > 0.f ? 16u : 0u) | (w3 > 0.f ? 32u : 0u);
+                        mx[c] = fmaxf(fmaxf(w0, w1), fmaxf(w2, w3));
+                        code |= cj << (8 * c);
+                    }
+                    const int px = px0 + 16 * h;
+                    const bool ok2 = !(lane & 1) && blk_[j >> 1] && py0 < ea.DH && px < ea.DW;     // even sizes: the whole window is inside or outside
+                    const unsigned po = (unsigned)(((py0 >> 1) * pw + (px >> 1)) * ea.pool_cs + n0 + 16 * j + c4);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mx), rp, ok2 ? po * 4u : OOB, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(code, rc, ok2 ? po : OOB, 0, 0);
+                }
+            X3_T(teb)
+            return;
+        }
+        // ---- FWD: no mask, no accumulation, no residual (every forward layer);  BWD: act' mask on every destination, nothing else.
+        // All mask requests first, then one add / max / select / store per block.
+        if constexpr (EK == EK_FWD || EK == EK_BWD) {
+            constexpr bool MASKED = EK == EK_BWD;
+            f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int k = 0; k < NT; ++k) {
+                    const __amdgpu_buffer_rsrc_t rm = rsrc(ea.mask(du_[k]), k);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                mk[2 * i + h][2 * k + jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, vo[k][i][h], jj * 64, 0));
+                }
+            }
+            X3_T(tea)
+#pragma unroll
+            for (int k = 0; k < NT; ++k) {
+                const __amdgpu_buffer_rsrc_t rd = rsrc(ea.dst(du_[k]), k);
+                const float msl = ea.mask_mode(du_[k]) == 1 ? 0.2f : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj]);
+                            if constexpr (MASKED) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[c] *= (mk[2 * i + h][2 * k + jj][c] > 0.f) ? 1.f : msl;
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
+                        }
+            }
+            X3_T(teb)
+            return;
+        }
+        // ---- the general case (residual, accumulation, a mask on one destination only), branch-free as well: what a block does not use is
+        // requested out of range (no memory traffic, zeros come back), so the number of vector-memory operations does not depend on the flags
+        X3_T(tea)
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int du = du_[k], mm2 = ea.mask_mode(du), acc2 = ea.accum(du);
+            const bool use_add2 = ea.addsrc && du == 0;
+            const __amdgpu_buffer_rsrc_t rd = rsrc(ea.dst(du), k);
+            const __amdgpu_buffer_rsrc_t rm = rsrc(mm2 ? ea.mask(du) : ea.dst(du), k);
+            const __amdgpu_buffer_rsrc_t rad = rsrc(use_add2 ? ea.addsrc : ea.dst(du), k);
+            const float msl = mm2 == 1 ? 0.2f : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 m2[MT][2], ad2[MT][2], pr2[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        m2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        ad2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, use_add2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        pr2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, acc2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                    }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj] + ad2[i][h]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] *= (m2[i][h][c] > 0.f || !mm2) ? 1.f : msl;
+                        o += pr2[i][h];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
+                    }
+            }
+        }
+        X3_T(teb)
+    };
+#else
     // ---- deferred output stores of the 32-column kernel (X3_DEFER32).  A CU's vector-memory STORE path takes ~16-19 bytes per cycle (round 4:
     // eight 1 KB stores per wave = 64 KB per CU in 3450 cycles, whatever surrounds them), which at the end of a K = 32 tile is 12 % of the
     // tile with the matrix pipe idle.  The epilogue therefore leaves the tile's eight full-resolution stores in registers (value + offset) and
@@ -879,6 +1085,8 @@ igemm_x3_kernel(const IgemmArgs a) {
         X3_T(teb)
     };
 
+#endif      // X3_DIRECT
+
     // ---- main loop over (tile, 16-channel chunk).  A chunk's three filter rows are straight-line code, so every s_waitcnt
     // below is exact: vector-memory operations complete in issue order.  Items are numbered it = 3 * chunk + row; item it
     // reads weight stage it % NSTAGE and, right after its barrier, requests the weights of item it + AHEAD.
@@ -923,14 +1131,20 @@ igemm_x3_kernel(const IgemmArgs a) {
         // A wave that stages in row 1 needs its halo loads (requested in row 0, tap 1) there already: vmcnt(0) instead of vmcnt(HL).
         // The loop is instantiated per (units in row 1, units in row 2): with modes 1 / 2 the two wave halves run two straight-line bodies.
         auto run = [&](auto f1, auto f2) __attribute__((always_inline)) {
+#if X3_DIRECT
+        __builtin_amdgcn_s_waitcnt(0x0f70);                             // (the wait + barrier in front of filter row 0 stand at the END of the loop body)
+        X3_SYNC();
+#endif
         for (;;) {
             const Ck n1 = chunk_at(1);
             // ---- filter row 0: its weights have landed; the barrier publishes them and halo image img (written during the
             // previous chunk's rows 1 / 2), and says every wave is done with the other image and stage
+#if !X3_DIRECT
             __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
             X3_T(tw)
             X3_SYNC();
             X3_T(tb)
+#endif
             mfma_row(0, st, img, FillNone{}, std::true_type{}, [&](int rp) {
                 if (rp < D) dma_piece(cur, g, 1, st ^ 1, true, rp); else if (rp == D) halo_prep(n1.tile, n1.g); else halo_slot(rp - D - 1); }, nohook);
             X3_T(tm)
@@ -949,6 +1163,28 @@ igemm_x3_kernel(const IgemmArgs a) {
             X3_T(tb)
             mfma_row(2, st, img, f2, std::false_type{}, [&](int rp) { dma_piece(n1.tile, n1.g, 0, st ^ 1, n1.ok, rp); }, nohook);
             X3_T(tm2)
+#if X3_DIRECT
+            // The next row 0's wait and barrier, per path: outstanding are [weights of the next row 0] and, behind an epilogue, its NST stores --
+            // which may stay in flight through that row (row 1's wait covers them).  Both stand INSIDE the paths: behind a merge the compiler,
+            // which waits for every LDS-DMA in front of a barrier by its own count, could no longer count the stores and would wait for them.
+            if (g == nchunks - 1) {
+                epilogue(cur, nullptr);
+                if (!n1.ok) break;
+                next_tile();
+                st ^= 1; img ^= 1;
+                __builtin_amdgcn_s_waitcnt(X3_VMCNT(NST));
+                X3_T(tw)
+                X3_SYNC();
+                X3_T(tb)
+            } else {
+                ++g;
+                st ^= 1; img ^= 1;
+                __builtin_amdgcn_s_waitcnt(0x0f70);
+                X3_T(tw)
+                X3_SYNC();
+                X3_T(tb)
+            }
+#else
             if (g == nchunks - 1) {
                 __syncthreads();                                        // every wave has finished reading stage st: it holds the epilogue patches now
                 epilogue(cur, reinterpret_cast<float*>(wsb + st * Cfg::WS_STAGE));
@@ -957,6 +1193,7 @@ igemm_x3_kernel(const IgemmArgs a) {
             if (!n1.ok) break;
             if (g == nchunks - 1) next_tile(); else ++g;
             st ^= 1; img ^= 1;
+#endif
         }
         };
         constexpr int FM = X3_FILLMODE;
@@ -977,16 +1214,37 @@ igemm_x3_kernel(const IgemmArgs a) {
             dma_weights(cur, 0, 1, 1);
             load_halo(n1.tile, n1.g);
         }
+#if X3_DIRECT
+        __builtin_amdgcn_s_waitcnt(X3_VMCNT(D + HL));
+        __syncthreads();
+#endif
         for (;;) {
             const Ck n1 = chunk_at(1), n2 = chunk_at(2);
             // ---- row 0: outstanding [w row 0][w row 1][halo next]
             X3_T(te)
+            auto req0 = [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); };
+            auto req1 = [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); };
+#if X3_DIRECT
+            // (The wait + barrier in front of row 0 stand at the END of the loop body, once per path: behind an epilogue its NST stores are
+            //  the youngest operations and stay in flight.  Row 1's wait then leaves the newest HL + D operations out whichever path came
+            //  before -- behind an epilogue that is the weights of row 2 and the last stores, i.e. it only asks for the first ones, issued a
+            //  filter row earlier -- and row 2's wait covers them all.)
+            mfma_row(0, 0, img, FillNone{}, std::false_type{}, req0, nohook);
+            X3_T(tm)
+            __builtin_amdgcn_s_waitcnt(X3_VMCNT(HL + D));                  // [w row 1] | [halo next][(stores)][w row 2]
+            X3_T(tw)
+            __syncthreads();
+            X3_T(tb)
+            mfma_row(1, 1, img, FillNone{}, std::false_type{}, req1, nohook);
+            X3_T(tm1)
+            __builtin_amdgcn_s_waitcnt(0x0f70 | D);                        // [halo next][(stores)][w row 2] | [w next row 0]
+            X3_T(tw)
+            __syncthreads();
+#else
             __builtin_amdgcn_s_waitcnt(0x0f70 | (D + HL));
             X3_T(tw)
             __syncthreads();
             X3_T(tb)
-            auto req0 = [&](int rp) { dma_piece(cur, g, 2, 2, true, rp); };
-            auto req1 = [&](int rp) { dma_piece(n1.tile, n1.g, 0, 0, n1.ok, rp); };
             if (DEFER && pend) {
                 // The previous tile's stores ride in this chunk's rows 0 (six) and 1 (two).  Waits and barriers stand INSIDE this path: the
                 // compiler waits for every LDS-DMA issued before a barrier and can count the younger operations (here: the stores) only on
@@ -1019,6 +1277,7 @@ igemm_x3_kernel(const IgemmArgs a) {
                 X3_T(tw)
                 __syncthreads();
             }
+#endif
             X3_T(tb)
 #if X3_M16
             // the halo of the chunk after next: its requests ride in this row's gaps as the staging frees the registers (LATE, see mfma_row);
@@ -1031,16 +1290,37 @@ igemm_x3_kernel(const IgemmArgs a) {
             load_halo(n2.tile, n2.g);
 #endif
             X3_T(tm2)
+#if X3_DIRECT
+            if (g == nchunks - 1) {
+                epilogue(cur, nullptr);
+                if (!n1.ok) break;
+                next_tile();
+                img ^= 1;
+                __builtin_amdgcn_s_waitcnt(X3_VMCNT(D + HL + NST));        // [w row 0] | [w row 1][halo next][NST stores]
+                X3_T(tw)
+                __syncthreads();
+            } else {
+                ++g;
+                img ^= 1;
+                __builtin_amdgcn_s_waitcnt(X3_VMCNT(D + HL));              // [w row 0] | [w row 1][halo next]
+                X3_T(tw)
+                __syncthreads();
+            }
+        }
+#else
             if (g == nchunks - 1) epilogue(cur, epi_sep);
             if (!n1.ok) break;
             if (g == nchunks - 1) next_tile(); else ++g;
             img ^= 1;
         }
+#endif
+#if !X3_DIRECT
         if (DEFER && pend) {                                            // the last tile's stores
             const __amdgpu_buffer_rsrc_t prd = pend_rsrc();
 #pragma unroll
             for (int i = 0; i < NST; ++i) pend_store(i, prd);
         }
+#endif
 #ifdef X3_STAMPS
         X3_T(te)
         dump_stamps();
@@ -1048,10 +1328,10 @@ igemm_x3_kernel(const IgemmArgs a) {
     }
 }
 
-template <int BN, bool POOL>
+template <int BN, int EK>
 int launch_x3(const IgemmArgs& a, hipStream_t s) {
     using Cfg = X3Cfg<BN>;
-    auto kern = igemm_x3_kernel<BN, POOL>;
+    auto kern = igemm_x3_kernel<BN, EK>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
     // ~150 KB of LDS: one 8-wave workgroup per CU resident; pnnp_set_persistent_split(n) launches n per CU with 1/n share each
@@ -1091,7 +1371,8 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
             a.OW != a.DW || (a.pool_cs & 3) || a.pool_cs < a.Ntot || ((uintptr_t)a.pool_dst & 15) || ((uintptr_t)a.pool_codes & 3))
             return PNNP_E_UNSUPPORTED;
         if ((int64_t)(a.OH / 2) * (a.OW / 2) * a.pool_cs * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
-        return a.Ntot >= 64 ? launch_x3<64, true>(b, s) : launch_x3<32, true>(b, s);
+        if (X3_SPEC) return pnnp_igemm_x3s_launch(b, a.Ntot >= 64, s);
+        return a.Ntot >= 64 ? launch_x3<64, EK_POOL>(b, s) : launch_x3<32, EK_POOL>(b, s);
     }
     // 64-column tiles unless they leave CUs idle: a layer with fewer (16 x 32 px x 64 ch) tiles than CUs (conv5_1 backward-data at
     // B = 16: 128; everything in a single-crop forward) runs on 32-column tiles, twice as many
@@ -1099,5 +1380,12 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     if (cus < 1) cus = 256;
     const int64_t tiles64 = (int64_t)((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + 63) / 64);
     const bool wide = a.Ntot >= 64 && tiles64 * 4 >= (int64_t)cus * 3;
-    return wide ? launch_x3<64, false>(b, s) : launch_x3<32, false>(b, s);
+    if (X3_SPEC) return pnnp_igemm_x3s_launch(b, wide, s);
+    // which epilogue (see the kernel template): forward, masked backward-data, or the general one
+    const bool two = a.dst[1] != nullptr;
+    const bool plain = !a.addsrc && !a.accum[0] && !(two && a.accum[1]);
+    const bool is_fwd = plain && !a.mask_mode[0] && !(two && a.mask_mode[1]), is_bwd = plain && a.mask_mode[0] && (!two || a.mask_mode[1]);
+    if (is_fwd) return wide ? launch_x3<64, EK_FWD>(b, s) : launch_x3<32, EK_FWD>(b, s);
+    if (is_bwd) return wide ? launch_x3<64, EK_BWD>(b, s) : launch_x3<32, EK_BWD>(b, s);
+    return wide ? launch_x3<64, EK_GEN>(b, s) : launch_x3<32, EK_GEN>(b, s);
 }
