@@ -136,6 +136,9 @@ igemm_x3s_kernel(const IgemmArgs a) {
 
     if (wave >= NCW) {
         // =============================================== PRODUCER ===============================================
+#ifdef X3S_PPRIO
+        __builtin_amdgcn_s_setprio(X3S_PPRIO);                        // experiment: the producers win the issue arbitration
+#endif
         const int pw = wave - NCW, ptid = tid - 64 * NCW;            // 0 .. 3, 0 .. 255
         // staging slots: s = ptid + 256 k -> (pixel s >> 1, channel octet s & 1); a slot past the end repeats the previous one of the thread
         int rk[NSLOT], qk[NSLOT]; unsigned pixk[NSLOT]; int xdst[NSLOT];
@@ -286,6 +289,11 @@ igemm_x3s_kernel(const IgemmArgs a) {
             constexpr int gi = decltype(Gc)::value;
             constexpr int tp = gi / GT, gt = gi % GT, j = gt / (MB * 3), w = gt % (MB * 3), mb = w / 3, sp = w % 3;
             constexpr int pass = tp * NB + j, buf = pass & 1;
+#ifdef X3S_PRIOALT                 // experiment: the two consumer waves of a SIMD (w, w + 4) take turns as the arbitration winner, every X3S_PRIOALT MFMAs
+            if constexpr (gi % X3S_PRIOALT == 0) {
+                if ((((gi / X3S_PRIOALT) & 1) != 0) == (wave >= NCW / 2)) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+            }
+#endif
 #define X3S_MFMA(FA, FB) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Bv[buf][FB]), __builtin_bit_cast(bf16x8, A[mb][FA]), acc[mb][j], 0, 0, 0)
             if constexpr (sp == 0) X3S_MFMA(1, 2);                  // hi lo' + lo hi'
             else if constexpr (sp == 1) X3S_MFMA(0, 1);             // hi mid' + mid mid'

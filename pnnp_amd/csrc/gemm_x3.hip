@@ -18,6 +18,10 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
+int pnnp_gemm_x3s_launch(const IgemmArgs& a, hipStream_t s);        // csrc/gemm_x3s.hip: the same GEMMs with specialised waves
+#ifndef GX_SPEC
+#define GX_SPEC 1                  // 1: the pointwise layers run on csrc/gemm_x3s.hip (producer / consumer waves); 0: on the kernel below
+#endif
 
 namespace {
 
@@ -414,6 +418,10 @@ int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     b.seg_channels = chan_per_seg;
     const int64_t wbytes = (int64_t)(a.Ntot / 32) * b.nseg * b.chunks_per_seg * 2 * WBLK;
     if (wbytes >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    if (GX_SPEC) {
+        b.chunks_per_seg = chan_per_seg / 16;                       // csrc/gemm_x3s.hip walks K in 16-channel items
+        return pnnp_gemm_x3s_launch(b, s);
+    }
     // 128-column tiles unless they leave CUs idle (single-crop forwards): then 64-column tiles, twice as many
     int cus = pnnp_device_cus();
     if (cus < 1) cus = 256;

@@ -1,0 +1,474 @@
+// Pointwise convolutions as a float32 GEMM on the bf16 matrix cores with SPECIALISED waves (round 4; the design of csrc/conv_x3s.hip applied
+// to what csrc/gemm_x3.hip runs: ConvTranspose2d(k2, s2) forward / backward-data, 1x1 shortcuts, the stride-2 3x3 convolution as 9 strided
+// taps and its backward-data per input-pixel parity class -- one tap per K segment, described by IgemmArgs).
+//
+// Without a halo a staged activation feeds only the tile's N columns, so gemm_x3.hip's waves -- each splitting its share of the next item
+// between its own MFMAs -- spent more time on the split than on the matrix pipe (cycle stamps: 4300-5400 cycles per item for 3072 MFMA
+// cycles, matrix pipe busy 0.2-0.4; profiles/r4/gemm_x3_stamps_before.txt) and then 11-16 thousand cycles per tile in an epilogue that
+// went through an LDS patch.  Here:
+//   8 CONSUMER waves (two per SIMD), 64 pixels x WN = 64 (32) channels each: ds_read_b128 + v_mfma_f32_16x16x32_bf16 only (two pieces
+//     concatenated along K, weights as the first operand), epilogue straight from the accumulators, stores left in flight;
+//   4 PRODUCER waves (one per SIMD): per 16-channel item the weights by LDS-DMA and the activations fp32 global -> registers -> hi / mid /
+//     lo split -> the other of two LDS images, both requested A = 6 (4) items ahead: an item is only 1536 matrix-pipe cycles, and with
+//     two items of flight time (first version) the kernel ran at the memory latency, not at the matrix pipe (busy 0.43 at K = 512).
+//     vmcnt completes in issue order, so the weights must be requested as early as the activations: ring of A + 1 stages, A register sets.
+// One s_barrier per item.  Tiles: 256 px x 128 columns (4 x 2 consumer waves of 64 px x 64), 512 px x 64 (8 x 1), 256 px x 64 (4 x 2 waves
+// of 64 px x 32: small layers), 512 px x 32.
+#include "igemm.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+int pnnp_gemm_x3s_launch(const IgemmArgs& a, hipStream_t s);
+
+namespace {
+
+constexpr int NCW = 8, NPW = 4, NTHR = 64 * (NCW + NPW), PTHR = 64 * NPW;
+constexpr int MT = 2;                                              // pixel rows (of 32 px) per consumer wave
+constexpr int WBLK1 = 2 * 3 * 32 * 16;                             // one item of one 32-column block: [octet 2][piece 3][32][16 B] = 3072
+constexpr unsigned OOB = 0x80000000u;
+#define GXS_VMCNT(N) (0x0f70 | ((N) & 15) | (((N) >> 4) << 14))
+#define GXS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")     // (see csrc/conv_x3s.hip: not __syncthreads())
+
+template <int BN, int WN_> struct GCfg {
+    static constexpr int WN = WN_;                                 // columns per consumer wave: 64 or 32
+    static constexpr int NWN = BN / WN, NWM = NCW / NWN;           // consumer waves along N (1 / 2) and along the pixels (8 / 4)
+    static constexpr int TH = NWM * MT, PT = TH * 32;              // tile: 16 / 8 rows of 32 px = 512 / 256 pixels
+    static constexpr int NB = WN / 16, NTW = WN / 32;              // 16-column accumulator blocks / 32-column blocks per wave
+    static constexpr int XS_F4 = 3 * 2 * PT, XS_BYTES = XS_F4 * 16; // one image: [piece 3][octet 2][pixel] 16-byte words: 49152 / 24576
+    static constexpr int WS_STAGE = (BN / 32) * WBLK1;             // 12288 / 6144 / 3072
+    static constexpr int NDMA = WS_STAGE / 1024, DPW = (NDMA + NPW - 1) / NPW;
+    static constexpr int NSL = 2 * PT / PTHR;                      // (pixel, octet) staging slots per producer thread and item: 4 / 2
+    static constexpr int A = PT == 256 ? 6 : 3;                    // items of lookahead (= register sets of the producers); ring of A + 1 weight stages
+    static constexpr int NSTAGE = A + 1;
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE;
+    static_assert(NWN * WN == BN && (NWN == 1 || NWN == 2), "tile shapes");
+    static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
+    static_assert(A * 2 * NSL + (A - 1) * DPW <= 63, "the producers' vmcnt");
+};
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+    const int q = n >> 3, r = n & 7, x = id & 7, k = id >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // RNE, low half = a
+    unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned& m, unsigned& l) {
+    h = cvt_pk_bf16(a0, a1);
+    const float r0 = a0 - __uint_as_float(h << 16), r1 = a1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
+
+#ifdef GXS_STAMPS                 // debug build: cycle sums per wave, dumped into dst[0] (tools/gx_stamps.py --spec)
+#define GXS_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
+#else
+#define GXS_T(v)
+#endif
+enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2 };                       // the epilogue a kernel carries: plain / act' masks / residual + accumulation
+
+template <int BN, int WN, int EK>
+__global__ void __launch_bounds__(NTHR, 1)
+gemm_x3s_kernel(const IgemmArgs a) {
+    using Cfg = GCfg<BN, WN>;
+    constexpr int TH = Cfg::TH, PT = Cfg::PT, NB = Cfg::NB, NTW = Cfg::NTW, NSL = Cfg::NSL, D = Cfg::DPW, XS_F4 = Cfg::XS_F4, A = Cfg::A, NSTAGE = Cfg::NSTAGE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    u32x4* xs = reinterpret_cast<u32x4*>(smem);                     // two activation images
+    char* wsb = smem + 2 * Cfg::XS_BYTES;                           // the weight ring
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0 .. 7 consumers, 8 .. 11 producers
+
+    const int tiles_x = (a.DW + 31) >> 5, tiles_y = (a.DH + TH - 1) / TH;
+    const int n_tiles = (a.Ntot + BN - 1) / BN;
+    const int total = tiles_x * tiles_y * a.B * n_tiles;
+    const int G = gridDim.x;
+    const int nitems = a.nseg * a.chunks_per_seg;                   // 16-channel items of K
+    struct Tile { int b, y0, x0, n0; };
+    auto decode = [&](int t) {
+        Tile o;
+        const int nt_i = t % n_tiles;
+        int m_i = t / n_tiles;
+        const int tx = m_i % tiles_x; m_i /= tiles_x;
+        o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN;
+        return o;
+    };
+    // A cursor walks this workgroup's items (tile t, t + G, ...; inside a tile the K segments, inside a segment its 16-channel chunks) ONE
+    // item at a time with additions and carries only: decoding a tile number costs six integer divisions by run-time values, and with
+    // one decode per lookahead per item (first version) the producers spent 1750 of an item's 3100 cycles on bookkeeping.
+    const Tile gstep = decode(G);
+    auto advance = [&](Tile o) {
+        o.n0 += gstep.n0; if (o.n0 >= n_tiles * BN) { o.n0 -= n_tiles * BN; o.x0 += 32; }
+        o.x0 += gstep.x0; if (o.x0 >= tiles_x * 32) { o.x0 -= tiles_x * 32; o.y0 += TH; }
+        o.y0 += gstep.y0; if (o.y0 >= tiles_y * TH) { o.y0 -= tiles_y * TH; o.b += 1; }
+        o.b += gstep.b;
+        return o;
+    };
+    struct It { Tile tile; int t, g, si, cc; bool ok; };
+    auto step = [&](It& c) {
+        ++c.g;
+        if (++c.cc == a.chunks_per_seg) { c.cc = 0; ++c.si; }
+        if (c.g == nitems) { c.g = 0; c.si = 0; c.cc = 0; c.t += G; c.tile = advance(c.tile); c.ok = c.t < total; }
+    };
+    It cu;                                                           // the current item
+    cu.t = xcd_remap(blockIdx.x, G);
+    if (cu.t >= total) return;
+    cu.tile = decode(cu.t); cu.g = 0; cu.si = 0; cu.cc = 0; cu.ok = true;
+
+    if (wave >= NCW) {
+        // =============================================== PRODUCER ===============================================
+#ifdef GXS_PPRIO
+        __builtin_amdgcn_s_setprio(GXS_PPRIO);                        // experiment: the producers win the issue arbitration
+#endif
+        const int pw = wave - NCW, ptid = tid - 64 * NCW;
+        // staging slots: s = ptid + 256 k -> (pixel s >> 1, channel octet s & 1): two consecutive lanes read the 64 contiguous bytes of a pixel
+        const int oct = ptid & 1;
+        int prow[NSL], pcol[NSL], xdst[NSL];
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) {
+            const int pix = (ptid + PTHR * k) >> 1;
+            prow[k] = pix >> 5; pcol[k] = pix & 31;
+            xdst[k] = oct * PT + pix;                               // + piece * 2 PT (+ image * XS_F4)
+        }
+        const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
+        f32x4 ra[A][NSL][2];                                        // A register sets: the activations of the next A items
+        // What a request needs is computed once per (tile, K segment) -- resource, scalar offset, the slots' lane offsets and validity -- and
+        // once per tile for the weights; inside a segment the next item is 16 channels (64 bytes) on, the next k-step of the pack 3072 bytes
+        // on.  (A producer shares its SIMD with two MFMA waves and gets an issue slot every ~8 cycles: the ~150 instructions of a request
+        // computed from scratch took 1200 cycles of a 1536-cycle item.)
+        const float* la_base = a.w; int la_soff = 0; unsigned la_vo[NSL];      // (the resource is re-made from the pointer: 4 scalar moves)
+        static_assert(D <= 3, "LDS-DMA pieces per producer wave");
+        int la_wsoff[3]; unsigned la_wvo[3];                        // (a literal size: with [D] the host pass of hipcc 7.2 silently drops the kernel stubs)
+#pragma unroll
+        for (int k = 0; k < NSL; ++k) la_vo[k] = OOB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { la_wsoff[i] = 0; la_wvo[i] = OOB; }
+        auto load_item = [&](const It& q, auto set_tag) {
+            constexpr int set = decltype(set_tag)::value;
+            if (q.cc == 0) {                                        // first item of a segment (of a tile)
+                const Tile& tl = q.tile;
+                const IgemmSeg sg = a.seg[q.si];
+                const int mul = a.in_mul;
+                const int shift = (a.IW + 1) * sg.cstride;         // the resource starts before the image: offsets >= -1 pixel stay >= 0
+                la_base = sg.ptr + ((int64_t)tl.b * a.IH * a.IW * sg.cstride - shift);
+                la_soff = (((tl.y0 * mul + sg.yoff) * a.IW + tl.x0 * mul + sg.xoff) * sg.cstride + sg.coff + shift) * 4;
+                const unsigned cs4 = (unsigned)sg.cstride * 4u;
+#pragma unroll
+                for (int k = 0; k < NSL; ++k) {
+                    const int iy = (tl.y0 + prow[k]) * mul + sg.yoff, ix = (tl.x0 + pcol[k]) * mul + sg.xoff;
+                    const int bad = iy | (a.IH - 1 - iy) | ix | (a.IW - 1 - ix) | (a.DH - 1 - tl.y0 - prow[k]) | (a.DW - 1 - tl.x0 - pcol[k]) | (q.ok ? 0 : -1);
+                    la_vo[k] = bad < 0 ? OOB : __umul24((unsigned)((prow[k] * a.IW + pcol[k]) * mul), cs4) + oct * 32;
+                }
+            }
+            const __amdgpu_buffer_rsrc_t la_rs = __builtin_amdgcn_make_buffer_rsrc((void*)la_base, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                ra[set][k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(la_rs, la_vo[k], la_soff, 0));
+                ra[set][k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(la_rs, la_vo[k], la_soff + 16, 0));
+            }
+            la_soff += 64;
+        };
+        auto stage_set = [&](auto set_tag, int img) {
+            constexpr int set = decltype(set_tag)::value;
+#pragma unroll
+            for (int k = 0; k < NSL; ++k) {
+                u32x4 sh, sm, sl;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 v = ra[set][k][p >> 1];
+                    unsigned h, m, l;
+                    split2(v[(p & 1) * 2], v[(p & 1) * 2 + 1], h, m, l);
+                    sh[p] = h; sm[p] = m; sl[p] = l;
+                }
+                u32x4* d = xs + img * XS_F4 + xdst[k];
+                d[0] = sh; d[2 * PT] = sm; d[4 * PT] = sl;
+            }
+        };
+        // LDS-DMA of the weights of item q into stage st: per 32-column block the 3072 contiguous bytes of its k-step, as 1 KB pieces
+        const int K16 = nitems;
+        auto dma_weights = [&](const It& q, int st) {
+            if (q.g == 0) {                                         // first item of a tile
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    const int ins = min(pw + NPW * i, Cfg::NDMA - 1);
+                    const int j = ins / 3, r = ins - 3 * j;
+                    const int nb = (q.tile.n0 >> 5) + j;
+                    const bool ok = q.ok && nb * 32 < a.Ntot;
+                    la_wsoff[i] = ok ? (nb * K16 * WBLK1 + r * 1024) : 0;
+                    la_wvo[i] = ok ? (unsigned)lane * 16u : OOB;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const int ins = min(pw + NPW * i, Cfg::NDMA - 1);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(wsb + st * Cfg::WS_STAGE + ins * 1024),
+                                                         16, la_wvo[i], la_wsoff[i], 0, 0);
+                la_wsoff[i] += WBLK1;
+            }
+        };
+        // ---- prologue: weights and activations of items 0 .. A - 1 (stage j, set j); item 0 straight into image 0
+        It la = cu;                                                  // the lookahead cursor: A items ahead of cu
+        static_for<0, A>([&](auto J) { constexpr int j = decltype(J)::value; dma_weights(la, j); load_item(la, J); step(la); });
+        stage_set(std::integral_constant<int, 0>{}, 0);
+        GXS_BARRIER();                                              // barrier 0 (the wait for set 0 covered the weights of item 0)
+        int it = 0, st = 0;                                          // items since the start (image it & 1); stage of item it
+        // Item it, S = it mod A: [weights of item it + A -> the stage item it - 1 left] [activations of item it + A -> set S, split during
+        // item it - 1] [split the set of item it + 1 into image (it + 1) & 1]; in front of the barrier the weights of item it + 1
+        // (requested A - 1 blocks ago) must have landed: vmcnt(what was issued behind them = A x the loads of an item + (A - 1) x its LDS-DMAs).
+#ifdef GXS_STAMPS
+        long long t_req = 0, t_split = 0, t_wait = 0, t_bar = 0, tlast_ = clock64(), tall = tlast_;
+#endif
+        auto block = [&](auto s_tag) __attribute__((always_inline)) {
+            constexpr int S = decltype(s_tag)::value;
+            dma_weights(la, st == 0 ? NSTAGE - 1 : st - 1);
+            load_item(la, s_tag);
+            step(la);
+            GXS_T(t_req)
+            stage_set(std::integral_constant<int, (S + 1) % A>{}, (it + 1) & 1);
+            GXS_T(t_split)
+            __builtin_amdgcn_s_waitcnt(GXS_VMCNT(A * 2 * NSL + (A - 1) * D));
+            GXS_T(t_wait)
+            step(cu);
+            if (!cu.ok) return false;
+            GXS_BARRIER();
+            GXS_T(t_bar)
+            ++it; st = st == NSTAGE - 1 ? 0 : st + 1;
+            return true;
+        };
+        for (;;) {
+            bool go = true;
+            static_for<0, A>([&](auto S) { if (go) go = block(S); });
+            if (!go) break;
+        }
+#ifdef GXS_STAMPS
+        if (lane == 0) {
+            float* d = a.dst[0] + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+            d[0] = (float)t_req; d[1] = (float)t_split; d[2] = (float)t_wait; d[3] = (float)t_bar; d[4] = (float)(clock64() - tall); d[5] = (float)(it + 1);
+        }
+#endif
+        return;
+    }
+
+    // =============================================== CONSUMER ===============================================
+    const int wn = wave % Cfg::NWN, wm = wave / Cfg::NWN;             // this wave's column group / pixel-row pair
+    constexpr int MB = 2 * MT;
+    f32x4 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int r16 = lane & 15, q16 = lane >> 4, oct16 = q16 & 1, ps16 = q16 >> 1;
+    // operand forms as in csrc/conv_x3s.hip: pixels 0 = [hi | mid], 1 = [hi | lo]; weights 0 = [hi' | hi'], 1 = [mid' | mid'], 2 = [lo' | hi']
+    const int aoff0 = ((ps16 ? 1 : 0) * 2 + oct16) * PT + wm * (MT * 32) + r16, aoff1 = ((ps16 ? 2 : 0) * 2 + oct16) * PT + wm * (MT * 32) + r16;
+    const int boff0 = ((oct16 * 3 + 0) * 32 + r16) * 16, boff1 = ((oct16 * 3 + 1) * 32 + r16) * 16,
+              boff2 = ((oct16 * 3 + (ps16 ? 0 : 2)) * 32 + r16) * 16;
+    auto mfma_item = [&](int st, int img) {
+        const char* wst = wsb + st * Cfg::WS_STAGE + wn * NTW * WBLK1;
+        const u32x4* xim = xs + img * XS_F4;
+        u32x4 A[MB][2], Bv[2][3];
+        auto a_read = [&](int mb, int f) { A[mb][f] = xim[(f ? aoff1 : aoff0) + (mb >> 1) * 32 + 16 * (mb & 1)]; };
+        auto b_read = [&](int j, int f, int buf) {
+            Bv[buf][f] = *reinterpret_cast<const u32x4*>(wst + (j >> 1) * WBLK1 + (f == 0 ? boff0 : (f == 1 ? boff1 : boff2)) + (j & 1) * 256);
+        };
+#pragma unroll
+        for (int f = 0; f < 3; ++f) b_read(0, 2 - f, 0);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) { a_read(mb, 1); a_read(mb, 0); }
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<0, NB * MB * 3>([&](auto Gc) {
+            constexpr int gi = decltype(Gc)::value;
+            constexpr int j = gi / (MB * 3), w = gi % (MB * 3), mb = w / 3, sp = w % 3, buf = j & 1;
+#define GXS_MFMA(FA, FB) acc[mb][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Bv[buf][FB]), __builtin_bit_cast(bf16x8, A[mb][FA]), acc[mb][j], 0, 0, 0)
+            if constexpr (sp == 0) GXS_MFMA(1, 2);                  // hi lo' + lo hi'
+            else if constexpr (sp == 1) GXS_MFMA(0, 1);             // hi mid' + mid mid'
+            else GXS_MFMA(0, 0);                                    // hi hi' + mid hi'
+#undef GXS_MFMA
+            if constexpr (w < 3 && j + 1 < NB) b_read(j + 1, 2 - w, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+
+    // ---- epilogue, straight from the accumulators (a lane holds 4 consecutive channels of one pixel): sub-pixel scatter of ConvTranspose2d
+    // forward (n_sub), strided / offset outputs (out_mul, out_yoff / out_xoff), two destinations (n_split), bias, activation, act' mask,
+    // residual, accumulation -- csrc/gemm_x3.hip's contract
+    auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
+        const int b = tl.b;
+        const int p16 = lane & 15, c4 = (lane >> 4) * 4;
+        const int py0 = tl.y0 + wm * MT, px0 = tl.x0 + p16;
+        int du_[NTW], cs_[NTW], bch_[NTW]; bool blk_[NTW];
+        unsigned vo[NTW][MT][2];
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) {
+            const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + wn * WN + k * 32);
+            const int du = nwv >= a.n_split ? 1 : 0;
+            const int subu = a.n_sub ? nwv / a.n_sub : 0;
+            const int chw = nwv - subu * a.n_sub - (du ? a.n_split : 0);
+            const int yo2 = a.out_yoff + (subu >> 1), xo2 = a.out_xoff + (subu & 1);
+            du_[k] = du; cs_[k] = a.dst_cs[du]; blk_[k] = nwv < a.Ntot; bch_[k] = nwv - subu * a.n_sub;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int py = py0 + i, px = px0 + 16 * h;
+                    const int oy = py * a.out_mul + yo2, ox = px * a.out_mul + xo2;
+                    const bool ok = blk_[k] && py < a.DH && px < a.DW && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+                    vo[k][i][h] = ok ? (unsigned)(((oy * a.OW + ox) * cs_[k] + chw + c4) * 4) : OOB;
+                }
+        }
+        auto rsrc = [&](const float* base, int k) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)b * a.OH * a.OW * cs_[k]), 0, a.OH * a.OW * cs_[k] * 4, 0x00020000);
+        };
+        const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
+        f32x4 bias4[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && blk_[j >> 1]) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + bch_[j >> 1] + 16 * (j & 1) + c4);
+        }
+        auto act4 = [&](f32x4 o) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+            return o;
+        };
+        auto take = [&](int mb, int j) { const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; return v; };
+        if constexpr (EK == EK_FWD || EK == EK_BWD) {
+            constexpr bool MASKED = EK == EK_BWD;
+            f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int k = 0; k < NTW; ++k) {
+                    const int mm = a.mask_mode[du_[k]];
+                    const __amdgpu_buffer_rsrc_t rm = rsrc(mm ? a.mask[du_[k]] : a.dst[du_[k]], k);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                        for (int i = 0; i < MT; ++i)
+#pragma unroll
+                            for (int h = 0; h < 2; ++h)
+                                mk[2 * i + h][2 * k + jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm ? vo[k][i][h] : OOB, jj * 64, 0));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NTW; ++k) {
+                const __amdgpu_buffer_rsrc_t rd = rsrc(a.dst[du_[k]], k);
+                const int mm = a.mask_mode[du_[k]];
+                const float msl = mm == 1 ? 0.2f : 0.f;
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj]);
+                            if constexpr (MASKED) {
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o[c] *= (mk[2 * i + h][2 * k + jj][c] > 0.f || !mm) ? 1.f : msl;
+                            }
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
+                        }
+            }
+            return;
+        }
+        // the general case (residual, accumulation), branch-free: what a block does not use is requested out of range (zeros, no traffic)
+#pragma unroll
+        for (int k = 0; k < NTW; ++k) {
+            const int du = du_[k], mm2 = a.mask_mode[du], acc2 = a.accum[du];
+            const bool use_add2 = a.addsrc && du == 0;
+            const __amdgpu_buffer_rsrc_t rd = rsrc(a.dst[du], k);
+            const __amdgpu_buffer_rsrc_t rm = rsrc(mm2 ? a.mask[du] : a.dst[du], k);
+            const __amdgpu_buffer_rsrc_t rad = rsrc(use_add2 ? a.addsrc : a.dst[du], k);
+            const float msl = mm2 == 1 ? 0.2f : 0.f;
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                f32x4 m2[MT][2], ad2[MT][2], pr2[MT][2];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        m2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        ad2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, use_add2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        pr2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, acc2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                    }
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj] + ad2[i][h]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) o[c] *= (m2[i][h][c] > 0.f || !mm2) ? 1.f : msl;
+                        o += pr2[i][h];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
+                    }
+            }
+        }
+    };
+
+    int it = 0, st = 0;
+#ifdef GXS_STAMPS
+    long long t_mfma = 0, t_epi = 0, t_bar = 0, t_top = 0, tlast_ = clock64(), tall = tlast_;
+#endif
+    GXS_BARRIER();                                                  // barrier 0
+    GXS_T(t_bar)
+    for (;;) {
+        GXS_T(t_top)
+        mfma_item(st, it & 1);
+        GXS_T(t_mfma)
+        if (cu.g == nitems - 1) epilogue(cu.tile);
+        GXS_T(t_epi)
+        step(cu);
+        if (!cu.ok) break;
+        GXS_BARRIER();
+        GXS_T(t_bar)
+        ++it; st = st == NSTAGE - 1 ? 0 : st + 1;
+    }
+#ifdef GXS_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    if (lane == 0) {
+        float* d = a.dst[0] + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+        d[0] = (float)t_mfma; d[1] = (float)t_epi; d[2] = (float)t_bar; d[3] = (float)t_top; d[4] = (float)(clock64() - tall); d[5] = (float)(it + 1);
+    }
+#endif
+}
+
+template <int BN, int WN, int EK>
+int launch_gxs(const IgemmArgs& a, hipStream_t s) {
+    using Cfg = GCfg<BN, WN>;
+    auto kern = gemm_x3s_kernel<BN, WN, EK>;
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int tiles = ((a.DW + 31) / 32) * ((a.DH + Cfg::TH - 1) / Cfg::TH) * a.B * ((a.Ntot + BN - 1) / BN);
+    if (tiles <= 0) return PNNP_OK;
+    const int wgs = pnnp_persistent_grid(tiles);
+    hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), Cfg::LDS_BYTES, s, a);
+    return pnnp_launch_status();
+}
+
+template <int BN, int WN>
+int launch_gxs_ek(const IgemmArgs& b, hipStream_t s) {
+    const bool two = b.dst[1] != nullptr;
+    const bool plain = !b.addsrc && !b.accum[0] && !(two && b.accum[1]);
+    const bool any_mask = b.mask_mode[0] || (two && b.mask_mode[1]);
+    if (plain && !any_mask) return launch_gxs<BN, WN, EK_FWD>(b, s);
+    if (plain) return launch_gxs<BN, WN, EK_BWD>(b, s);
+    return launch_gxs<BN, WN, EK_GEN>(b, s);
+}
+
+}  // namespace
+
+// `b`: validated by pnnp_gemm_x3_launch (csrc/gemm_x3.hip), with chunks_per_seg = 16-channel items per K segment.
+int pnnp_gemm_x3s_launch(const IgemmArgs& b, hipStream_t s) {
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    // the widest tile that still gives 3/4 of the CUs a tile: 256 px x 128, 512 px x 64, 256 px x 64; N = 32 (mod 64): 512 px x 32
+    const int64_t rows8 = (int64_t)((b.DW + 31) / 32) * ((b.DH + 7) / 8) * b.B, rows16 = (int64_t)((b.DW + 31) / 32) * ((b.DH + 15) / 16) * b.B;
+    if (b.Ntot % 128 == 0 && rows8 * (b.Ntot / 128) * 4 >= (int64_t)cus * 3) return launch_gxs_ek<128, 64>(b, s);
+    if (b.Ntot % 64 == 0) return rows16 * (b.Ntot / 64) * 4 >= (int64_t)cus * 3 ? launch_gxs_ek<64, 64>(b, s) : launch_gxs_ek<64, 32>(b, s);
+    return launch_gxs_ek<32, 32>(b, s);
+}

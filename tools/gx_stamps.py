@@ -18,8 +18,20 @@ else:
     w = torch.randn(co, ci, 1, 1, device=dev) * 0.02; f = u8(ops.x3mat_bytes(ci, co)); j = ops.PackJobs(); j.add_x3_1x1(w, f, None); j.run()
     x = torch.randn(B, h, h, ci // 2, device=dev); x2 = torch.randn(B, h, h, ci // 2, device=dev); y = torch.empty(B, h, h, co, device=dev)
     run = lambda: ops.conv1x1_x3_fwd(x, x2, f, None, y, co, 0); K = ci; N = co; px = B * h * h
+SPEC = os.environ.get('GXS', '0') == '1'
 for _ in range(3): run()
 torch.cuda.synchronize()
+if SPEC:
+    torch.cuda.synchronize()
+    wgs = 256
+    d = y.reshape(-1)[:wgs * 12 * 8].reshape(wgs, 12, 8).cpu()
+    for wv, names in ((0, ['mfma', 'epilogue', 'barrier', 'top', 'total', 'items']), (4, None), (8, ['request', 'split', 'vmwait', 'barrier', 'total', 'items']), (9, None)):
+        if names: cur_names = names
+        m = d[:, wv].mean(0)
+        items = float(m[5])
+        print(('consumer' if wv < 8 else 'producer'), wv, ' '.join(f'{n}={float(v) / items:.0f}' for n, v in zip(cur_names[:4], m)), f'total/item={float(m[4]) / items:.0f} items={items:.0f}')
+    print(f'{kind} {h} {ci}->{co} B={B}')
+    sys.exit(0)
 bn = 128 if (N % 128 == 0 and (px // 256) * (N // 128) * 4 >= 256 * 3) else 64
 tiles = (px // 256) * ((N + bn - 1) // bn)
 wgs = min(tiles, 256)
