@@ -34,8 +34,9 @@ PEAK_BF16_MFMA_TFLOPS = 2516.6     # MI355X_MICROARCH.md (~2.5 PF dense): v_mfma
 # dense peak, and what the kernel is.  `roofline.frac` = executed / peak (a hardware fraction, always <= 1).
 FAMILY = {
     'x3':     (6.0, PEAK_BF16_MFMA_TFLOPS, ('conv9_fwd_x3', 'conv9_dgrad_x3'),
-               "igemm_x3_kernel (conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: the six piece products of a block as "
-               "three v_mfma_f32_16x16x32_bf16 with two pieces concatenated along K, i.e. 6 executed bf16 FLOP per algorithmic FLOP, fp32 accumulation)"),
+               "igemm_x3s_kernel (csrc/conv_x3s.hip: conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: the six piece products of a "
+               "block as three v_mfma_f32_16x16x32_bf16 with two pieces concatenated along K, i.e. 6 executed bf16 FLOP per algorithmic FLOP, fp32 accumulation; "
+               "8 MFMA-only consumer waves + 4 producer waves per workgroup)"),
     'wino':   (16.0 / 36.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd_wino', 'conv9_dgrad_wino'),
                "wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 multiply-adds where the direct form has 36)"),
     'direct': (1.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd', 'conv9_dgrad'),

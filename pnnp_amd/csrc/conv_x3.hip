@@ -1371,7 +1371,7 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
             a.OW != a.DW || (a.pool_cs & 3) || a.pool_cs < a.Ntot || ((uintptr_t)a.pool_dst & 15) || ((uintptr_t)a.pool_codes & 3))
             return PNNP_E_UNSUPPORTED;
         if ((int64_t)(a.OH / 2) * (a.OW / 2) * a.pool_cs * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
-        if (X3_SPEC) return pnnp_igemm_x3s_launch(b, a.Ntot >= 64, s);
+        if (X3_SPEC && a.Ntot <= 1024) return pnnp_igemm_x3s_launch(b, a.Ntot >= 64, s);      // (conv_x3s keeps the bias vector in LDS: up to 1024 columns)
         return a.Ntot >= 64 ? launch_x3<64, EK_POOL>(b, s) : launch_x3<32, EK_POOL>(b, s);
     }
     // 64-column tiles unless they leave CUs idle: a layer with fewer (16 x 32 px x 64 ch) tiles than CUs (conv5_1 backward-data at
@@ -1380,7 +1380,7 @@ int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     if (cus < 1) cus = 256;
     const int64_t tiles64 = (int64_t)((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + 63) / 64);
     const bool wide = a.Ntot >= 64 && tiles64 * 4 >= (int64_t)cus * 3;
-    if (X3_SPEC) return pnnp_igemm_x3s_launch(b, wide, s);
+    if (X3_SPEC && a.Ntot <= 1024) return pnnp_igemm_x3s_launch(b, wide, s);
     // which epilogue (see the kernel template): forward, masked backward-data, or the general one
     const bool two = a.dst[1] != nullptr;
     const bool plain = !a.addsrc && !a.accum[0] && !(two && a.accum[1]);

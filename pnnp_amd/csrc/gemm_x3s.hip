@@ -333,46 +333,84 @@ gemm_x3s_kernel(const IgemmArgs a) {
             if (a.bias && blk_[j >> 1]) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + bch_[j >> 1] + 16 * (j & 1) + c4);
         }
         auto act4 = [&](f32x4 o) {
+            const f32x4 t = o * aslope;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], aslope * o[c]);
+            for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], t[c]);
             return o;
         };
         auto take = [&](int mb, int j) { const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; return v; };
         if constexpr (EK == EK_FWD || EK == EK_BWD) {
             constexpr bool MASKED = EK == EK_BWD;
-            f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];
+            // FULL-LINE memory pattern (csrc/conv_x3s.hip): the two 16-column blocks of a 32-column block trade halves between lanes p and p + 8
+            // of a 16-lane row, so that each 16-byte store instruction writes 8 pixels x 128 bytes (whole lines) instead of 16 x 64; the
+            // act' masks come in by the same pattern and are traded back.
+            const bool lo8 = p16 < 8;
+            auto ror8 = [&](f32x4 v) {
+                float r0, r1, r2, r3;
+                asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                             "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xf"
+                             : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                return f32x4{r0, r1, r2, r3};
+            };
+            auto sel = [&](bool c, f32x4 x, f32x4 y) { return f32x4{c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w}; };
+            // this lane's byte offsets in instruction 1 (pixel p16 & 7 of the half) and 2 (eight pixels on) of block k
+            unsigned wo[NTW][MT][2][2];
+            const int pxl = tl.x0 + (p16 & 7);
+#pragma unroll
+            for (int k = 0; k < NTW; ++k) {
+                const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + wn * WN + k * 32);
+                const int subu = a.n_sub ? nwv / a.n_sub : 0;
+                const int chw = nwv - subu * a.n_sub - (du_[k] ? a.n_split : 0);
+                const int yo2 = a.out_yoff + (subu >> 1), xo2 = a.out_xoff + (subu & 1);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int py = py0 + i, px = pxl + 16 * h + 8 * e;
+                            const int oy = py * a.out_mul + yo2, ox = px * a.out_mul + xo2;
+                            const bool ok = blk_[k] && py < a.DH && px < a.DW && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+                            wo[k][i][h][e] = ok ? (unsigned)(((oy * a.OW + ox) * cs_[k] + chw + (lo8 ? 0 : 16) + c4) * 4) : OOB;
+                        }
+            }
+            f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];              // [.][2 k] = what instruction 1 fetched, [.][2 k + 1] = instruction 2
             if constexpr (MASKED) {
 #pragma unroll
                 for (int k = 0; k < NTW; ++k) {
                     const int mm = a.mask_mode[du_[k]];
                     const __amdgpu_buffer_rsrc_t rm = rsrc(mm ? a.mask[du_[k]] : a.dst[du_[k]], k);
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-                        for (int i = 0; i < MT; ++i)
+                        for (int h = 0; h < 2; ++h)
 #pragma unroll
-                            for (int h = 0; h < 2; ++h)
-                                mk[2 * i + h][2 * k + jj] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm ? vo[k][i][h] : OOB, jj * 64, 0));
+                            for (int e = 0; e < 2; ++e)
+                                mk[2 * i + h][2 * k + e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm ? wo[k][i][h][e] : OOB, 0, 0));
                 }
             }
 #pragma unroll
             for (int k = 0; k < NTW; ++k) {
                 const __amdgpu_buffer_rsrc_t rd = rsrc(a.dst[du_[k]], k);
                 const int mm = a.mask_mode[du_[k]];
-                const float msl = mm == 1 ? 0.2f : 0.f;
+                const float msl = mm == 1 ? 0.2f : (mm == 0 ? 1.f : 0.f);      // act'(x <= 0); 1 for a destination without a mask
 #pragma unroll
-                for (int jj = 0; jj < 2; ++jj)
+                for (int i = 0; i < MT; ++i)
 #pragma unroll
-                    for (int i = 0; i < MT; ++i)
+                    for (int h = 0; h < 2; ++h) {
+                        f32x4 o0 = take(2 * i + h, 2 * k), o1 = take(2 * i + h, 2 * k + 1);
+                        if constexpr (!MASKED) { o0 = act4(o0 + bias4[2 * k]); o1 = act4(o1 + bias4[2 * k + 1]); }      // (backward-data: no bias, no activation -- the launcher checks)
+                        if constexpr (MASKED) {
+                            const f32x4 m1 = mk[2 * i + h][2 * k], m2 = mk[2 * i + h][2 * k + 1], mx = ror8(sel(lo8, m2, m1));
+                            const f32x4 q0 = sel(lo8, m1, mx), q1 = sel(lo8, mx, m2);
+                            const f32x4 t0 = o0 * msl, t1 = o1 * msl;
 #pragma unroll
-                        for (int h = 0; h < 2; ++h) {
-                            f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj]);
-                            if constexpr (MASKED) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) o[c] *= (mk[2 * i + h][2 * k + jj][c] > 0.f || !mm) ? 1.f : msl;
-                            }
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
+                            for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
                         }
+                        const f32x4 ox = ror8(sel(lo8, o1, o0));
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h][0], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo[k][i][h][1], 0, 0);
+                    }
             }
             return;
         }
@@ -456,7 +494,7 @@ int launch_gxs_ek(const IgemmArgs& b, hipStream_t s) {
     const bool plain = !b.addsrc && !b.accum[0] && !(two && b.accum[1]);
     const bool any_mask = b.mask_mode[0] || (two && b.mask_mode[1]);
     if (plain && !any_mask) return launch_gxs<BN, WN, EK_FWD>(b, s);
-    if (plain) return launch_gxs<BN, WN, EK_BWD>(b, s);
+    if (plain && !b.act && !b.bias) return launch_gxs<BN, WN, EK_BWD>(b, s);
     return launch_gxs<BN, WN, EK_GEN>(b, s);
 }
 

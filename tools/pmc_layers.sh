@@ -16,7 +16,7 @@ names = sorted({c for v in agg.values() for c in v})
 w = csv.writer(open(sys.argv[2], 'w', newline=''))
 w.writerow(['dispatch', 'kernel', 'grid', 'lds'] + names)
 for k, v in agg.items():
-    if 'igemm' in k[1] or 'wino' in k[1] or 'wgrad' in k[1]:
+    if 'igemm' in k[1] or 'wino' in k[1] or 'wgrad' in k[1] or 'gemm_x3' in k[1]:
         w.writerow(list(k) + [v.get(n, '') for n in names])
 PY
 tail -5 gpurun_out/pmc_layers_$TAG.txt

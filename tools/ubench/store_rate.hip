@@ -20,7 +20,9 @@ __global__ void __launch_bounds__(512, 1) store_kernel(float* dst, long long wg_
     if (KIND == 0) { vo = (wave * 64 + lane) * 16; step = 8 * 1024; }
     else if (KIND == 1) { vo = (wave * 64 + lane) * 4; step = 8 * 256; }
     else if (KIND == 2) { vo = ((wave * 64 + 4 * (lane >> 4)) * cs + (lane & 15)) * 4; step = 4; }      // r = 0..3 -> + cs floats; 16 columns on: + 64 B
-    else { vo = ((wave * 64 + 4 * (lane >> 5)) * cs + (lane & 31)) * 4; step = 4; }
+    else if (KIND == 3) { vo = ((wave * 64 + 4 * (lane >> 5)) * cs + (lane & 31)) * 4; step = 4; }
+    else if (KIND == 4) { vo = ((wave * 64 + (lane & 15)) * cs + (lane >> 4) * 4) * 4; step = 64; }       // b128: 16 pixels x 64 B per instruction (conv_x3s epilogue)
+    else { vo = ((wave * 64 + (lane >> 3)) * cs + (lane & 7) * 4) * 4; step = 128; }                    // b128: 8 pixels x 128 B per instruction (round 3's LDS-patch epilogue)
     const u32x4 v = {(unsigned)tid, 1u, 2u, 3u};
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
@@ -32,6 +34,12 @@ __global__ void __launch_bounds__(512, 1) store_kernel(float* dst, long long wg_
             // (i & 3) = r (next pixel), (i >> 2) & 3 = 16-channel block (cs = 64: 4 blocks), then 16 pixels on, then the next 64-pixel group of the wave
             const int r = i & 3, j = (i >> 2) & 3, h = (i >> 4) & 3, rest = i >> 6;
             __builtin_amdgcn_raw_buffer_store_b32(v[0], rd, vo, ((r + 16 * h + 512 * rest) * cs + 16 * j) * 4, 0);
+        } else if (KIND == 4) {
+            const int j = i & 3, h = (i >> 2) & 3, rest = i >> 4;          // 4 x 16-channel blocks of a pixel, then 16 pixels on
+            __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, ((16 * h + 512 * rest) * cs + 16 * j) * 4, 0);
+        } else if (KIND == 5) {
+            const int j = i & 1, h = (i >> 1) & 7, rest = i >> 4;          // 2 x 32-channel blocks, then 8 pixels on
+            __builtin_amdgcn_raw_buffer_store_b128(v, rd, vo, ((8 * h + 512 * rest) * cs + 32 * j) * 4, 0);
         } else {
             const int r = i & 3, g = (i >> 2) & 3, j = (i >> 4) & 1, rest = i >> 5;       // rows r + 8 g (+ 4 by the lane half), 32-channel block j
             __builtin_amdgcn_raw_buffer_store_b32(v[0], rd, vo, ((r + 8 * g + 512 * rest) * cs + 32 * j) * 4, 0);
@@ -69,5 +77,7 @@ int main(int argc, char** argv) {
     run<2>(wgs, n, dst, stride, out, "dword 16x16 accumulator layout", 256);
     run<3>(wgs, n, dst, stride, out, "dword 32x32 accumulator layout", 256);
     run<0>(wgs, n / 4, dst, stride, out, "dwordx4, same bytes as the dwords", 1024);
+    run<4>(wgs, n, dst, stride, out, "dwordx4, 16 px x 64 B (cs = 64)", 1024);
+    run<5>(wgs, n, dst, stride, out, "dwordx4, 8 px x 128 B (cs = 64)", 1024);
     return 0;
 }
