@@ -37,6 +37,9 @@ cp gpurun_out/aux_kernels.json gpurun_out/aux_kernel_stats.csv $OUT/ 2>/dev/null
 timeout 300 python tools/eval_bench.py > $OUT/eval_bench.txt 2>&1
 timeout 300 python tools/convt_wgrad_bench.py > $OUT/convt_wgrad_bench.txt 2>&1
 timeout 300 python tools/layer_bench.py --x3 > $OUT/layer_bench.txt 2>&1
+timeout 300 python tools/pointwise_bench.py > $OUT/pointwise_bench.txt 2>&1
+PW_REPS=1 timeout 600 bash tools/pmc_prog.sh pointwise 'SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY' gemm_x3s tools/pointwise_bench.py > /dev/null 2>&1
+cp gpurun_out/pmc_pointwise.csv $OUT/ 2>/dev/null
 timeout 200 python tools/squat_test.py 32 > $OUT/squat_test.txt 2>&1
 # steady-state API sequence of one config-5 step (memcpys / memsets / launches per step)
 cd /tmp; rm -rf /tmp/rp_api
