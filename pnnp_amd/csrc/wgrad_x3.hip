@@ -28,6 +28,12 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+#ifndef WX3_SPEC
+#define WX3_SPEC 1               // 1: layers with channel counts in multiples of 64 run on csrc/wgrad_x3s.hip (12 consumer + 4 producer waves)
+#endif
+struct Wx3sArgs { const float* G; int Gcs; const float* X[2]; int Xcs[2]; int n_split; int B, H, W, M, N; float* slab; float* bias_slab; int Z; };
+int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s);           // csrc/wgrad_x3s.hip
+
 namespace {
 
 struct Wx3Args {
@@ -583,10 +589,13 @@ int wx3_shape(int M, int N) {
 }
 int wx3_th(int shape) { return shape == 4 ? 1 : (shape == 0 ? 4 : 2); }
 
+bool wx3_spec(int M, int N) { return WX3_SPEC && M % 64 == 0 && N % 64 == 0; }
+
 int wx3_splits(int B, int H, int W, int M, int N) {
     const int shape = wx3_shape(M, N);
-    const int bm = shape == 4 ? 128 : ((shape & 1) ? 64 : 32), bn = shape == 4 ? 64 : ((shape & 2) ? 64 : 32);
-    const int th = wx3_th(shape);
+    const bool spec = wx3_spec(M, N);                               // csrc/wgrad_x3s.hip: 64 x 64 output tiles, two-row pixel tiles
+    const int bm = spec ? 64 : (shape == 4 ? 128 : ((shape & 1) ? 64 : 32)), bn = spec ? 64 : (shape == 4 ? 64 : ((shape & 2) ? 64 : 32));
+    const int th = spec ? 2 : wx3_th(shape);
     const int tiles = ((W + 31) / 32) * ((H + th - 1) / th) * B;
     const int out_tiles = (M / bm) * (N / bn);
     int cus = pnnp_device_cus();
@@ -647,6 +656,12 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
     a.slab = workspace;
     a.bias_slab = dbias ? workspace + (int64_t)a.Z * 9 * Cout * N : nullptr;
     int rc;
+    if (wx3_spec(Cout, N)) {
+        Wx3sArgs b{};
+        b.G = a.G; b.Gcs = a.Gcs; b.X[0] = a.X[0]; b.X[1] = a.X[1]; b.Xcs[0] = a.Xcs[0]; b.Xcs[1] = a.Xcs[1]; b.n_split = a.n_split;
+        b.B = a.B; b.H = a.H; b.W = a.W; b.M = a.M; b.N = a.N; b.slab = a.slab; b.bias_slab = a.bias_slab; b.Z = a.Z;
+        rc = pnnp_wx3s_launch(b, st);
+    } else
     switch (wx3_shape(Cout, N)) {
         case 4: rc = launch_wx3<4, 2, 1>(a, st); break;
         case 3: rc = launch_wx3<2, 2, 2>(a, st); break;

@@ -132,6 +132,36 @@ def test_x3_is_as_accurate_as_the_fp32_mfma_kernel():
     assert e3 < 2.0 * e32 + 1e-8 and e3 < 5e-7
 
 
+@pytest.mark.parametrize('case', [(2, 8, 32, 32, 32, 64), (1, 9, 33, 64, 64, 32), (1, 16, 64, 128, 128, 64)])
+def test_x3_bwd_data_mask_on_the_second_destination_only(case):
+    """Backward-data of a decoder's first conv (archs/Unet.py:74-93: cat([up, skip])): the `up` half has no activation behind it, the skip half
+    does -- one launch, act' mask on destination 2 only (the masked-epilogue kernel requests the missing mask out of range)."""
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2)
+    g = _rand(B, Co, H, W, seed=5)
+    xin = _rand(B, C1 + C2, H, W, seed=6).requires_grad_(True)
+    F.conv2d(xin, w, None, padding=1).backward(g)
+    ref = xin.grad
+    _, dg = _packs(w.cuda(), fwd=False)
+    m2 = _rand(B, C2, H, W, seed=8)
+    d1 = torch.full((B, H, W, C1), float('nan'), device='cuda'); d2 = torch.full((B, H, W, C2), float('nan'), device='cuda')
+    ops.conv_x3_bwd_data(nhwc(g).cuda(), dg, d1, dx2=d2, mask2=nhwc(m2).cuda(), mode2=1)
+    close(nchw(d1), ref[:, :C1], what=f'x3 dgrad dst1 (no mask) {case}')
+    close(nchw(d2), ref[:, C1:] * torch.where(m2 > 0, 1.0, 0.2), what=f'x3 dgrad dst2 (LeakyReLU mask) {case}')
+
+
+def test_x3_more_output_channels_than_the_bias_buffer_holds():
+    """csrc/conv_x3s.hip keeps the bias vector in LDS (1024 channels); wider layers take round 3's kernel: same results, same contract."""
+    from pnnp_amd import ops
+    B, H, W, Ci, Co = 1, 16, 32, 32, 1088
+    x = _rand(B, Ci, H, W, seed=1); w = _rand(Co, Ci, 3, 3, seed=3, scale=0.2); b = _rand(Co, seed=4)
+    f, _ = _packs(w.cuda(), dgrad=False)
+    y = torch.full((B, H, W, Co), float('nan'), device='cuda')
+    ops.conv_x3_fwd(nhwc(x).cuda(), None, f, b.cuda(), y, Co, 1)
+    close(nchw(y), F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2), what='x3 fwd 1088 output channels')
+
+
 @pytest.mark.parametrize('case', [(2, 16, 48, 32, 0, 32), (1, 12, 40, 32, 0, 64), (1, 6, 70, 64, 0, 128), (2, 8, 32, 32, 32, 32),
                                   (1, 8, 36, 64, 64, 64), (1, 5, 17, 128, 128, 128), (1, 4, 4, 256, 0, 256), (1, 16, 32, 32, 0, 256),
                                   (3, 32, 64, 32, 0, 32), (2, 16, 32, 64, 64, 64), (3, 19, 50, 64, 32, 96), (1, 9, 33, 96, 0, 32)])
