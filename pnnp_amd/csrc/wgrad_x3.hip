@@ -29,10 +29,11 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef WX3_SPEC
-#define WX3_SPEC 1               // 1: layers with channel counts in multiples of 64 run on csrc/wgrad_x3s.hip (12 consumer + 4 producer waves)
+#define WX3_SPEC 1               // 1: csrc/wgrad_x3s.hip (12 consumer + 4 producer waves; output tiles 64 x 64, 64 x 32, 32 x 64, 32 x 32); 0: the kernel below
 #endif
 struct Wx3sArgs { const float* G; int Gcs; const float* X[2]; int Xcs[2]; int n_split; int B, H, W, M, N; float* slab; float* bias_slab; int Z; };
 int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s);           // csrc/wgrad_x3s.hip
+int pnnp_wx3s_th(int M, int N);                                     // its pixel-tile height for (M, N)
 
 namespace {
 
@@ -589,13 +590,13 @@ int wx3_shape(int M, int N) {
 }
 int wx3_th(int shape) { return shape == 4 ? 1 : (shape == 0 ? 4 : 2); }
 
-bool wx3_spec(int M, int N) { return WX3_SPEC && M % 64 == 0 && N % 64 == 0; }
+bool wx3_spec(int, int) { return WX3_SPEC != 0; }
 
 int wx3_splits(int B, int H, int W, int M, int N) {
     const int shape = wx3_shape(M, N);
-    const bool spec = wx3_spec(M, N);                               // csrc/wgrad_x3s.hip: 64 x 64 output tiles, two-row pixel tiles
-    const int bm = spec ? 64 : (shape == 4 ? 128 : ((shape & 1) ? 64 : 32)), bn = spec ? 64 : (shape == 4 ? 64 : ((shape & 2) ? 64 : 32));
-    const int th = spec ? 2 : wx3_th(shape);
+    const bool spec = wx3_spec(M, N);                               // csrc/wgrad_x3s.hip: its own tiles
+    const int bm = spec ? (M % 64 == 0 ? 64 : 32) : (shape == 4 ? 128 : ((shape & 1) ? 64 : 32)), bn = spec ? (N % 64 == 0 ? 64 : 32) : (shape == 4 ? 64 : ((shape & 2) ? 64 : 32));
+    const int th = spec ? pnnp_wx3s_th(M, N) : wx3_th(shape);
     const int tiles = ((W + 31) / 32) * ((H + th - 1) / th) * B;
     const int out_tiles = (M / bm) * (N / bn);
     int cus = pnnp_device_cus();

@@ -1,14 +1,16 @@
 // Weight gradient of a 3x3 / stride 1 / pad 1 convolution on the bf16 matrix cores with SPECIALISED waves (round 4) -- the arithmetic, the LDS
-// images, the slabs and the reduce of csrc/wgrad_x3.hip, for layers whose channel counts are multiples of 64.
+// images, the slabs and the reduce of csrc/wgrad_x3.hip.
 //
 // wgrad_x3.hip's eight waves each carry a 32 x 32 x 9-tap accumulator block (144 registers) and split their share of the next pixel tile
 // between their own MFMAs; a wave's own vector instructions are ADDED to its MFMA time (tools/ubench/mfma_valu_coissue.hip), and 144 + operands
 // leave no room for a third wave per SIMD.  Here a workgroup is
-//   12 CONSUMER waves (three per SIMD): wave (mo, no, tr) owns the 32 x 32 block (mo, no) of a 64 x 64 output tile for the three taps of filter
-//     ROW tr -- 48 accumulator registers -- and issues transposed LDS reads + MFMAs only;
-//   4 PRODUCER waves (one per SIMD): the next pixel tile (G: 2 rows x 32 px x 64 channels, X: its 4 x 34 halo x 64 channels) fp32 global ->
-//     registers (one tile ahead) -> hi / mid / lo split -> the other LDS image; the bias gradient (column sums of G) on the way.
-// 1024 threads, <= 128 registers each, one barrier per pixel tile (72 MFMAs per consumer).
+//   12 CONSUMER waves (three per SIMD): wave (mo, no, tr, wk) owns the 32 x 32 block (mo, no) of a (32 MO) x (32 NO) output tile for the three
+//     taps of filter ROW tr -- 48 accumulator registers -- and 1 / WK of a pixel tile's k-steps (WK = 4 / (MO NO): 64 x 64 tiles have one
+//     consumer per (block, row), 32 x 32 tiles four that are summed through LDS at the end); transposed LDS reads + MFMAs only;
+//   4 PRODUCER waves (one per SIMD): the next pixel tile (G: TH rows x 32 px, X: its (TH + 2) x 34 halo) fp32 global -> registers (one tile
+//     ahead) -> hi / mid / lo split -> the other LDS image; the bias gradient (column sums of G) on the way.
+// 1024 threads, <= 128 registers each, one barrier per pixel tile.  (The 16 x 16 x 32 MFMA shape was tried in this kernel too -- commit 936596b,
+// WXS_M16: parity-green, 44 transposed reads per k-step instead of 24, 4-5 % slower; profiles/r4/ab_wgrad_specialised.txt.)
 #include "common.h"
 #include <type_traits>
 
@@ -33,19 +35,24 @@ int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s);
 namespace {
 
 constexpr int NCW = 12, NPW = 4, NTHR = 64 * (NCW + NPW);
-constexpr int TH = 2, KS = TH * 2;                                 // pixel tile: 2 rows x 32 px = four 16-pixel k-steps
-constexpr int GPIX = TH * 32, XR = TH + 2, XC = 34, XPIX = XR * XC; // 64 / 136 pixels
-constexpr int G_BYTES = 2 * 3 * GPIX * 64, X_BYTES = 2 * 3 * XPIX * 64, IMG_BYTES = G_BYTES + X_BYTES, LDS_BYTES = 2 * IMG_BYTES;   // 24576 + 52224; 153600
-constexpr int NG = GPIX * 8 / 128, NX = (XPIX * 8 + 127) / 128;    // float4 staging slots per producer thread: 4 of G, 9 of X (two waves per 32-channel block)
-static_assert(LDS_BYTES <= 160 * 1024 && (GPIX * 8) % 128 == 0, "LDS budget; G slots divide evenly (bias sums count every pixel once)");
+constexpr int XC = 34;
 constexpr unsigned OOB = 0x80000000u;
 #define WXS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#ifndef WXS_M16
-#define WXS_M16 0                      // 1: v_mfma_f32_16x16x32_bf16 with two pieces concatenated along K (parity-green, but 4-5 % SLOWER than 0 =
-#endif                                 //    v_mfma_f32_32x32x16_bf16: 44 transposed reads per k-step instead of 24; profiles/r4/ab_wgrad_specialised.txt)
 #ifndef WX3_ALT_SIGN
 #define WX3_ALT_SIGN 1                 // odd pixel splits accumulate -G * X (csrc/wgrad_x3.hip: the matrix core's accumulation rounds toward minus infinity)
 #endif
+
+template <int MO, int NO, int TH> struct WsCfg {
+    static constexpr int WK = 4 / (MO * NO);                       // consumers that share a (block, filter row): pixel split inside the workgroup
+    static constexpr int KS = TH * 2, KSW = KS / WK;               // 16-pixel k-steps per pixel tile; per consumer
+    static constexpr int GPIX = TH * 32, XPIX = (TH + 2) * XC;
+    static constexpr int G_BYTES = MO * 3 * GPIX * 64, X_BYTES = NO * 3 * XPIX * 64, IMG_BYTES = G_BYTES + X_BYTES, LDS_BYTES = 2 * IMG_BYTES;
+    static constexpr int GT = 256 / MO, XT = 256 / NO;             // producer threads per 32-channel block of G / X
+    static constexpr int NG = GPIX * 8 / GT, NX = (XPIX * 8 + XT - 1) / XT;      // float4 staging slots per producer thread
+    static_assert(MO * NO * WK == 4 && KSW * WK == KS, "wave layout");
+    static_assert((GPIX * 8) % GT == 0, "G slots divide evenly (the bias sums count every pixel once)");
+    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NCW * 16 * 64 * 4, "LDS budget (images; the final reduction aliases them)");
+};
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {      // RNE, low half = a
     unsigned r; asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
@@ -58,54 +65,53 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
     l = cvt_pk_bf16(s0, s1);
 }
 
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
+template <int MO, int NO, int TH>
 __global__ void __launch_bounds__(NTHR, 1)
 wgrad_x3s_kernel(const Wx3sArgs a) {
+    using Cfg = WsCfg<MO, NO, TH>;
+    constexpr int WK = Cfg::WK, KSW = Cfg::KSW, GPIX = Cfg::GPIX, XPIX = Cfg::XPIX, G_BYTES = Cfg::G_BYTES, IMG_BYTES = Cfg::IMG_BYTES, NG = Cfg::NG, NX = Cfg::NX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0 .. 11 consumers, 12 .. 15 producers
 
-    const int n_tiles = a.N / 64;
+    const int n_tiles = a.N / (32 * NO);
     int id = blockIdx.x;
     const int z = id % a.Z; id /= a.Z;
     const int ni = id % n_tiles, mi = id / n_tiles;
-    const int m0 = mi * 64, n0 = ni * 64;
+    const int m0 = mi * 32 * MO, n0 = ni * 32 * NO;
     const int tiles_x = (a.W + 31) >> 5, tiles_y = (a.H + TH - 1) / TH;
     const int ntile = tiles_x * tiles_y * a.B;
     if (z >= ntile) return;                                          // (Z <= ntile: never)
 
     if (wave >= NCW) {
         // =============================================== PRODUCER ===============================================
-        const int pw = wave - NCW, blk = pw >> 1;                    // this wave stages 32-channel block blk of G and of X, with one other wave
-        const int lt = (pw & 1) * 64 + lane;                         // 0 .. 127
+        const int pw = wave - NCW;
         const int q8 = lane & 7;                                     // channel quad of the block (8 lanes read a pixel's 128 contiguous bytes)
+        // the waves that stage 32-channel block gblk of G (GT threads) / xblk of X (XT threads): wave-uniform, like the tensors behind them
+        const int gblk = MO == 2 ? pw >> 1 : 0, lg = MO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
+        const int xblk = NO == 2 ? pw >> 1 : 0, lx = NO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
         unsigned g_off[NG]; int g_r[NG], g_c[NG], g_dst[NG];
 #pragma unroll
         for (int k = 0; k < NG; ++k) {
-            const int pix = (lt + 128 * k) >> 3;
+            const int pix = (lg + Cfg::GT * k) >> 3;
             g_r[k] = pix >> 5; g_c[k] = pix & 31;
             g_off[k] = (unsigned)((g_r[k] * a.W + g_c[k]) * a.Gcs + q8 * 4) * 4u;
-            g_dst[k] = WXS_M16 ? blk * 3 * GPIX * 64 + ((q8 >> 2) * GPIX + pix) * 32 + (q8 & 3) * 8      // [block][piece][16-channel half][pixel][32 B]
-                               : (blk * 3 * GPIX + pix) * 64 + q8 * 8;                                   // [block][piece][pixel][64 B]; + piece * GPIX * 64
+            g_dst[k] = (gblk * 3 * GPIX + pix) * 64 + q8 * 8;       // byte offset in an image; + piece * GPIX * 64
         }
-        const int xd = (n0 + 32 * blk >= a.n_split) ? 1 : 0;         // wave-uniform source of this wave's X block
-        const int xch0 = n0 + 32 * blk - (xd ? a.n_split : 0);
+        const int xd = (n0 + 32 * xblk >= a.n_split) ? 1 : 0;        // wave-uniform source of this wave's X block
+        const int xch0 = n0 + 32 * xblk - (xd ? a.n_split : 0);
         const int xcs = a.Xcs[xd];
         unsigned x_off[NX]; int x_r[NX], x_c[NX], x_dst[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
-            int j = lt + 128 * k;
-            if (j >= XPIX * 8) j -= 128;                             // a slot past the end repeats the thread's previous one
+            int j = lx + Cfg::XT * k;
+            if (j >= XPIX * 8) j -= Cfg::XT;                         // a slot past the end repeats the thread's previous one
             const int pix = j >> 3;
             x_r[k] = pix / XC; x_c[k] = pix - x_r[k] * XC;          // halo coordinates: image pixel (y0 - 1 + r, x0 - 1 + c)
             x_off[k] = (unsigned)((x_r[k] * a.W + x_c[k]) * xcs + q8 * 4) * 4u;
-            x_dst[k] = G_BYTES + (WXS_M16 ? blk * 3 * XPIX * 64 + ((q8 >> 2) * XPIX + pix) * 32 + (q8 & 3) * 8 : (blk * 3 * XPIX + pix) * 64 + q8 * 8);
+            x_dst[k] = G_BYTES + (xblk * 3 * XPIX + pix) * 64 + q8 * 8;
         }
-        const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * blk), 0, 0x7fffffff, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * gblk), 0, 0x7fffffff, 0x00020000);
         const int xshift = (a.W + 1) * xcs;                          // the X resource starts one row + one pixel BEFORE the tensor
         const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X[xd] + xch0 - xshift), 0, 0x7fffffff, 0x00020000);
         f32x4 rg[NG], rx[NX];
@@ -166,27 +172,34 @@ wgrad_x3s_kernel(const Wx3sArgs a) {
             }
             img ^= 1;
         }
-        // ---- bias gradient of this pixel split: add up the threads that share (blk, q8) through LDS (the images are dead)
-        WXS_BARRIER();
-        if (a.bias_slab && ni == 0) {                               // block-uniform
-            float* bs = reinterpret_cast<float*>(smem);             // [2 blocks][8 quads][4][16 slots]
-            const int slot = (pw & 1) * 8 + (lane >> 3);
+        // ---- (the consumers' pixel-split reduction: 2 barriers per tap of a row when WK > 1) then the bias gradient of this pixel split: add up
+        // the threads that share (block, q8) through LDS (the images are dead)
+        if (WK > 1) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) bs[((blk * 8 + q8) * 4 + c) * 16 + slot] = bsum[c];
+            for (int i = 0; i < 6; ++i) WXS_BARRIER();
         }
         WXS_BARRIER();
-        if (a.bias_slab && ni == 0 && pw < 1) {                      // one producer wave: 64 channels
+        constexpr int NSLOTS = Cfg::GT / 8;                           // threads per (block, quad)
+        if (a.bias_slab && ni == 0) {                               // block-uniform
+            float* bs = reinterpret_cast<float*>(smem);             // [MO blocks][8 quads][4][NSLOTS]
+            const int slot = lg >> 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bs[((gblk * 8 + q8) * 4 + c) * NSLOTS + slot] = bsum[c];
+        }
+        WXS_BARRIER();
+        if (a.bias_slab && ni == 0 && pw < 1 && lane < 32 * MO) {    // one producer wave: 32 MO channels
             float* bs = reinterpret_cast<float*>(smem);
             const int b2 = lane >> 5, ch = lane & 31;
             float s = 0.f;
-            for (int k = 0; k < 16; ++k) s += bs[((b2 * 8 + (ch >> 2)) * 4 + (ch & 3)) * 16 + k];
+            for (int k = 0; k < NSLOTS; ++k) s += bs[((b2 * 8 + (ch >> 2)) * 4 + (ch & 3)) * NSLOTS + k];
             a.bias_slab[(int64_t)z * a.M + m0 + b2 * 32 + ch] = (WX3_ALT_SIGN && (z & 1)) ? -s : s;      // (the reduce kernel adds odd splits with a minus sign)
         }
         return;
     }
 
     // =============================================== CONSUMER ===============================================
-    const int tr = wave % 3, no = (wave / 3) & 1, mo = wave / 6;    // filter row, 32-column block, 32-row block
+    const int tr = wave % 3, rest = wave / 3;                        // filter row; (block, pixel split)
+    const int wk = rest % WK, no = (rest / WK) % NO, mo = rest / (WK * NO);
     const int l31 = lane & 31, half = lane >> 5;
     f32x16 acc[3];
 #pragma unroll
@@ -207,58 +220,15 @@ wgrad_x3s_kernel(const Wx3sArgs a) {
         WXS_BARRIER();
         const char* gimg = smem + img * IMG_BYTES;
         const char* ximg = gimg + G_BYTES;
-#if WXS_M16
-        // 16 x 16 x 32 with two PIECES concatenated along K (csrc/wgrad_x3.hip WX3_M16, csrc/conv_x3.hip): the LDS images keep the two 16-channel
-        // halves of a block in separate planes; k-block (lane >> 4) & 1 takes pixels {0-3, 8-11} or {4-7, 12-15} of the k-step; lanes 0-31 read the
-        // first piece of a form, lanes 32-63 the second.  Forms: A0 = [hi | mid], A1 = [hi | lo]; B0 = [hi' | hi'], B1 = [mid' | mid'], B2 = [lo' | hi'].
-        const int lb = ((((lane >> 4) & 1) * 4 + ((lane & 15) >> 2)) * 32) + (lane & 3) * 8, hi2 = lane >> 5;
-        constexpr int PSG = GPIX * 64, PSX = XPIX * 64;
-        const int la0 = lb + hi2 * PSG, la1 = lb + hi2 * 2 * PSG, lb2 = lb + (1 - hi2) * 2 * PSX;
-        auto half_read = [&](const char* base) {
-            return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base)));
-        };
-        auto a_base = [&](int ks, int mh, int f) { return gimg + (mo * 3) * PSG + (mh * GPIX + (ks >> 1) * 32 + (ks & 1) * 16) * 32 + (f ? la1 : la0); };
-        auto b_base = [&](int ks, int dx, int nh, int f) {
-            return ximg + (no * 3) * PSX + (nh * XPIX + ((ks >> 1) + tr) * XC + (ks & 1) * 16 + dx) * 32 + (f == 0 ? lb : (f == 1 ? lb + PSX : lb2));
-        };
-        auto put_half = [](u32x4& d, int h, u32x2 v) { if (h == 0) { d.x = v.x; d.y = v.y; } else { d.z = v.x; d.w = v.y; } };
-        u32x4 Av[2][2][2], Bv[2][3];                                 // [k-step parity][16-row half][form], [step parity][form]
-#pragma unroll
-        for (int mh = 0; mh < 2; ++mh)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) { put_half(Av[0][mh][f], 0, half_read(a_base(0, mh, f))); put_half(Av[0][mh][f], 1, half_read(a_base(0, mh, f) + 256)); }
-#pragma unroll
-        for (int f = 0; f < 3; ++f) { put_half(Bv[0][f], 0, half_read(b_base(0, 0, 0, f))); put_half(Bv[0][f], 1, half_read(b_base(0, 0, 0, f) + 256)); }
-        constexpr int NSTEP = KS * 6;                                // steps (k-step, tap, 16-column half) of six MFMAs
-        static_for<0, NSTEP * 6>([&](auto GI) {
-            constexpr int gi = decltype(GI)::value, S = gi / 6, Gq = gi % 6, ks = S / 6, st = S % 6, dx = st / 2, nh = st % 2, mh = Gq / 3, pr = Gq % 3;
-            constexpr int cur = S & 1;
-            if constexpr (Gq == 0) __builtin_amdgcn_sched_barrier(0);
-            f32x4 c4 = {acc[dx][4 * (2 * mh + nh)], acc[dx][4 * (2 * mh + nh) + 1], acc[dx][4 * (2 * mh + nh) + 2], acc[dx][4 * (2 * mh + nh) + 3]};
-            if constexpr (pr == 0) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][1]), __builtin_bit_cast(bf16x8, Bv[cur][2]), c4, 0, 0, 0);
-            else if constexpr (pr == 1) c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][0]), __builtin_bit_cast(bf16x8, Bv[cur][1]), c4, 0, 0, 0);
-            else c4 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, Av[ks & 1][mh][0]), __builtin_bit_cast(bf16x8, Bv[cur][0]), c4, 0, 0, 0);
-            acc[dx][4 * (2 * mh + nh)] = c4.x; acc[dx][4 * (2 * mh + nh) + 1] = c4.y; acc[dx][4 * (2 * mh + nh) + 2] = c4.z; acc[dx][4 * (2 * mh + nh) + 3] = c4.w;
-            // the next step's B words: one transposed read per gap (form Gq / 2, half Gq % 2)
-            if constexpr (S + 1 < NSTEP) {
-                constexpr int S1 = S + 1, ks1 = S1 / 6, dx1 = (S1 % 6) / 2, nh1 = S1 % 2;
-                put_half(Bv[cur ^ 1][Gq >> 1], Gq & 1, half_read(b_base(ks1, dx1, nh1, Gq >> 1) + (Gq & 1) * 256));
-            }
-            // the next k-step's A words: eight reads in the gaps of its predecessor's last two steps
-            if constexpr (ks + 1 < KS && st >= 4) {
-                constexpr int j = (st - 4) * 6 + Gq;
-                if constexpr (j < 8) put_half(Av[(ks + 1) & 1][j >> 2][(j >> 1) & 1], j & 1, half_read(a_base(ks + 1, j >> 2, (j >> 1) & 1) + (j & 1) * 256));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        });
-#else
         u32x4 av[2][3], bv[2][3];
-        auto gload = [&](int ks, u32x4 (&ax)[3]) {
+        auto gload = [&](int kl, u32x4 (&ax)[3]) {                   // kl: this consumer's kl-th k-step of the tile
+            const int ks = wk * KSW + kl;
             const char* gbase = gimg + ((mo * 3) * GPIX + (ks >> 1) * 32 + (ks & 1) * 16) * 64 + tr_lane;
 #pragma unroll
             for (int p = 0; p < 3; ++p) ax[p] = tr_read(gbase + p * GPIX * 64);
         };
-        auto xload = [&](int ks, int dx, u32x4 (&bx)[3]) {
+        auto xload = [&](int kl, int dx, u32x4 (&bx)[3]) {
+            const int ks = wk * KSW + kl;
             const char* xbase = ximg + ((no * 3) * XPIX + ((ks >> 1) + tr) * XC + (ks & 1) * 16 + dx) * 64 + tr_lane;
 #pragma unroll
             for (int p = 0; p < 3; ++p) bx[p] = tr_read(xbase + p * XPIX * 64);
@@ -266,15 +236,15 @@ wgrad_x3s_kernel(const Wx3sArgs a) {
         gload(0, av[0]);
         xload(0, 0, bv[0]);
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
+        for (int kl = 0; kl < KSW; ++kl) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int s = ks * 3 + dx;
+                const int s = kl * 3 + dx;
                 // the next step's X words (and, at a k-step's last tap, the next k-step's G words) one step ahead
-                if (s + 1 < KS * 3) xload((s + 1) / 3, (s + 1) % 3, bv[(s + 1) & 1]);
-                if (dx == 2 && ks + 1 < KS) gload(ks + 1, av[(ks + 1) & 1]);
+                if (s + 1 < KSW * 3) xload((s + 1) / 3, (s + 1) % 3, bv[(s + 1) & 1]);
+                if (dx == 2 && kl + 1 < KSW) gload(kl + 1, av[(kl + 1) & 1]);
                 __builtin_amdgcn_sched_barrier(0);
-                const u32x4 (&ax)[3] = av[ks & 1];
+                const u32x4 (&ax)[3] = av[kl & 1];
                 const u32x4 (&bx)[3] = bv[s & 1];
                 // smallest terms first: (hi,lo) (lo,hi) (mid,mid) (hi,mid) (mid,hi) (hi,hi)
 #define WXS_MFMA(PA, PB) acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ax[PA]), __builtin_bit_cast(bf16x8, bx[PB]), acc[dx], 0, 0, 0)
@@ -283,32 +253,60 @@ wgrad_x3s_kernel(const Wx3sArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-#endif
         img ^= 1;
     }
-    // ---- the slab [z][tap][m][n]
+    // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one tap at a time), then the slab [z][tap][m][n]:
+    // 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
+    float* red = reinterpret_cast<float*>(smem);
     const int64_t slab_base = (int64_t)z * a.M * a.N * 9;
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-        const int t = tr * 3 + dx;
+        f32x16 v = acc[dx];
+        if (WK > 1) {
+            WXS_BARRIER();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            // 32 x 32 x 16: column l31, row (r & 3) + 8 (r >> 2) + 4 half;  16 x 16 x 32: block (mh, nh) = (r >> 3, (r >> 2) & 1), column lane & 15, row 4 (lane >> 4) + (r & 3)
-            const int n = n0 + no * 32 + (WXS_M16 ? 16 * ((r >> 2) & 1) + (lane & 15) : l31);
-            const int m = m0 + mo * 32 + (WXS_M16 ? 16 * (r >> 3) + 4 * (lane >> 4) + (r & 3) : (r & 3) + 8 * (r >> 2) + 4 * half);
-            a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = acc[dx][r];
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = v[r];
+            WXS_BARRIER();
+            if (wk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WK; ++k) s += red[((wave + 3 * k) * 16 + r) * 64 + lane];      // (the split index steps the wave number by 3)
+                    v[r] = s;
+                }
+            }
+        }
+        if (wk == 0) {
+            const int t = tr * 3 + dx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + no * 32 + l31, m = m0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = v[r];
+            }
         }
     }
     WXS_BARRIER();                                                  // (the producers' bias reduction: two more barriers for every wave)
     WXS_BARRIER();
 }
 
+template <int MO, int NO, int TH>
+int launch_wxs(const Wx3sArgs& a, hipStream_t s) {
+    using Cfg = WsCfg<MO, NO, TH>;
+    auto kern = wgrad_x3s_kernel<MO, NO, TH>;
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int blocks = (a.M / (32 * MO)) * (a.N / (32 * NO)) * a.Z;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTHR), Cfg::LDS_BYTES, s, a);
+    return pnnp_launch_status();
+}
+
 }  // namespace
 
+// pixel-tile height of the configuration for (M, N): 64 x 64 -> 2 rows, 64 x 32 -> 3, 32 x 64 -> 2, 32 x 32 -> 4 (what the LDS holds twice)
+int pnnp_wx3s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? 2 : 3) : ((N % 64 == 0) ? 2 : 4); }
+
 int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s) {
-    static PnnpPerDevice lds_once;
-    if (pnnp_allow_lds(lds_once, wgrad_x3s_kernel, LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
-    const int blocks = (a.M / 64) * (a.N / 64) * a.Z;
-    hipLaunchKernelGGL(wgrad_x3s_kernel, dim3(blocks), dim3(NTHR), LDS_BYTES, s, a);
-    return pnnp_launch_status();
+    if (a.M % 64 == 0) return a.N % 64 == 0 ? launch_wxs<2, 2, 2>(a, s) : launch_wxs<2, 1, 3>(a, s);
+    return a.N % 64 == 0 ? launch_wxs<1, 2, 2>(a, s) : launch_wxs<1, 1, 4>(a, s);
 }
