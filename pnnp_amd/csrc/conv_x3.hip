@@ -64,7 +64,9 @@ constexpr int TH = NWAVE * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;   // 16-row
 #define X3_M16 1                   // 1: v_mfma_f32_16x16x32_bf16 with two PIECES concatenated along K (see mfma_row16); 0: v_mfma_f32_32x32x16_bf16
 #endif
 #ifndef X3_DIRECT
-#define X3_DIRECT 1                // 1: the epilogue stores straight from the accumulators (operands swapped in the MFMA: see `epilogue`); 0: rounds 2-4's LDS patch
+#define X3_DIRECT 0                // 0: rounds 2-4's epilogue through an LDS patch (what this kernel -- now the fallback of csrc/conv_x3s.hip -- shipped and was
+                                   //    tested with for three rounds); 1: stores straight from the accumulators, operands swapped in the MFMA (the first,
+                                   //    neutral step towards conv_x3s: profiles/r4/ab_specialised_waves.txt)
 #endif
 #if X3_DIRECT && !X3_M16
 #error "X3_DIRECT reads the 16x16 accumulator layout"
