@@ -45,6 +45,36 @@ def run(out, n=48, seed=1234):
                 dW = torch.full((Co, C1 + C2, 3, 3), float('nan'), device=dev); db = torch.full((Co,), float('nan'), device=dev)
                 ops.conv_x3_bwd_weight(gy, Co, x1, C1, x2, dW, db, ws)
                 res[f'{it} wgrad'] = torch.cat([dW.flatten().cpu(), db.cpu()])
+    u8 = lambda n: torch.zeros(n, device=dev, dtype=torch.uint8)
+    for it in range(n // 2):                                     # the pointwise GEMMs: ConvTranspose2d, 1x1 (two inputs), stride-2 3x3
+        B = rnd.choice([1, 2]); h = rnd.randint(2, 40); w_ = rnd.randint(2, 50)
+        ci = rnd.choice([32, 64, 128, 256]); co = rnd.choice([32, 64, 128])
+        g = torch.Generator(device=dev).manual_seed(seed + 1000 + it)
+        wt = torch.randn(ci, co, 2, 2, device=dev, generator=g) * 0.1; b = torch.randn(co, device=dev, generator=g)
+        f = u8(ops.x3mat_bytes(ci, 4 * co)); d = u8(ops.x3mat_bytes(4 * co, ci))
+        j = ops.PackJobs(); j.add_x3_convt(wt, f, d); j.run()
+        x = torch.randn(B, h, w_, ci, device=dev, generator=g); y = torch.full((B, 2 * h, 2 * w_, co), float('nan'), device=dev)
+        ops.convt_x3_fwd(x, f, b, y, co)
+        m = torch.randn(B, h, w_, ci, device=dev, generator=g); dx = torch.full((B, h, w_, ci), float('nan'), device=dev)
+        ops.convt_x3_bwd_data(y, d, dx, mask=m, mode=1)
+        res[f'{it} convt {B}x{h}x{w_} {ci}->{co}'] = torch.cat([y.flatten().cpu(), dx.flatten().cpu()])
+        w1 = torch.randn(co, 2 * ci, 1, 1, device=dev, generator=g) * 0.1
+        f = u8(ops.x3mat_bytes(2 * ci, co)); d = u8(ops.x3mat_bytes(co, 2 * ci))
+        j = ops.PackJobs(); j.add_x3_1x1(w1, f, d); j.run()
+        x2 = torch.randn(B, h, w_, ci, device=dev, generator=g); y1 = torch.full((B, h, w_, co), float('nan'), device=dev)
+        ops.conv1x1_x3_fwd(x, x2, f, None, y1, co, 0)
+        d1 = torch.full((B, h, w_, ci), float('nan'), device=dev); d2 = torch.full((B, h, w_, ci), float('nan'), device=dev)
+        ops.conv1x1_x3_bwd_data(y1, d, d1, dx2=d2)
+        res[f'{it} pw1x1'] = torch.cat([y1.flatten().cpu(), d1.flatten().cpu(), d2.flatten().cpu()])
+        H2, W2 = 2 * h, 2 * w_
+        w3 = torch.randn(co, ci, 3, 3, device=dev, generator=g) * 0.1
+        f = u8(ops.x3mat_bytes(9 * ci, co)); d = u8(9 * ops.x3mat_bytes(co, ci))
+        j = ops.PackJobs(); j.add_x3_s2(w3, f, d); j.run()
+        xs = torch.randn(B, H2, W2, ci, device=dev, generator=g); ys = torch.full((B, h, w_, co), float('nan'), device=dev)
+        ops.conv_s2_x3_fwd(xs, f, b, ys, co)
+        dxs = torch.zeros(B, H2, W2, ci, device=dev)
+        ops.conv_s2_x3_bwd_data(ys, d, dxs)
+        res[f'{it} s2'] = torch.cat([ys.flatten().cpu(), dxs.flatten().cpu()])
     torch.save(res, out)
     print('wrote', out, len(res), 'results')
 
