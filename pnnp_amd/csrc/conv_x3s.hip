@@ -79,6 +79,10 @@ __device__ __forceinline__ void split2(float a0, float a1, unsigned& h, unsigned
 #ifndef X3S_SKEW
 #define X3S_SKEW 0
 #endif
+#ifndef X3S_STORE_AUX
+#define X3S_STORE_AUX 2              // cache-policy bits of the epilogue's full-resolution stores: 2 = nt (non-temporal: +0.3-0.5 % on the step, three
+                                   // alternating same-box pairs, profiles/r4/ab_store_policy.txt); 0 = default, 1 = sc0, 3 = sc0 + nt measured too
+#endif
 #ifndef X3S_SKEW_PHASES
 #define X3S_SKEW_PHASES 8
 #endif
@@ -490,8 +494,8 @@ igemm_x3s_kernel(const IgemmArgs a) {
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {                     // full resolution: whole lines (the halves of the block pair traded)
                         const f32x4 ox = ror8(sel(lo8, wn[1][i], wn[0][i]));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, wn[0][i], ox)), rd, wo[k][i][h], 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, wn[1][i])), rd, wo2(k, i, h), 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, wn[0][i], ox)), rd, wo[k][i][h], 0, X3S_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, wn[1][i])), rd, wo2(k, i, h), 0, X3S_STORE_AUX);
                     }
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj) {
@@ -580,8 +584,8 @@ igemm_x3s_kernel(const IgemmArgs a) {
                                 for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
                             }
                             const f32x4 ox = ror8(sel(lo8, o1, o0));
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h], 0, 0);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo2(k, i, h), 0, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h], 0, X3S_STORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo2(k, i, h), 0, X3S_STORE_AUX);
                         }
                 }
             };

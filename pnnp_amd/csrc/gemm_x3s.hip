@@ -27,6 +27,9 @@ constexpr int NCW = 8, NPW = 4, NTHR = 64 * (NCW + NPW), PTHR = 64 * NPW;
 constexpr int MT = 2;                                              // pixel rows (of 32 px) per consumer wave
 constexpr int WBLK1 = 2 * 3 * 32 * 16;                             // one item of one 32-column block: [octet 2][piece 3][32][16 B] = 3072
 constexpr unsigned OOB = 0x80000000u;
+#ifndef GXS_STORE_AUX
+#define GXS_STORE_AUX 0              // cache-policy bits of the epilogue's stores (2 = nt: see csrc/conv_x3s.hip X3S_STORE_AUX)
+#endif
 #define GXS_VMCNT(N) (0x0f70 | ((N) & 15) | (((N) >> 4) << 14))
 #define GXS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")     // (see csrc/conv_x3s.hip: not __syncthreads())
 
@@ -408,8 +411,8 @@ gemm_x3s_kernel(const IgemmArgs a) {
                             for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
                         }
                         const f32x4 ox = ror8(sel(lo8, o1, o0));
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h][0], 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo[k][i][h][1], 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h][0], 0, GXS_STORE_AUX);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo[k][i][h][1], 0, GXS_STORE_AUX);
                     }
             }
             return;
