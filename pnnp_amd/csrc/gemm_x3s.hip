@@ -28,7 +28,8 @@ constexpr int MT = 2;                                              // pixel rows
 constexpr int WBLK1 = 2 * 3 * 32 * 16;                             // one item of one 32-column block: [octet 2][piece 3][32][16 B] = 3072
 constexpr unsigned OOB = 0x80000000u;
 #ifndef GXS_STORE_AUX
-#define GXS_STORE_AUX 0              // cache-policy bits of the epilogue's stores (2 = nt: see csrc/conv_x3s.hip X3S_STORE_AUX)
+#define GXS_STORE_AUX 2              // cache-policy bits of the epilogue's stores: 2 = nt (non-temporal, as in csrc/conv_x3s.hip: config 3 +0.3 %, config 5 +0.6 %,
+                                   // three alternating same-box pairs: profiles/r4/ab_store_policy.txt)
 #endif
 #define GXS_VMCNT(N) (0x0f70 | ((N) & 15) | (((N) >> 4) << 14))
 #define GXS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")     // (see csrc/conv_x3s.hip: not __syncthreads())
