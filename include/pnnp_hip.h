@@ -161,6 +161,7 @@ typedef struct PnnpPackJob {
     int kind, T, K, N;
     int64_t sk, sn, st, off;
     int flip, Kvalid, Ndst, n_off;
+    const unsigned* amax;            /* kind 4 (fp16x2 pack): the weight tensor's amax slot */
 } PnnpPackJob;
 int pnnp_pack_jobs_f32(const PnnpPackJob* jobs /*[host]*/, int n, void* stream);
 int pnnp_pack_jobs_add_conv(PnnpPackJob* jobs, int* n, int cap, const float* w, float* fwd /*or null*/, float* dgrad /*or null*/,
@@ -201,6 +202,38 @@ int pnnp_conv3x3_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgra
                                  int B, int H, int W, void* stream);
 int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int C1,
                                      const float* addsrc, const float* mask, int mode, int B, int H, int W, void* stream);
+/* ---- the same layers on the fp16 matrix cores with float32 operands split into TWO scaled fp16 pieces ("h2": csrc/conv_h2s.hip, csrc/h2.h):
+ * hi = f16(s a), lo = f16(s a - hi), a b = hi hi' + hi lo' + lo hi' -- three fp16 products per multiply where bf16x3 needs six, fp32
+ * accumulation; s = the power of two that brings the TENSOR's largest magnitude into [2^14, 2^15).  That maximum travels in a 4-byte "amax
+ * slot" beside every tensor the kernels split: the bit pattern of max |element| (non-negative floats order like unsigned integers), zeroed by
+ * the caller once per pass and raised with atomicMax by whichever kernel writes the tensor (amax_y / amax_dx arguments here;
+ * pnnp_amax_f32 for a tensor from elsewhere).  A slot may over-estimate (costs range at the small end), never under-estimate.
+ * Supported range: every float32 tensor whose elements of interest lie within 2^-18 of its maximum keeps 22 significand bits per operand;
+ * smaller elements carry an absolute error of 2^-40 of the maximum (tests/test_gpu_h2.py runs the float64 yardsticks of the bf16x3 family).
+ * Sign bits: a forward layer can store (activated output > 0) as one bit per element (bits_y: pnnp_h2_bits_words(B, H, W, Cout) words, a
+ * tile-private order that only pnnp_conv3x3_h2_bwd_data_f32 reads back) -- the LeakyReLU' / ReLU' mask of the backward pass at 1/32 of the
+ * float32 activation's traffic (archs/Unet.py:52,57-69).  Weights: kind-4 packs of pnnp_h2_weight_bytes(K, N) bytes, scaled with the
+ * weight tensor's own slot (pnnp_pack_jobs_add_amax in an earlier launch of the pack table, then pnnp_pack_jobs_add_h2). */
+int pnnp_h2_supported(int K, int N);
+int64_t pnnp_h2_weight_bytes(int K, int N);
+int64_t pnnp_h2_bits_words(int B, int H, int W, int C);
+int pnnp_amax_f32(const float* x, int64_t count, unsigned* slot, void* stream);
+int pnnp_pack_jobs_add_amax(PnnpPackJob* jobs, int* n, int cap, const float* x, int64_t count, unsigned* slot);
+int pnnp_pack_jobs_add_h2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/,
+                          int Cout, int Cin, int Cin_pad, const unsigned* amax_w);
+int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
+                            const void* w_h2, const unsigned* amax_w, const float* bias, const float* residual, float* y,
+                            unsigned* amax_y /*or null*/, unsigned* bits_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3_h2_fwd_pool_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
+                                 const void* w_h2, const unsigned* amax_w, const float* bias, float* y, float* pooled, unsigned char* codes,
+                                 unsigned* amax_y /*or null*/, unsigned* bits_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                 float* dx1, int C1, const float* mask1, const unsigned* bits1, int mode1, int accum1, unsigned* amax_dx1,
+                                 float* dx2 /*or null*/, int C2, const float* mask2, const unsigned* bits2, int mode2, int accum2, unsigned* amax_dx2,
+                                 int B, int H, int W, void* stream);
+int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                     float* dx, int C1, const float* addsrc, const float* mask, int mode, unsigned* amax_dx,
+                                     int B, int H, int W, void* stream);
 /* pointwise layers on the bf16 matrix cores (csrc/gemm_x3.hip): ConvTranspose2d k2 s2 (archs/Unet.py:35-47), Conv2d 1x1 (ResidualBlock
  * shortcuts, archs/modules.py:176-197), Conv2d 3x3 stride 2 (archs/modules.py:130-138); same contracts as pnnp_convt2x2_* /
  * pnnp_conv_fwd_f32 + pnnp_conv_bwd_data_f32 with taps = 1 / pnnp_conv3x3s2_*; channel counts in multiples of 32; the weights are

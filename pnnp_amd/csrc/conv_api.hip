@@ -1,6 +1,7 @@
 // C-ABI entry points of the convolution stack: weight re-packing and the named
 // forward / backward-data operations built on the implicit-GEMM kernel (conv_igemm.hip).
 #include "igemm.h"
+#include "h2.h"
 
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s);
 int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);       // csrc/conv_x3.hip (3x3, bf16x3 split)
@@ -227,6 +228,64 @@ int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_
     IgemmArgs a;
     bwd_res_args(a, g, Cout, w_x3_dgrad, dx, C1, addsrc, mask, mode, B, H, W);
     return pnnp_igemm_x3_launch(a, Cout, as_stream(stream));
+}
+
+// ---------------------------------------------------------------- 3x3 / stride 1 / pad 1 on the fp16 matrix cores (fp16x2 split, csrc/conv_h2s.hip)
+// Same layer contracts as the pnnp_conv3x3_x3_* entries; in addition every tensor that is split on the fly comes with its amax slot
+// (csrc/h2.h), every destination may report max |stored value| into a slot, a forward layer may write the sign bits of its activated output
+// (pnnp_h2_bits_words words) and backward-data may take its act' masks as those bits instead of the float32 activation.
+int pnnp_h2_supported(int K, int N) { return (K > 0 && (K % 8) == 0 && N > 0 && (N % 32) == 0 && N <= 1024) ? 1 : 0; }
+
+int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
+                            const void* w_h2, const unsigned* amax_w, const float* bias, const float* residual, float* y,
+                            unsigned* amax_y, unsigned* bits_y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_h2 || !y || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args a{};
+    fwd_args(a.g, x1, C1, x2, C2, w_h2, bias, residual, y, B, H, W, Cout, act);
+    a.amax_in[0] = amax_x1; a.amax_in[1] = x2 ? amax_x2 : nullptr; a.amax_w = amax_w; a.amax_out[0] = amax_y;
+    a.bits_out = bits_y; a.bits_nblk[0] = (Cout + 31) / 32;
+    return pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
+}
+
+int pnnp_conv3x3_h2_fwd_pool_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
+                                 const void* w_h2, const unsigned* amax_w, const float* bias, float* y, float* pooled, unsigned char* codes,
+                                 unsigned* amax_y, unsigned* bits_y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_h2 || !y || !pooled || !codes || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1) || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args a{};
+    fwd_args(a.g, x1, C1, x2, C2, w_h2, bias, nullptr, y, B, H, W, Cout, act);
+    a.g.pool_dst = pooled; a.g.pool_codes = codes; a.g.pool_cs = Cout;
+    a.amax_in[0] = amax_x1; a.amax_in[1] = x2 ? amax_x2 : nullptr; a.amax_w = amax_w; a.amax_out[0] = amax_y;      // (the pooled map is a subset of y)
+    a.bits_out = bits_y; a.bits_nblk[0] = (Cout + 31) / 32;
+    return pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
+}
+
+// mask1 / mask2: the float32 activation, or bits1 / bits2: its sign bits from the forward kernel (then the float32 pointer is not read)
+int pnnp_conv3x3_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                 float* dx1, int C1, const float* mask1, const unsigned* bits1, int mode1, int accum1, unsigned* amax_dx1,
+                                 float* dx2, int C2, const float* mask2, const unsigned* bits2, int mode2, int accum2, unsigned* amax_dx2,
+                                 int B, int H, int W, void* stream) {
+    if (!g || !w_h2_dgrad || !dx1 || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args a{};
+    bwd_args(a.g, g, Cout, w_h2_dgrad, dx1, C1, mask1, mode1, accum1, dx2, C2, mask2, mode2, accum2, B, H, W);
+    if (bits1) a.g.mask_mode[0] = mode1;
+    if (bits2 && dx2) a.g.mask_mode[1] = mode2;
+    a.amax_in[0] = amax_g; a.amax_w = amax_w; a.amax_out[0] = amax_dx1; a.amax_out[1] = dx2 ? amax_dx2 : nullptr;
+    a.bits_in[0] = bits1; a.bits_in[1] = dx2 ? bits2 : nullptr; a.bits_nblk[0] = (C1 + 31) / 32; a.bits_nblk[1] = (C2 + 31) / 32;
+    return pnnp_igemm_h2s_launch(a, Cout, as_stream(stream));
+}
+
+int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                     float* dx, int C1, const float* addsrc, const float* mask, int mode, unsigned* amax_dx,
+                                     int B, int H, int W, void* stream) {
+    if (!g || !w_h2_dgrad || !dx || !addsrc || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args a{};
+    bwd_res_args(a.g, g, Cout, w_h2_dgrad, dx, C1, addsrc, mask, mode, B, H, W);
+    a.amax_in[0] = amax_g; a.amax_w = amax_w; a.amax_out[0] = amax_dx;
+    return pnnp_igemm_h2s_launch(a, Cout, as_stream(stream));
 }
 
 // ---------------------------------------------------------------- pointwise layers on the bf16 matrix cores (csrc/gemm_x3.hip)

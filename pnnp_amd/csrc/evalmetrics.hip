@@ -42,6 +42,10 @@ illum_apply_kernel(const float* __restrict__ pred, float* __restrict__ out, cons
         out[i] = scale * fminf(fmaxf(pred[i], 0.f), 1.f);
 }
 
+// torch.clamp(0, 1): a NaN stays a NaN (fminf / fmaxf return the OTHER operand for a NaN, which would turn a diverged network's
+// output into 0 and its PSNR into a finite number); comparisons with a NaN are false, so it falls through both selects.
+__device__ __forceinline__ float clamp01_nan(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+
 // The elementwise tail of the eval iteration in ONE pass (trainer_SID.py:226-235): crop the padded network output back, add the input
 // residual of a `res` network (left out of the padded forward: (f(pad x) + pad x)[crop] = f(pad x)[crop] + x), `ori`: x ratio on both
 // frames, clamp both to [0, 1].  Plane c of the network output is [HP][WP], the frame sits at (pad, pad).
@@ -55,8 +59,8 @@ eval_post_kernel(const float* __restrict__ net_out, const float* __restrict__ lr
         const float l = lr_in[i];
         float d = net_out[((int64_t)c * HP + y + pad) * WP + x + pad];
         if (add_residual) d += l;
-        dn[i] = fminf(fmaxf(d * ratio, 0.f), 1.f);              // (imgs_dn * ratio).clamp(0, 1): one rounding for the product, like the tensor op
-        if (lr_out) lr_out[i] = fminf(fmaxf(l * ratio, 0.f), 1.f);
+        dn[i] = clamp01_nan(d * ratio);                         // (imgs_dn * ratio).clamp(0, 1): one rounding for the product, like the tensor op
+        if (lr_out) lr_out[i] = clamp01_nan(l * ratio);
     }
 }
 
@@ -178,7 +182,7 @@ int pnnp_psnr_ssim_f32(const float* a, const float* b, float* out, int C, int H,
 
 // dn = clamp((net_out[crop] (+ lr_in)) * ratio, 0, 1), lr_out (or null) = clamp(lr_in * ratio, 0, 1): the elementwise tail of one eval
 // iteration (trainer_SID.py:226-235).  net_out: [C][HP][WP] with the frame at (pad, pad) (pad = 0, HP = H, WP = W: no crop);
-// lr_in, dn, lr_out: [C][H][W].  ratio_dev (device scalar) overrides ratio when not null.  NaN stays NaN (fminf / fmaxf order as torch.clamp).
+// lr_in, dn, lr_out: [C][H][W].  ratio_dev (device scalar) overrides ratio when not null.  NaN stays NaN like torch.clamp (clamp01_nan: selects, not fminf / fmaxf).
 int pnnp_eval_post_f32(const float* net_out, const float* lr_in, float* dn, float* lr_out, int C, int H, int W, int HP, int WP, int pad,
                        float ratio, const float* ratio_dev, int add_residual, void* stream) {
     if (!net_out || !lr_in || !dn || C <= 0 || H <= 0 || W <= 0 || pad < 0 || HP < H + 2 * pad || WP < W + 2 * pad) return PNNP_E_INVALID;

@@ -6,8 +6,12 @@
 //   job kind 1: Winograd filter transform into the kernel's chunked order (csrc/wino.hip)
 //   job kind 2: 3x3 filters split into three bf16 pieces in the order csrc/conv_x3.hip streams them by LDS-DMA
 //   job kind 3: a strided K x N matrix (1x1 / ConvTranspose / strided-tap weights) split likewise for csrc/gemm_x3.hip
+//   job kind 4: 3x3 filters scaled by a power of two and split into two fp16 pieces for csrc/conv_h2s.hip (the scale comes from the amax slot
+//               that a kind-5 job of an EARLIER launch filled)
+//   job kind 5: max |src| -> atomicMax into a 4-byte slot (csrc/h2.h)
 // The builders below produce exactly the jobs the per-layer entry points used to launch (same formulas, same layouts).
 #include "common.h"
+#include "h2.h"
 
 namespace {
 
@@ -131,6 +135,50 @@ __device__ __forceinline__ void x3mat_job(const PnnpPackJob& j, int64_t blk, int
     }
 }
 
+// fp16x2 pack of a 3x3 Conv2d weight for csrc/conv_h2s.hip:  dst (fp16) [N/32][K16][piece 2: hi', lo'][tap 9][octet 2][32][8]
+//   element (k, n, tap) as in x3_job;  W s with s = 2^pnnp_h2_scale_exp(*amax) (amax >= max |w|: a kind-5 job), hi' = f16(W s), lo' = f16(W s - hi')
+//   (round to nearest even; the residual is exact in float32).  job: K = Cout, N = Cin, T = dgrad, Kvalid = padded K, amax = the slot.
+__device__ __forceinline__ void h2_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
+    const int Cout = j.K, Cin = j.N, dgrad = j.T;
+    const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
+    const int Kp = j.Kvalid, K16 = Kp / 16;
+    const float s = __uint_as_float((unsigned)(pnnp_h2_scale_exp(j.amax[0]) + 127) << 23);
+    const int64_t total = (int64_t)Kp * ((N + 31) / 32 * 32) * 9;
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
+        const int e = (int)(t & 7);                                // destination order: coalesced 2-byte stores of one piece plane
+        int64_t r = t >> 3;
+        const int nn = (int)(r & 31); r >>= 5;
+        const int oct = (int)(r & 1); r >>= 1;
+        const int tap = (int)(r % 9); r /= 9;
+        const int c = (int)(r % K16);
+        const int nb = (int)(r / K16);
+        const int k = c * 16 + oct * 8 + e, n = nb * 32 + nn;
+        float v = 0.f;
+        if (k < K && n < N) v = dgrad ? w[((int64_t)k * Cin + n) * 9 + (8 - tap)] : w[((int64_t)n * Cin + k) * 9 + tap];
+        const float vs = v * s;
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
+        unsigned short* o = u + (((int64_t)nb * K16 + c) * 2 * 9 + tap) * 512 + oct * 256 + nn * 8 + e;
+        o[0] = __builtin_bit_cast(unsigned short, h); o[9 * 512] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
+// max |src[0 .. n)| -> slot (non-negative floats order like their bit patterns; NaN counts as larger than inf: a diverged tensor is flagged)
+__device__ __forceinline__ void amax_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ x = j.src;
+    const int64_t n = j.sk;
+    unsigned m = 0u;
+    auto upd = [&](float v) { const unsigned b = __float_as_uint(v) & 0x7fffffffu; m = b > m ? b : m; };
+    const int64_t n4 = (((uintptr_t)x) & 15) ? 0 : n >> 2;         // 16-byte loads where the tensor allows
+    const float4* __restrict__ x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = blk * 256 + threadIdx.x; i < n4; i += (int64_t)nblk * 256) { const float4 v = x4[i]; upd(v.x); upd(v.y); upd(v.z); upd(v.w); }
+    for (int64_t i = n4 * 4 + blk * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) upd(x[i]);
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, sft, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned*>(j.dst), m);
+}
+
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     int j = 0;
     while (j + 1 < tb.n && (int)blockIdx.x >= tb.blk_end[j]) ++j;          // uniform: <= 32 scalar compares
@@ -140,11 +188,14 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     if (job.kind == 1) wino_job(job, (int64_t)blockIdx.x - b0, nblk);
     else if (job.kind == 2) x3_job(job, (int64_t)blockIdx.x - b0, nblk);
     else if (job.kind == 3) x3mat_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else if (job.kind == 4) h2_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else if (job.kind == 5) amax_job(job, (int64_t)blockIdx.x - b0, nblk);
     else gather_job(job, (int64_t)blockIdx.x - b0, nblk);
 }
 
 int job_blocks(const PnnpPackJob& j) {
-    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
+    if (j.kind == 5) { const int64_t b5 = (j.sk + 256 * 16 - 1) / (256 * 16); return (int)(b5 > 1024 ? 1024 : (b5 < 1 ? 1 : b5)); }
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : ((j.kind == 2 || j.kind == 4) ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -177,7 +228,8 @@ int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
         int blocks = 0;
         for (int i = 0; i < tb.n; ++i) {
             const PnnpPackJob& j = jobs[i0 + i];
-            if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0 || (j.K & 7)))       /* kind 3 enumerates whole 8-row groups */) return PNNP_E_INVALID;
+            if (j.kind == 5) { if (!j.src || !j.dst || j.sk < 0) return PNNP_E_INVALID; }
+            else if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 4 && (!j.amax || j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0 || (j.K & 7)))       /* kind 3 enumerates whole 8-row groups */) return PNNP_E_INVALID;
             tb.job[i] = j;
             blocks += job_blocks(j);
             tb.blk_end[i] = blocks;
@@ -240,6 +292,41 @@ int pnnp_pack_jobs_add_x3(PnnpPackJob* jobs, int* n, int cap, const float* w, vo
         ok = ok && push(jobs, n, cap, j);
     }
     return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+
+// fp16x2 packs of a 3x3 Conv2d weight for the pnnp_conv3x3_h2_* kernels (csrc/conv_h2s.hip), same shapes as pnnp_pack_jobs_add_x3; sizes:
+// pnnp_h2_weight_bytes.  `amax`: the weight tensor's slot, filled by pnnp_pack_jobs_add_amax in an EARLIER launch of the table (the Python
+// PackJobs keeps the amax jobs in a table of their own that runs first).
+int pnnp_pack_jobs_add_h2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin, int Cin_pad, const unsigned* amax) {
+    if (!jobs || !n || !w || !amax || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || (Cin_pad & 15)) return PNNP_E_INVALID;
+    bool ok = true;
+    for (int d = 0; d < 2; ++d) {
+        void* dst = d ? dgrad : fwd;
+        if (!dst) continue;
+        PnnpPackJob j{};
+        j.src = w; j.dst = reinterpret_cast<float*>(dst); j.kind = 4; j.T = d; j.K = Cout; j.N = Cin; j.amax = amax;
+        j.Kvalid = d ? (Cout + 15) / 16 * 16 : Cin_pad;
+        ok = ok && push(jobs, n, cap, j);
+    }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+// max |x[0 .. count)| -> atomicMax into *slot (the caller zeroes the slot first)
+int pnnp_pack_jobs_add_amax(PnnpPackJob* jobs, int* n, int cap, const float* x, int64_t count, unsigned* slot) {
+    if (!jobs || !n || !x || !slot || count < 0) return PNNP_E_INVALID;
+    PnnpPackJob j{};
+    j.src = x; j.dst = reinterpret_cast<float*>(slot); j.kind = 5; j.sk = count; j.K = 1; j.N = 1;
+    return push(jobs, n, cap, j) ? PNNP_OK : PNNP_E_WORKSPACE;
+}
+// bytes of one h2 pack: K (rounded up to 16) x N (rounded up to 32) x 9 taps x 2 pieces x 2 B
+int64_t pnnp_h2_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16 * 16) * ((N + 31) / 32 * 32) * 9 * 4; }
+
+// max |x[0 .. count)| -> atomicMax into *slot, as a launch of its own: for tensors whose producer has no fused amax (csrc/h2.h)
+int pnnp_amax_f32(const float* x, int64_t count, unsigned* slot, void* stream) {
+    if (!x || !slot || count < 0) return PNNP_E_INVALID;
+    if (count == 0) return PNNP_OK;
+    PnnpPackJob j{};
+    j.src = x; j.dst = reinterpret_cast<float*>(slot); j.kind = 5; j.sk = count; j.K = 1; j.N = 1;
+    return pnnp_pack_jobs_f32(&j, 1, stream);
 }
 
 namespace {

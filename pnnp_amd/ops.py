@@ -41,6 +41,8 @@ def _prep():
         L.pnnp_x3_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3g_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_x3mat_bytes.restype = C.c_int64
+        L.pnnp_h2_weight_bytes.restype = C.c_int64
+        L.pnnp_h2_bits_words.restype = C.c_int64
         L.pnnp_head_bwd_workspace_floats.restype = C.c_int64
         L.pnnp_first_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
@@ -56,7 +58,7 @@ def pack_conv_weight(w, fwd, dgrad, cin_pad=None, cout_pad=None):
 class PackJob(C.Structure):                      # PnnpPackJob of include/pnnp_hip.h
     _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('kind', C.c_int), ('T', C.c_int), ('K', C.c_int), ('N', C.c_int),
                 ('sk', C.c_int64), ('sn', C.c_int64), ('st', C.c_int64), ('off', C.c_int64),
-                ('flip', C.c_int), ('Kvalid', C.c_int), ('Ndst', C.c_int), ('n_off', C.c_int)]
+                ('flip', C.c_int), ('Kvalid', C.c_int), ('Ndst', C.c_int), ('n_off', C.c_int), ('amax', C.c_void_p)]
 
 
 class PackJobs:
@@ -69,6 +71,12 @@ class PackJobs:
         self.jobs = (PackJob * cap)()
         self.n = C.c_int(0)
         self.keep = []                           # the tensors behind the recorded pointers
+        # fp16x2 packs (add_h2) scale every weight tensor by its own maximum: the amax jobs form a table of their own that run() launches
+        # FIRST (a pack job reads the slot its amax job filled); `wslots` holds one 4-byte slot per weight tensor
+        self.amax_jobs = None
+        self.n_amax = C.c_int(0)
+        self.wslots = None
+        self._wslot_of = {}
 
     def add_conv(self, w, fwd, dgrad, cin_pad=None, cout_pad=None):
         co, ci, kh, kw = w.shape
@@ -93,6 +101,30 @@ class PackJobs:
                                             cin_pad or (ci + 15) // 16 * 16), 'pack_jobs_add_x3')
         self.keep += [w, fwd, dgrad]
 
+    def weight_slot(self, w):
+        """The amax slot (a 1-element int32 view) of weight tensor ``w``; its amax job is added on first use."""
+        key = (w.data_ptr(), w.numel())
+        if key not in self._wslot_of:
+            if self.wslots is None:
+                self.wslots = torch.zeros(self.cap, dtype=torch.int32, device=w.device)
+                self.amax_jobs = (PackJob * self.cap)()
+            i = len(self._wslot_of)
+            slot = self.wslots[i:i + 1]
+            check(_prep().pnnp_pack_jobs_add_amax(self.amax_jobs, C.byref(self.n_amax), self.cap, ptr(w), C.c_int64(w.numel()), ptr(slot)), 'pack_jobs_add_amax')
+            self._wslot_of[key] = slot
+            self.keep += [w]
+        return self._wslot_of[key]
+
+    def add_h2(self, w, fwd, dgrad, cin_pad=None):
+        """fp16x2 packs (csrc/conv_h2s.hip) of a 3x3 Conv2d weight; fwd / dgrad: uint8 buffers of h2_weight_bytes, or None.  Returns the
+        weight tensor's amax slot (what the kernels take as ``amax_w``)."""
+        co, ci = w.shape[0], w.shape[1]
+        slot = self.weight_slot(w)
+        check(_prep().pnnp_pack_jobs_add_h2(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci,
+                                            cin_pad or (ci + 15) // 16 * 16, ptr(slot)), 'pack_jobs_add_h2')
+        self.keep += [w, fwd, dgrad]
+        return slot
+
     def add_x3_convt(self, w, fwd, dgrad):
         ci, co = w.shape[0], w.shape[1]
         check(_prep().pnnp_pack_jobs_add_x3_convt(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), ci, co), 'pack_jobs_add_x3_convt')
@@ -114,6 +146,9 @@ class PackJobs:
         self.keep += [w, dst]
 
     def run(self):
+        if self.n_amax.value:
+            self.wslots.zero_()
+            check(_prep().pnnp_pack_jobs_f32(self.amax_jobs, self.n_amax.value, stream()), 'pack_jobs (amax)')
         check(_prep().pnnp_pack_jobs_f32(self.jobs, self.n.value, stream()), 'pack_jobs')
 
 
@@ -198,6 +233,70 @@ def conv_x3_bwd_data_res(g, w_x3_dgrad, dx, addsrc, mask=None, mode=0):
     with _Timed('conv9_dgrad_x3', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
         check(_prep().pnnp_conv3x3_x3_bwd_data_res_f32(ptr(g), Cout, ptr(w_x3_dgrad), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
                                                        B, H, W, stream()), 'conv_x3_bwd_data_res')
+
+
+# ---- the fp16x2 ("h2") family: csrc/conv_h2s.hip, csrc/h2.h.  amax_* are 1-element int32 CUDA tensors (the slots), bits_* int32 tensors of
+# h2_bits_words elements.
+def h2_supported(K, N):
+    return bool(_prep().pnnp_h2_supported(int(K), int(N)))
+
+
+def h2_weight_bytes(K, N):
+    return int(_prep().pnnp_h2_weight_bytes(int(K), int(N)))
+
+
+def h2_bits_words(B, H, W, C_):
+    return int(_prep().pnnp_h2_bits_words(int(B), int(H), int(W), int(C_)))
+
+
+def amax(x, slot):
+    """slot = max(slot, max |x|) as a kernel of its own (tensors whose producer has no fused amax)."""
+    require_cuda(x, slot)
+    with _Timed('amax', 0.0, 4.0 * x.numel()):
+        check(_prep().pnnp_amax_f32(ptr(x), C.c_int64(x.numel()), ptr(slot), stream()), 'amax')
+    return slot
+
+
+def conv_h2_fwd(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, amax_x2=None, amax_y=None, bits_y=None, residual=None):
+    """3x3 / stride 1 / pad 1 forward on the fp16 matrix cores, fp32 operands split in two scaled pieces (contract of conv_fwd, taps=9)."""
+    require_cuda(x1, x2, w_h2, y, amax_w, amax_x1)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv3x3_h2_fwd_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(residual),
+                                              ptr(y), ptr(amax_y), ptr(bits_y), B, H, W, cout, act, stream()), 'conv_h2_fwd')
+    return y
+
+
+def conv_h2_fwd_pool(x1, x2, w_h2, amax_w, bias, y, pooled, codes, cout, act, amax_x1, amax_x2=None, amax_y=None, bits_y=None):
+    require_cuda(x1, x2, w_h2, y, pooled, codes, amax_w, amax_x1)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv3x3_h2_fwd_pool_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y),
+                                                   ptr(pooled), ptr(codes), ptr(amax_y), ptr(bits_y), B, H, W, cout, act, stream()), 'conv_h2_fwd_pool')
+    return y
+
+
+def conv_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx1, mask1=None, bits1=None, mode1=0, accum1=0, amax_dx1=None,
+                     dx2=None, mask2=None, bits2=None, mode2=0, accum2=0, amax_dx2=None):
+    require_cuda(g, w_h2_dgrad, dx1, amax_g, amax_w)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]
+    C2 = dx2.shape[3] if dx2 is not None else 0
+    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv3x3_h2_bwd_data_f32(ptr(g), Cout, ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w),
+                                                   ptr(dx1), C1, ptr(mask1), ptr(bits1), mode1, accum1, ptr(amax_dx1),
+                                                   ptr(dx2), C2, ptr(mask2), ptr(bits2), mode2, accum2, ptr(amax_dx2), B, H, W, stream()), 'conv_h2_bwd_data')
+
+
+def conv_h2_bwd_data_res(g, amax_g, w_h2_dgrad, amax_w, dx, addsrc, mask=None, mode=0, amax_dx=None):
+    require_cuda(g, w_h2_dgrad, dx, addsrc, amax_g, amax_w)
+    B, H, W, Cout = g.shape
+    C1 = dx.shape[3]
+    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
+        check(_prep().pnnp_conv3x3_h2_bwd_data_res_f32(ptr(g), Cout, ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
+                                                       ptr(amax_dx), B, H, W, stream()), 'conv_h2_bwd_data_res')
 
 
 def gemm_x3_supported(K, N):

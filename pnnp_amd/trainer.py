@@ -47,8 +47,8 @@ class BucketedAllReduce:
     ~0.4-0.5 ms of ring time against a ~23 ms step, i.e. 2 %) hiding it is worth less than that risk, so by default the all-reduce is
     ONE collective over the whole flat buffer, issued when the backward pass has finished; ``overlap=True`` launches the buckets
     from the backward pass as described above (bench.py --overlap-allreduce; measure before relying on it).  Round 4 removed the
-    hazard itself for the forward / backward-data kernels: with ``ops.set_persistent_split(4)`` (HipTrainStep does it when
-    ``overlap_allreduce`` is on) they launch quarter shares that the hardware dispatcher hands to whichever CU is free -- measured with a
+    hazard itself for the forward / backward-data kernels: with ``ops.set_persistent_split(4)`` (HipTrainStep sets it around the
+    backward pass of a step when ``overlap_allreduce`` is on, and restores the previous value) they launch quarter shares that the hardware dispatcher hands to whichever CU is free -- measured with a
     kernel squatting on 8 / 32 / 64 CUs beside conv2_2: x 1.05 / 1.04 / 1.21 instead of x 1.45 (tests/test_gpu_overlap.py,
     tools/squat_test.py); alone on the chip the split costs 6-14 % of a layer, hence not the default.  The backward-weight kernels keep
     their static pixel splits (their summation order is part of the bit-reproducibility contract)."""
@@ -167,10 +167,11 @@ class HipTrainStep:
         all-reduced sum is the mean over the global batch."""
         self.global_batch = global_batch
         self.overlap_allreduce = overlap_allreduce      # BucketedAllReduce(overlap=): buckets from inside the backward pass (see its docstring)
-        if overlap_allreduce and (world > 1 or force_reducer):
-            # collectives will be resident on some CUs while convolution grids are dispatched: quarter shares handed out by the hardware
-            # dispatcher instead of one static share per CU (tests/test_gpu_overlap.py: x 1.05 instead of x 1.45 beside a kernel on 32 CUs)
-            ops.set_persistent_split(4)
+        # collectives resident on some CUs while convolution grids are dispatched: quarter shares handed out by the hardware dispatcher
+        # instead of one static share per CU (tools/squat_test.py: x 1.05 instead of x 1.45 beside a kernel on 32 CUs).  The setting is
+        # process-wide library state, so it is scoped to the backward pass of a step whose reducer overlaps (step(): set, run, restore) --
+        # an eval loop, a layer benchmark or another HipTrainStep in the same process keeps whatever it had (ADVICE round 4).
+        self.overlap_split = 4 if (overlap_allreduce and (world > 1 or force_reducer)) else None
         self.proxy_check_every = 50          # steps between reads of the NoiseFlow proxy's `scale >= 0` flag (a host sync each)
         self.net = net
         self.engine = net.engine
@@ -328,7 +329,15 @@ class HipTrainStep:
         ops.l1_clamp_loss(pred, hr, g8, loss, lws, scale=scale, clamp_target=bool(self.clip), grad_weight=self.shard(B)[1])
         if self.reducer is not None:
             self.reducer.reset()
-        e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)
+        prev_split = None
+        if self.reducer is not None and self.overlap_split:
+            prev_split = ops.get_persistent_split()
+            ops.set_persistent_split(self.overlap_split)
+        try:
+            e.backward(g8, on_ready=self.reducer.ready if self.reducer is not None else None)
+        finally:
+            if prev_split is not None:
+                ops.set_persistent_split(prev_split)
         if self.reducer is not None:
             self.reducer.finish()
         self.step_count += 1

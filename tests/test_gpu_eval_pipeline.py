@@ -107,3 +107,23 @@ def test_eval_tail_kernel_equals_the_tensor_ops_bit_for_bit(res):
         # (a `res` network: f(pad x)[crop] + x here, (f(pad x) + pad x)[crop] in the module -- the same float32 sum)
         assert torch.equal(out['lr'], ref_lr)
         assert torch.equal(out['dn'], ref_dn), float((out['dn'] - ref_dn).abs().max())
+
+
+def test_eval_tail_kernel_propagates_nan_like_torch_clamp():
+    """A diverged network (NaN / +-inf in its output) must report NaN metrics, not finite ones: `(x * ratio).clamp(0, 1)` keeps a NaN
+    (trainer_SID.py:234-235), and so does pnnp_eval_post_f32 (fminf / fmaxf would have turned it into 0)."""
+    import ctypes as C
+    from pnnp_amd import _lib
+    g = torch.Generator(device='cuda').manual_seed(6)
+    out = torch.randn(4, 24, 40, device='cuda', generator=g)
+    lr = torch.randn(4, 16, 32, device='cuda', generator=g)
+    out[0, 5, 6] = float('nan'); out[1, 7, 8] = float('inf'); out[2, 9, 10] = -float('inf'); lr[3, 1, 2] = float('nan')
+    dn = torch.empty_like(lr); lo = torch.empty_like(lr)
+    for add_res in (0, 1):
+        _lib.check(_lib.lib().pnnp_eval_post_f32(_lib.ptr(out), _lib.ptr(lr), _lib.ptr(dn), _lib.ptr(lo), 4, 16, 32, 24, 40, 4,
+                                                 C.c_float(3.0), None, add_res, _lib.stream()), 'eval_post')
+        ref = out[:, 4:-4, 4:-4] + (lr if add_res else 0.0)
+        ref_dn, ref_lr = (ref * 3.0).clamp(0, 1), (lr * 3.0).clamp(0, 1)
+        assert torch.isnan(dn[0, 1, 2]) and float(dn[1, 3, 4]) == 1.0 and float(dn[2, 5, 6]) == 0.0 and torch.isnan(lo[3, 1, 2])
+        assert torch.equal(torch.nan_to_num(dn, nan=-7.0), torch.nan_to_num(ref_dn, nan=-7.0))
+        assert torch.equal(torch.nan_to_num(lo, nan=-7.0), torch.nan_to_num(ref_lr, nan=-7.0))

@@ -23,6 +23,8 @@ def main():
     ap.add_argument('--only', default='fwd,dgrad,wgrad')
     ap.add_argument('--layers', default='')
     ap.add_argument('--x3', action='store_true', help='bf16x3 kernels (csrc/conv_x3.hip) for fwd / dgrad')
+    ap.add_argument('--h2', action='store_true', help='fp16x2 kernels (csrc/conv_h2s.hip) for fwd / dgrad (dgrad masks as sign bits; --h2-fmask: as float32)')
+    ap.add_argument('--h2-fmask', action='store_true')
     a = ap.parse_args()
     B, S = a.batch, a.size
     dev = torch.device('cuda')
@@ -59,10 +61,28 @@ def main():
             f3 = torch.zeros(ops.x3_weight_bytes(C1 + C2, Co), dtype=torch.uint8, device=dev)
             d3 = torch.zeros(ops.x3_weight_bytes(Co, C1 + C2), dtype=torch.uint8, device=dev)
             jobs.add_x3(w, f3, d3, cin_pad=(C1 + C2 + 15) // 16 * 16); jobs.run()
+        if a.h2:
+            jobs = ops.PackJobs()
+            fh = torch.zeros(ops.h2_weight_bytes(C1 + C2, Co), dtype=torch.uint8, device=dev)
+            dh = torch.zeros(ops.h2_weight_bytes(Co, C1 + C2), dtype=torch.uint8, device=dev)
+            sw = jobs.add_h2(w, fh, dh, cin_pad=(C1 + C2 + 15) // 16 * 16); jobs.run()
+            slot = lambda *ts: [ops.amax(t, s_) for s_ in [torch.zeros(1, dtype=torch.int32, device=dev)] for t in ts][-1]
+            s1 = slot(x1); s2 = slot(x2) if C2 else None; sg = slot(g)
+            sy = torch.zeros(1, dtype=torch.int32, device=dev); sd1 = torch.zeros(1, dtype=torch.int32, device=dev); sd2 = torch.zeros(1, dtype=torch.int32, device=dev)
+            by = torch.zeros(ops.h2_bits_words(B, H, H, Co), dtype=torch.int32, device=dev)
+            b1 = torch.randint(-2 ** 31, 2 ** 31 - 1, (ops.h2_bits_words(B, H, H, C1),), dtype=torch.int32, device=dev) if C1 % 32 == 0 else None
+            b2 = torch.randint(-2 ** 31, 2 ** 31 - 1, (ops.h2_bits_words(B, H, H, C2),), dtype=torch.int32, device=dev) if C2 else None
         fns = {'fwd': (lambda: ops.conv_x3_fwd(x1, x2, f3, bias, y, Co, 1)) if a.x3 else (lambda: ops.conv_fwd(x1, x2, f, bias, y, Co, 9, 1)),
                'dgrad': (lambda: ops.conv_x3_bwd_data(g, d3, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)) if (a.x3 and C1 % 32 == 0) else
                         (lambda: ops.conv_bwd_data(g, d, dx1, mask1=x1, mode1=1, dx2=dx2, mask2=x2, mode2=1)),
                'wgrad': (lambda: ops.conv_x3_bwd_weight(g, Co, x1, C1, x2, dW, db, ws3)) if (a.x3 and C1 % 32 == 0) else (lambda: ops.conv_bwd_weight(g, Co, x1, C1, x2, dW, db, 9, ws))}
+        if a.h2:
+            fns['fwd'] = lambda: ops.conv_h2_fwd(x1, x2, fh, sw, bias, y, Co, 1, s1, s2, amax_y=sy, bits_y=by)
+            if C1 % 32 == 0:
+                if a.h2_fmask:
+                    fns['dgrad'] = lambda: ops.conv_h2_bwd_data(g, sg, dh, sw, dx1, mask1=x1, mode1=1, amax_dx1=sd1, dx2=dx2, mask2=x2, mode2=1, amax_dx2=sd2)
+                else:
+                    fns['dgrad'] = lambda: ops.conv_h2_bwd_data(g, sg, dh, sw, dx1, bits1=b1, mode1=1, amax_dx1=sd1, dx2=dx2, bits2=b2, mode2=1, amax_dx2=sd2)
         for k in kinds:
             fns[k](); torch.cuda.synchronize()
             ts = []

@@ -22,8 +22,9 @@ from pnnp_amd import _lib, ops  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def squat_lib():
-    so = os.path.join(HERE, 'ubench', 'libsquat.so')
+def squat_lib(build_dir=None):
+    """``build_dir``: where libsquat.so is built (tests pass a temporary directory: pytest writes nothing into the tree)."""
+    so = os.path.join(build_dir or os.path.join(HERE, 'ubench'), 'libsquat.so')
     src = os.path.join(HERE, 'ubench', 'squat.hip')
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
         subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', so, src])
@@ -32,8 +33,8 @@ def squat_lib():
     return L
 
 
-def measure(k=32, S=256, Ci=64, Co=64, B=16, reps=5):
-    L = squat_lib()
+def measure(k=32, S=256, Ci=64, Co=64, B=16, reps=5, build_dir=None):
+    L = squat_lib(build_dir)
     x = torch.randn(B, S, S, Ci, device='cuda'); w = torch.randn(Co, Ci, 3, 3, device='cuda') * 0.05; b = torch.randn(Co, device='cuda')
     wx = torch.empty(ops.x3_weight_bytes(Ci, Co), dtype=torch.uint8, device='cuda')
     jobs = ops.PackJobs(); jobs.add_x3(w, wx, None, cin_pad=Ci); jobs.run()
