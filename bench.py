@@ -37,6 +37,11 @@ FAMILY = {
                "igemm_x3s_kernel (csrc/conv_x3s.hip: conv3x3 forward + backward-data, float32 operands split into three bf16 pieces: the six piece products of a "
                "block as three v_mfma_f32_16x16x32_bf16 with two pieces concatenated along K, i.e. 6 executed bf16 FLOP per algorithmic FLOP, fp32 accumulation; "
                "8 MFMA-only consumer waves + 4 producer waves per workgroup)"),
+    'h2':     (28.0 / 9.0, PEAK_BF16_MFMA_TFLOPS, ('conv9_fwd_h2', 'conv9_dgrad_h2'),
+               "igemm_h2s_kernel (csrc/conv_h2s.hip: conv3x3 forward + backward-data, float32 operands scaled per tensor and split into two fp16 pieces: "
+               "per 16-channel chunk and 16x16 block 14 v_mfma_f32_16x16x32_f16 for the nine taps (hi hi' + lo hi' per tap, hi lo' for two taps at a time), "
+               "i.e. 28/9 = 3.11 executed fp16 FLOP per algorithmic FLOP (the fp16 dense peak equals the bf16 one), fp32 accumulation; "
+               "8 MFMA-only consumer waves + 4 producer waves per workgroup)"),
     'wino':   (16.0 / 36.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd_wino', 'conv9_dgrad_wino'),
                "wino_kernel (conv3x3 forward + backward-data as Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: 16 multiply-adds where the direct form has 36)"),
     'direct': (1.0, PEAK_F32_MFMA_TFLOPS, ('conv9_fwd', 'conv9_dgrad'),
@@ -196,8 +201,8 @@ def main():
     ap.add_argument('--noise', default='physics', choices=['physics', 'noiseflow'])
     ap.add_argument('--proxy-mode', default='train', choices=['train', 'eval'],
                     help='NoiseFlow proxy BatchNorm mode while sampling: train = trainer_LRID (config 5), eval = trainer_SID')
-    ap.add_argument('--family', default='x3', choices=['x3', 'wino', 'direct'],
-                    help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
+    ap.add_argument('--family', default='x3', choices=['x3', 'h2', 'wino', 'direct'],
+                    help='3x3 kernel family: x3 = bf16x3 split on the bf16 matrix cores (default), h2 = fp16x2 split on the fp16 matrix cores (csrc/h2.h; where it does not apply: x3), wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=240.0,
                     help='time budget of the CPU baseline legs (BASELINE.md section 3 protocol: B=16, 2 warm-up + 5 timed steps, all physical cores + 1 thread); '
@@ -257,7 +262,7 @@ def main():
         proxy = proxy.to(dev)
         proxy = proxy.train() if args.proxy_mode == 'train' else proxy.eval()
     net = net.to(dev)
-    net.engine.set_policy(x3=args.family == 'x3', wino=args.family != 'direct')
+    net.engine.set_policy(x3=args.family in ('x3', 'h2'), wino=args.family != 'direct', h2=args.family == 'h2')
     B, S = args.batch, args.size
     global_batch = B * world
     if args.strong:                             # one global batch split by shard_crops (remainders to the low ranks)
@@ -294,7 +299,7 @@ def main():
     # the per-class table comes from a short un-timed pass afterwards, so that the headline number is not taxed by ~200 event
     # records per step (measured: 1.7 %).
     pol = net.engine.policy
-    fam0 = 'x3' if pol.x3 else ('wino' if pol.wino else 'direct')
+    fam0 = ('h2' if getattr(pol, 'h2', False) else 'x3') if pol.x3 else ('wino' if pol.wino else 'direct')
     dom_kinds = set(FAMILY[fam0][2])
     if not args.no_kernel_events:
         ops.PROFILE, ops.PROFILE_KINDS = [], dom_kinds
@@ -340,7 +345,7 @@ def main():
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)" if pol.x3 else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": ("f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the fp16 matrix cores through a per-tensor-scaled 2-way split, 22 significand bits per operand: csrc/h2.h; backward-weight and the pointwise layers on the bf16 matrix cores through the exact 3-way split)" if getattr(pol, 'h2', False) else "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)") if pol.x3 else "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else f"NoiseFlow.sample proxy (iso 6400, ratio in {{1,2,4,8,16}}, BatchNorm in {args.proxy_mode} mode)") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
@@ -378,7 +383,7 @@ def main():
             if os.path.exists(tj) and args.arch == 'unet' and args.noise == 'physics' and B == 16 and S == 512:
                 tdoc = json.load(open(tj))
                 if tdoc.get('csrc_sha') == csrc_sha():
-                    traffic = tdoc.get({'x3': 'x3', 'wino': 'wino', 'direct': 'igemm9'}[fam], {}).get('hbm_bytes_per_launch')
+                    traffic = tdoc.get({'x3': 'x3', 'h2': 'h2', 'wino': 'wino', 'direct': 'igemm9'}[fam], {}).get('hbm_bytes_per_launch')
                     traffic_note = f"PMC passes at commit {tdoc.get('commit')}, kernel sources {tdoc.get('csrc_sha')}"
                 else:
                     traffic_note = f"profiles/traffic.json was measured on other kernel sources ({tdoc.get('csrc_sha')} != {csrc_sha()}): not attached"

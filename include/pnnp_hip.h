@@ -332,6 +332,9 @@ int pnnp_maxpool2_bwd_f32(const float* x, const float* gy, float* gx, int B, int
 int pnnp_maxpool2_fwd_codes_f32(const float* x, float* y, unsigned char* codes /*[B][H/2][W/2][C]*/, int B, int H, int W, int C, void* stream);
 int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
                                 int accumulate, void* stream);
+/* ... and max |gx| (of the sums it stored, when accumulating) into an amax slot of the fp16x2 family (see pnnp_conv3x3_h2_fwd_f32) */
+int pnnp_maxpool2_bwd_codes_amax_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                                     int accumulate, unsigned* amax_gx /*or null*/, void* stream);
 /* ---------------------------------------------------------------- the thin ends of the networks (csrc/thin.hip)
  * The 1x1 head conv10_1 (archs/Unet.py:80,93: nf -> out_nc, no activation) and the first 3x3 convolution's weight gradient
  * (archs/Unet.py:31 conv1_1, in_nc -> nf).  With 4 channels on one side these are HBM streams over the full-resolution
@@ -349,10 +352,15 @@ int pnnp_head_fwd_f32(const float* x, int xcs, int cin, const float* w /*[cout][
 int pnnp_head_bwd_f32(const float* g, int gcs, const float* x, int xcs, int cin, const float* w, float* gx, int gxcs, int mode,
                       float* dW, float* dbias /*or null*/, int B, int H, int W, int cout, int accumulate, float* ws, int64_t ws_floats,
                       void* stream);
+int pnnp_head_bwd_amax_f32(const float* g, int gcs, const float* x, int xcs, int cin, const float* w, float* gx, int gxcs, int mode,
+                           float* dW, float* dbias /*or null*/, int B, int H, int W, int cout, int accumulate, float* ws, int64_t ws_floats,
+                           unsigned* amax_gx /*or null: max |gx| into an amax slot of the fp16x2 family*/, void* stream);
 int pnnp_first_wgrad_supported(int cin, int cout, int H, int W);
 int64_t pnnp_first_wgrad_workspace_floats(int cout);
 int pnnp_first_fwd_f32(const float* x, int xcs, int cin, const float* w /*[cout][cin][3][3]*/, const float* bias /*or null*/, float* y, int ycs,
                        int B, int H, int W, int cout, int act /*0 none, 1 LeakyReLU(0.2), 2 ReLU*/, void* stream);
+int pnnp_first_fwd_amax_f32(const float* x, int xcs, int cin, const float* w, const float* bias /*or null*/, float* y, int ycs,
+                            int B, int H, int W, int cout, int act, unsigned* amax_y /*or null: max |y| into an amax slot*/, void* stream);
 int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x, int xcs, int cin, float* dW, float* dbias /*or null*/,
                               int B, int H, int W, int accumulate, float* ws, int64_t ws_floats, void* stream);
 /* boundary layout changes: NCHW [B][C][H][W] <-> NHWC [B][H][W][Cp] (Cp >= C, zero padded);

@@ -31,12 +31,16 @@ class ConvPolicy:
     kernels of csrc/thin.hip instead of the channel-padded GEMM kernels.  An engine takes DEFAULT_POLICY at construction; ``engine.set_policy(...)`` switches it (tests compare the
     families against each other at full size)."""
 
-    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True, thin=True, pool_fused=True):
+    def __init__(self, wino=True, wino_wgrad=True, wino_mink=32, x3=True, thin=True, pool_fused=True, h2=False):
         self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin = bool(wino), bool(wino_wgrad), int(wino_mink), bool(x3), bool(thin)
-        self.pool_fused = bool(pool_fused)         # training forward: MaxPool2d(2) in the epilogue of the bf16x3 conv in front of it
+        self.pool_fused = bool(pool_fused)         # training forward: MaxPool2d(2) in the epilogue of the bf16x3 / fp16x2 conv in front of it
+        # ``h2``: the 3x3 layers that qualify for x3 run on the fp16 matrix cores instead, float32 operands split into TWO scaled fp16 pieces
+        # (csrc/conv_h2s.hip, csrc/h2.h: half the matrix instructions of bf16x3; amax slots travel beside the tensors, the act' masks of the
+        # backward pass are the forward kernels' sign bits).  Opt-in (VERDICT round 4, item 1: default only once every float64 yardstick passes).
+        self.h2 = bool(h2)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -51,6 +55,13 @@ class ConvPolicy:
             return False, False
         return (ops.x3_supported(ci, co) and (c1 is None or c1 % 16 == 0),
                 ops.x3_supported(co, ci) and (c1 is None or c1 % 32 == 0))
+
+    def use_h2(self, co, ci, taps=9, c1=None):
+        """(forward, backward-data) of a 3x3 Conv2d(ci -> co) on the fp16x2 kernel?  Same shape rules as use_x3 (+ at most 1024 channels written)."""
+        if taps != 9 or not (self.h2 and self.x3):
+            return False, False
+        return (ops.h2_supported(ci, co) and (c1 is None or c1 % 16 == 0),
+                ops.h2_supported(co, ci) and (c1 is None or c1 % 32 == 0))
 
     def use_wino(self, co, ci, taps=9):
         """(forward, backward-data) of a Conv2d(ci -> co, taps) on the Winograd kernel?"""
@@ -81,7 +92,7 @@ class ConvPolicy:
         return self.wino and self.wino_wgrad and g_cs == cout and x_cs == c1 and ops.wino_wgrad_supported(h, w, cout, c1, c2)
 
 
-DEFAULT_POLICY = ConvPolicy(wino=os.environ.get('PNNP_WINO', '1') != '0', x3=os.environ.get('PNNP_X3', '1') != '0')      # host-side defaults only; the library reads no environment
+DEFAULT_POLICY = ConvPolicy(wino=os.environ.get('PNNP_WINO', '1') != '0', x3=os.environ.get('PNNP_X3', '1') != '0', h2=os.environ.get('PNNP_H2', '0') != '0')      # host-side defaults only; the library reads no environment
 
 
 class _EngineBase:
@@ -101,7 +112,7 @@ class _EngineBase:
         """``set_policy(x3=False)`` etc.: fields not named keep their current value."""
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
-                       thin=self.policy.thin, pool_fused=self.policy.pool_fused)
+                       thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
             cur.update(kw)
             policy = ConvPolicy(**cur)
         self.policy = self._pol = policy
@@ -188,6 +199,36 @@ class _Bufs:
             self.t[name] = b
         return b
 
+    # ---- fp16x2 family (csrc/h2.h): one 4-byte amax slot per tensor the kernels split, in two tables -- 'f' (activations, zeroed when a
+    # forward starts) and 'b' (gradients, zeroed when a backward starts) -- and the sign-bit images of the activations that serve as act' masks
+    NSLOTS = 64
+
+    def slots(self, which, device):
+        key = 'slots_' + which
+        t = self.t.get(key)
+        if t is None or t.device != device:
+            t = self.t[key] = torch.zeros(self.NSLOTS, dtype=torch.int32, device=device)
+            self.t[key + '_idx'] = {}
+        return t
+
+    def slot(self, which, name, device):
+        t = self.slots(which, device)
+        idx = self.t['slots_' + which + '_idx']
+        if name not in idx:
+            if len(idx) >= self.NSLOTS:
+                raise PnnpError('amax slot table full')
+            idx[name] = len(idx)
+        i = idx[name]
+        return t[i:i + 1]
+
+    def bits(self, name, B, H, W, C_, device):
+        n = ops.h2_bits_words(B, H, W, C_)
+        key = 'bits_' + name
+        b = self.t.get(key)
+        if b is None or b.numel() != n or b.device != device:
+            b = self.t[key] = torch.empty(n, dtype=torch.int32, device=device)
+        return b
+
 
 class UNetEngine(_EngineBase):
     """Forward / backward schedule of UNetSeeInDark over the C-ABI layer kernels."""
@@ -225,6 +266,7 @@ class UNetEngine(_EngineBase):
     def _build_pack_jobs(self, need_dgrad, dev, P):
         jobs = ops.PackJobs()
         self._x3, self._wn = {}, {}            # per layer: (forward, backward-data) on the bf16x3 / Winograd kernel
+        self._h2, self._wslot = {}, {}         # per layer: (forward, backward-data) fp16x2 packs; the weight tensor's amax slot
         def buf(key, n, dt=torch.float32):
             if key not in self.packed:
                 self.packed[key] = torch.empty(n, dtype=dt, device=dev)
@@ -239,9 +281,18 @@ class UNetEngine(_EngineBase):
             c1 = ci // 2 if (name.endswith('_1') and name[4] in '6789') else None       # decoder conv{6..9}_1 read cat([up, skip])
             xf, xd = self._pol.use_x3(co, cip, taps, c1)
             xd = xd and bwd
+            hf, hd = self._pol.use_h2(co, cip, taps, c1)
+            hf, hd = hf and xf, hd and xd
+            if hf or hd:                                           # the fp16x2 kernel takes what bf16x3 would have taken
+                self._h2[name] = (buf((name, dev, 'h2f'), ops.h2_weight_bytes(cip, co), torch.uint8) if hf else None,
+                                  buf((name, dev, 'h2d'), ops.h2_weight_bytes(co, ci), torch.uint8) if hd else None)
+                self._wslot[name] = jobs.add_h2(w, self._h2[name][0], self._h2[name][1], cin_pad=(cip + 15) // 16 * 16)
+                xf, xd = xf and not hf, xd and not hd
             wf, wd = self._wino(name, co, ci, taps)
             wf, wd = wf and not xf, wd and bwd and not xd
             df, dd = not (xf or wf), bwd and not (xd or wd)        # what is left for the direct fp32 kernels
+            if name in self._h2:
+                df, dd, wf, wd = df and not hf, dd and not hd, wf and not hf, wd and not hd
             self._x3[name], self._wn[name] = (xf, xd), (wf, wd)
             if df or dd:
                 jobs.add_conv(w, buf((name, dev, 'f'), taps * cip * co) if df else None, buf((name, dev, 'd'), taps * cop * ci) if dd else None,
@@ -323,14 +374,41 @@ class UNetEngine(_EngineBase):
         g = lambda n, s: bufs.get(n, s, dev)
         a = {}
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
+        # fp16x2 family: amax slots of the activations (keyed by the name of the layer that wrote the tensor; a pooled map shares its
+        # full-resolution map's slot) and, in a training forward, the sign bits of every LeakyReLU output that backward-data will need
+        h2_on = bool(self._h2)
+        if h2_on:
+            bufs.slots('f', dev).zero_()
+        sl = lambda n: bufs.slot('f', n, dev)
+        src_name = {}                          # id(tensor) -> the layer name its amax slot is keyed by
+
+        def produced(t, name, fused):
+            """`t` was just written by layer `name`; without a fused amax (and if an fp16x2 kernel will read it) a kernel of its own fills the slot."""
+            src_name[id(t)] = name
+            if h2_on and not fused:
+                ops.amax(t, sl(name))
+            return t
 
         def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
             y = out if out is not None else g(name, (B, h, w, cout))
+            hp = self._h2.get(name, (None, None))[0]
+            if hp is not None:
+                bits = bufs.bits(name, B, h, w, cout, dev) if (train and act == LRELU) else None
+                if bits is not None:
+                    a['bits:' + name] = bits
+                ops.conv_h2_fwd(src, src2, hp, self._wslot[name], P[name + '.bias'], y, cout, act, sl(src_name[id(src)]),
+                                sl(src_name[id(src2)]) if src2 is not None else None, amax_y=sl(name), bits_y=bits)
+                src_name[id(y)] = name
+                return y
+            if h2_on:
+                src_name[id(y)] = name
             if self._x3.get(name, (False, False))[0]:
-                return ops.conv_x3_fwd(src, src2, self._wx(name)[0], P[name + '.bias'], y, cout, act)
-            if self._wn.get(name, (False, False))[0]:
-                return ops.conv_wino_fwd(src, src2, self._wu(name)[0], P[name + '.bias'], y, cout, act)
-            return ops.conv_fwd(src, src2, self._w(name)[0], P[name + '.bias'], y, cout, taps, act)
+                ops.conv_x3_fwd(src, src2, self._wx(name)[0], P[name + '.bias'], y, cout, act)
+            elif self._wn.get(name, (False, False))[0]:
+                ops.conv_wino_fwd(src, src2, self._wu(name)[0], P[name + '.bias'], y, cout, act)
+            else:
+                ops.conv_fwd(src, src2, self._w(name)[0], P[name + '.bias'], y, cout, taps, act)
+            return produced(y, name, fused=False) if (h2_on and taps == 9) else y
 
         hs = [H >> i for i in range(5)]
         ws = [W >> i for i in range(5)]
@@ -339,14 +417,15 @@ class UNetEngine(_EngineBase):
             i = lvl + 1
             if lvl == 0 and self._pol.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
                 # conv1_1 on the streaming kernel: its 4 input channels are not worth a (padded) GEMM chunk
-                a['c1a'] = ops.first_fwd(cur, P['conv1_1.weight'], P['conv1_1.bias'], g('conv1_1', (B, H, W, ch[0])), LRELU)
+                a['c1a'] = produced(ops.first_fwd(cur, P['conv1_1.weight'], P['conv1_1.bias'], g('conv1_1', (B, H, W, ch[0])), LRELU,
+                                                  amax_y=sl('conv1_1') if h2_on else None), 'conv1_1', fused=True)
             else:
                 a[f'c{i}a'] = conv(f'conv{i}_1', cur, None, hs[lvl], ws[lvl], ch[lvl])
             if lvl == 4:
                 a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
                 continue
             codes = None
-            fused = self._pol.pool_fused and self._x3.get(f'conv{i}_2', (False, False))[0]
+            fused = self._pol.pool_fused and (self._x3.get(f'conv{i}_2', (False, False))[0] or self._h2.get(f'conv{i}_2', (None, None))[0] is not None)
             if train or fused:                     # argmax + sign codes: the backward pass then does not re-read the full-resolution map
                 codes = bufs.t.get(f'pc{i}')
                 shp = (B, hs[lvl + 1], ws[lvl + 1], ch[lvl])
@@ -354,14 +433,26 @@ class UNetEngine(_EngineBase):
                     codes = bufs.t[f'pc{i}'] = torch.empty(shp, dtype=torch.uint8, device=dev)
                 a[f'pc{i}'] = codes
             pooled = g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl]))
-            if fused:
+            hp = self._h2.get(f'conv{i}_2', (None, None))[0]
+            if hp is not None and self._pol.pool_fused:
+                # conv{i}_2 writes the pooled map, the codes, its amax (the pooled map is a subset) and the sign bits from its own epilogue
+                name = f'conv{i}_2'
+                bits = bufs.bits(name, B, hs[lvl], ws[lvl], ch[lvl], dev) if train else None
+                if bits is not None:
+                    a['bits:' + name] = bits
+                a[f'c{i}'] = ops.conv_h2_fwd_pool(a[f'c{i}a'], None, hp, self._wslot[name], P[name + '.bias'], g(name, (B, hs[lvl], ws[lvl], ch[lvl])),
+                                                  pooled, codes, ch[lvl], LRELU, sl(src_name[id(a[f'c{i}a'])]), amax_y=sl(name), bits_y=bits)
+                src_name[id(a[f'c{i}'])] = name
+                a[f'p{i}'] = pooled
+            elif fused:
                 # conv{i}_2 writes the pooled map and the codes from its own epilogue (csrc/conv_x3.hip)
-                a[f'c{i}'] = ops.conv_x3_fwd_pool(a[f'c{i}a'], None, self._wx(f'conv{i}_2')[0], P[f'conv{i}_2.bias'],
-                                                  g(f'conv{i}_2', (B, hs[lvl], ws[lvl], ch[lvl])), pooled, codes, ch[lvl], LRELU)
+                a[f'c{i}'] = produced(ops.conv_x3_fwd_pool(a[f'c{i}a'], None, self._wx(f'conv{i}_2')[0], P[f'conv{i}_2.bias'],
+                                                           g(f'conv{i}_2', (B, hs[lvl], ws[lvl], ch[lvl])), pooled, codes, ch[lvl], LRELU), f'conv{i}_2', fused=False)
                 a[f'p{i}'] = pooled
             else:
                 a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
                 a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], pooled, codes=codes)
+            src_name[id(a[f'p{i}'])] = f'conv{i}_2'                 # max |pooled| <= max |full-resolution map|
             cur = a[f'p{i}']
         cur = a['c5']
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
@@ -370,7 +461,7 @@ class UNetEngine(_EngineBase):
                 u = ops.convt_x3_fwd(cur, self._wx(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
             else:
                 u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
-            a[f'u{i}'] = u
+            a[f'u{i}'] = produced(u, f'upv{i}', fused=False)
             a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             cur = a[f'c{i}']
@@ -382,6 +473,7 @@ class UNetEngine(_EngineBase):
             ops.nhwc_to_nchw(o, out, residual=x if (self.m.res and add_residual) else None)
         if train:
             a['_pol'] = self._pol
+            a['_src_name'] = src_name
             self.saved = (a, (B, H, W, dev), gen)
         return out
 
@@ -403,13 +495,49 @@ class UNetEngine(_EngineBase):
         ws = [W >> i for i in range(5)]
         wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, W),), dev)
 
+        # fp16x2 family: amax slots of the gradients (keyed by the buffer name), zeroed per backward; the activations' slots are the forward's
+        h2_on = bool(self._h2)
+        if h2_on:
+            bufs.slots('b', dev).zero_()
+        src_name = a.get('_src_name', {})
+        slf = lambda t: bufs.slot('f', src_name[id(t)], dev)
+        gname = {}                             # id(gradient tensor) -> slot name
+
+        def gslot(t):
+            return bufs.slot('b', gname[id(t)], dev)
+
+        def gproduced(t, name, fused):
+            gname[id(t)] = name
+            if h2_on and not fused:
+                ops.amax(t, bufs.slot('b', name, dev))
+            return t
+
         def dgrad(name, gsrc, dx1, **kw):
+            hp = self._h2.get(name, (None, None))[1]
+            dx2 = kw.get('dx2')
+            if hp is not None:
+                # the act' masks as the forward kernels' sign bits where the masking activation came out of an fp16x2 layer
+                for k_mask, k_bits in (('mask1', 'bits1'), ('mask2', 'bits2')):
+                    m = kw.get(k_mask)
+                    if m is not None and ('bits:' + src_name.get(id(m), '?')) in a:
+                        kw[k_bits] = a['bits:' + src_name[id(m)]]
+                        kw[k_mask] = None
+                gname[id(dx1)] = 'd1:' + name
+                if dx2 is not None:
+                    gname[id(dx2)] = 'd2:' + name
+                ops.conv_h2_bwd_data(gsrc, gslot(gsrc), hp, self._wslot[name], dx1, amax_dx1=gslot(dx1),
+                                     amax_dx2=gslot(dx2) if dx2 is not None else None, **kw)
+                return
             if self._x3.get(name, (False, False))[1]:
                 ops.conv_x3_bwd_data(gsrc, self._wx(name)[1], dx1, **kw)
             elif self._wn.get(name, (False, False))[1]:
                 ops.conv_wino_bwd_data(gsrc, self._wu(name)[1], dx1, **kw)
             else:
                 ops.conv_bwd_data(gsrc, self._w(name)[1], dx1, **kw)
+            if h2_on:
+                gproduced(dx1, 'd1:' + name, fused=False)
+                if dx2 is not None:
+                    gproduced(dx2, 'd2:' + name, fused=False)
 
         def done(name):
             if on_ready is not None:
@@ -433,11 +561,13 @@ class UNetEngine(_EngineBase):
         g_cur = gb('c9', a['c9'].shape)
         if self._pol.use_thin_head(ch[0], self.cout, B * H * W):
             ops.head_bwd(g_out8, a['c9'], P['conv10_1.weight'], g_cur, G('conv10_1.weight', P['conv10_1.weight'].shape),
-                         G('conv10_1.bias', (self.cout,)), wsf, mode=LRELU, accumulate=acc)
+                         G('conv10_1.bias', (self.cout,)), wsf, mode=LRELU, accumulate=acc, amax_gx=bufs.slot('b', 'head', dev) if h2_on else None)
             done('conv10_1')
+            gproduced(g_cur, 'head', fused=True)
         else:
             wgrad('conv10_1', g_out8, self.cout, a['c9'], ch[0], taps=1)
             ops.conv_bwd_data(g_out8, self._w('conv10_1')[1], g_cur, mask1=a['c9'], mode1=LRELU, taps=1)
+            gproduced(g_cur, 'head', fused=False)
         for i in range(9, 5, -1):          # decoder, top-down
             lvl = 9 - i
             wgrad(f'conv{i}_2', g_cur, ch[lvl], a[f'c{i}a'], ch[lvl])
@@ -458,6 +588,7 @@ class UNetEngine(_EngineBase):
                 ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
             else:
                 ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
+            gproduced(g_cur, f'upv{i}', fused=False)
         dx = None
         for i in range(5, 0, -1):          # encoder, bottom-up
             lvl = i - 1
@@ -470,7 +601,9 @@ class UNetEngine(_EngineBase):
                 g_p = gb(f'p{i - 1}', src.shape)
                 dgrad(f'conv{i}_1', g_a, g_p)
                 g_cur = gb(f'c{i - 1}', a[f'c{i - 1}'].shape)      # already holds the skip gradient
-                ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1, codes=a.get(f'pc{i - 1}'))
+                # (the skip gradient + the scattered pooled gradient: a new tensor, a new amax slot)
+                ops.maxpool_bwd(a[f'c{i - 1}'], g_p, g_cur, LRELU, 1, codes=a.get(f'pc{i - 1}'), amax_gx=bufs.slot('b', f'pool{i - 1}', dev) if h2_on else None)
+                gproduced(g_cur, f'pool{i - 1}', fused=True)
             else:
                 if self._pol.use_thin_first(self.cin, ch[0], H, W, a['x8'].shape[3]):
                     ops.first_bwd_weight(g_a, ch[0], a['x8'], self.cin, G('conv1_1.weight', P['conv1_1.weight'].shape),

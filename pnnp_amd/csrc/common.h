@@ -58,3 +58,11 @@ static inline int pnnp_persistent_grid(int64_t tiles) {
     const int64_t wgs = (int64_t)cus * pnnp_get_persistent_split();
     return (int)(wgs < tiles ? wgs : tiles);
 }
+
+// amax slots of the fp16x2 family (csrc/h2.h): a wave's largest |stored value| -> atomicMax on the slot (non-negative floats order like their
+// bit patterns).  Call once per wave at the end of a kernel, all 64 lanes active.
+__device__ __forceinline__ void pnnp_amax_commit(float m, unsigned* slot) {
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
+}

@@ -166,7 +166,8 @@ maxpool_fwd_codes_kernel(const float* __restrict__ x, float* __restrict__ y, uns
 
 __global__ void __launch_bounds__(256)
 maxpool_bwd_codes_kernel(const unsigned char* __restrict__ codes, const float* __restrict__ gy, float* __restrict__ gx,
-                         int B, int H, int W, int C, int act_mode, int accumulate) {
+                         int B, int H, int W, int C, int act_mode, int accumulate, unsigned* __restrict__ amax) {
+    float amx = 0.f;                                                 // max |stored value| (the fp16x2 family's scale of gx: csrc/h2.h)
     const int h = H / 2, w = W / 2, cq = C / 4;
     const int64_t total = (int64_t)B * h * w * cq;
     const float slope = act_mode == 1 ? 0.2f : (act_mode == 2 ? 0.f : 1.f);
@@ -197,8 +198,10 @@ maxpool_bwd_codes_kernel(const unsigned char* __restrict__ codes, const float* _
             float4 v = make_float4(o[k][0], o[k][1], o[k][2], o[k][3]);
             if (accumulate) { const float4 t = *d; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             *d = v;
+            amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
     }
+    if (amax) pnnp_amax_commit(amx, amax);
 }
 
 // per-channel sum over pixels of an NHWC tensor: partial[blockIdx][C] then a fixed-order finish
@@ -381,13 +384,17 @@ int pnnp_maxpool2_fwd_codes_f32(const float* x, float* y, unsigned char* codes, 
 }
 
 // Backward of the pool (+ the activation in front of it) from the codes: same result as pnnp_maxpool2_bwd_f32 without reading x.
-int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
-                                int accumulate, void* stream) {
+int pnnp_maxpool2_bwd_codes_amax_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                                     int accumulate, unsigned* amax_gx, void* stream) {
     if (!codes || !gy || !gx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1) || (C & 3)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     hipLaunchKernelGGL(maxpool_bwd_codes_kernel, dim3(grid1d((int64_t)B * (H / 2) * (W / 2) * (C / 4))), dim3(256), 0, as_stream(stream),
-                       codes, gy, gx, B, H, W, C, act_mode, accumulate);
+                       codes, gy, gx, B, H, W, C, act_mode, accumulate, amax_gx);
     return pnnp_launch_status();
+}
+int pnnp_maxpool2_bwd_codes_f32(const unsigned char* codes, const float* gy, float* gx, int B, int H, int W, int C, int act_mode,
+                                int accumulate, void* stream) {
+    return pnnp_maxpool2_bwd_codes_amax_f32(codes, gy, gx, B, H, W, C, act_mode, accumulate, nullptr, stream);
 }
 
 // out[c] (+)= sum over pixels of x[pix][c];  workspace >= 1024*C floats

@@ -88,6 +88,7 @@ head_fwd_kernel(HeadFwd a) {
 struct HeadBwd {
     const float* g; const float* x; const float* w; float* gx; float* partial;
     int64_t npix; int gcs, xcs, gxcs, cin, cout, mode;
+    unsigned* amax;                     // max |gx| (csrc/h2.h) or null
 };
 
 // partial[block][4 * cin + 4]: dW[co][ci] for co < 4, then db[co]
@@ -106,6 +107,7 @@ head_bwd_kernel(HeadBwd a) {
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero, zero, zero, zero};
     f32x4 db = zero;
+    float amx = 0.f;
     const int64_t ngroups = a.npix >> 6;
     const int64_t wave0 = (int64_t)blockIdx.x * 4 + wv, nwaves = (int64_t)gridDim.x * 4;
     for (int64_t grp = wave0; grp < ngroups; grp += nwaves) {
@@ -129,11 +131,13 @@ head_bwd_kernel(HeadBwd a) {
                 for (int j = 0; j < 4; ++j) d[j] *= xv[k][j] > 0.f ? 1.f : slope;
             }
             *reinterpret_cast<f32x4*>(a.gx + (base + k * PPI + p) * a.gxcs + 4 * q) = d;
+            amx = fmaxf(fmaxf(amx, fmaxf(fabsf(d[0]), fabsf(d[1]))), fmaxf(fabsf(d[2]), fabsf(d[3])));
 #pragma unroll
             for (int co = 0; co < 4; ++co) acc[co] += xv[k] * g4[co];
             db += g4;
         }
     }
+    if (a.amax) pnnp_amax_commit(amx, a.amax);
     // lanes with the same q (other pixels) -> lane q; the bias sums only need the lanes of one q
 #pragma unroll
     for (int m = LPP; m < 64; m <<= 1) {
@@ -293,6 +297,7 @@ first_wgrad_kernel(FirstW a) {
 struct FirstF {
     const float* x; const float* w; const float* bias; float* y;
     int B, H, W, xcs, ycs, cin, act, tiles_w, ntiles;
+    unsigned* amax;                     // max |y| (csrc/h2.h) or null
 };
 
 template <int CO>
@@ -313,6 +318,7 @@ first_fwd_kernel(FirstF a) {
     const float bs = a.bias ? a.bias[co] : 0.f;
     const float slope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
     const int tiles_h = a.H / TR;
+    float amx = 0.f;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const int tw = tile % a.tiles_w, th = (tile / a.tiles_w) % tiles_h, b = tile / (a.tiles_w * tiles_h);
         const int h0 = th * TR, w0 = tw * FW_TW;
@@ -351,7 +357,7 @@ first_fwd_kernel(FirstF a) {
                 }
                 float v = (acc[0] + acc[1]) + bs;
                 v = fmaxf(v, slope * v);
-                if (col < nw) (row ? y1 : y0)[(int64_t)col * a.ycs] = v;
+                if (col < nw) { (row ? y1 : y0)[(int64_t)col * a.ycs] = v; amx = fmaxf(amx, fabsf(v)); }
             }
         };
         for (int w = 0; w < FW_TW; w += 3) {
@@ -366,6 +372,7 @@ first_fwd_kernel(FirstF a) {
             for (int r = 0; r < 4; ++r) s1[r] = xr[r * FW_LW + w + 5];
         }
     }
+    if (a.amax) pnnp_amax_commit(amx, a.amax);
 }
 
 // Sum of the per-workgroup partials in a fixed order, scattered to the torch layouts.
@@ -438,6 +445,12 @@ int pnnp_head_fwd_f32(const float* x, int xcs, int cin, const float* w, const fl
 int pnnp_head_bwd_f32(const float* g, int gcs, const float* x, int xcs, int cin, const float* w, float* gx, int gxcs, int mode,
                       float* dW, float* dbias, int B, int H, int W, int cout, int accumulate, float* ws, int64_t ws_floats,
                       void* stream) {
+    return pnnp_head_bwd_amax_f32(g, gcs, x, xcs, cin, w, gx, gxcs, mode, dW, dbias, B, H, W, cout, accumulate, ws, ws_floats, nullptr, stream);
+}
+// ... and max |gx| into an amax slot (csrc/h2.h: gx is what the fp16x2 backward kernels of conv9_2 split)
+int pnnp_head_bwd_amax_f32(const float* g, int gcs, const float* x, int xcs, int cin, const float* w, float* gx, int gxcs, int mode,
+                           float* dW, float* dbias, int B, int H, int W, int cout, int accumulate, float* ws, int64_t ws_floats,
+                           unsigned* amax_gx, void* stream) {
     const int64_t npix = (int64_t)B * H * W;
     if (!g || !x || !w || !gx || !dW || !ws || B < 0 || H <= 0 || W <= 0 || (xcs & 3) || (gcs & 3) || (gxcs & 3) || xcs < cin || gxcs < cin ||
         gcs < 4 || mode < 0 || mode > 2)
@@ -447,7 +460,7 @@ int pnnp_head_bwd_f32(const float* g, int gcs, const float* x, int xcs, int cin,
     const int np = 4 * cin + 4;
     const int blocks = thin_blocks((npix >> 6) / 4, 4);
     if (ws_floats < (int64_t)blocks * np) return PNNP_E_WORKSPACE;
-    HeadBwd a{g, x, w, gx, ws, npix, gcs, xcs, gxcs, cin, cout, mode};
+    HeadBwd a{g, x, w, gx, ws, npix, gcs, xcs, gxcs, cin, cout, mode, amax_gx};
     const dim3 grid(blocks), blk(256);
     switch (head_lpp(cin)) {
         case 4: hipLaunchKernelGGL(head_bwd_kernel<4>, grid, blk, 0, as_stream(stream), a); break;
@@ -490,11 +503,16 @@ int pnnp_first_bwd_weight_f32(const float* g, int gcs, int cout, const float* x,
 // says whether the layer qualifies.
 int pnnp_first_fwd_f32(const float* x, int xcs, int cin, const float* w, const float* bias, float* y, int ycs, int B, int H, int W, int cout,
                        int act, void* stream) {
+    return pnnp_first_fwd_amax_f32(x, xcs, cin, w, bias, y, ycs, B, H, W, cout, act, nullptr, stream);
+}
+// ... and max |y| into an amax slot (csrc/h2.h)
+int pnnp_first_fwd_amax_f32(const float* x, int xcs, int cin, const float* w, const float* bias, float* y, int ycs, int B, int H, int W, int cout,
+                            int act, unsigned* amax_y, void* stream) {
     if (!x || !w || !y || B < 0 || H <= 0 || W <= 0 || (xcs & 3) || xcs < 4 || ycs < cout || act < 0 || act > 2) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     if (!pnnp_first_wgrad_supported(cin, cout, H, W)) return PNNP_E_UNSUPPORTED;
     const int tr = 512 / cout;
-    FirstF a{x, w, bias, y, B, H, W, xcs, ycs, cin, act, ceil_div(W, FW_TW), 0};
+    FirstF a{x, w, bias, y, B, H, W, xcs, ycs, cin, act, ceil_div(W, FW_TW), 0, amax_y};
     a.ntiles = B * (H / tr) * a.tiles_w;
     const dim3 grid(thin_blocks(a.ntiles, FW_PER_CU)), blk(256);
     if (cout == 32) hipLaunchKernelGGL(first_fwd_kernel<32>, grid, blk, 0, as_stream(stream), a);

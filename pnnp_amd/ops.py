@@ -589,15 +589,15 @@ def head_fwd(x, weight, bias, out, residual=None):
     return out
 
 
-def head_bwd(g, x, weight, gx, dW, dbias, ws, mode=0, accumulate=0):
+def head_bwd(g, x, weight, gx, dW, dbias, ws, mode=0, accumulate=0, amax_gx=None):
     """Backward of the 1x1 head in one pass: gx [B,H,W,>=cin] = (g W) * act'(x), dW [cout,cin,1,1] and dbias (+)=.
     g [B,H,W,gcs>=4] (first cout channels), x [B,H,W,>=cin] the head's input (an activation output when mode != 0)."""
     require_cuda(g, x, weight, gx, dW, ws)
     B, H, W, gcs = g.shape
     cout, cin = weight.shape[0], weight.shape[1]
     with _Timed('head_bwd', 4.0 * B * H * W * cin * cout, 4.0 * B * H * W * (2 * cin + cout)):
-        check(_prep().pnnp_head_bwd_f32(ptr(g), gcs, ptr(x), x.shape[3], cin, ptr(weight), ptr(gx), gx.shape[3], mode, ptr(dW), ptr(dbias),
-                                        B, H, W, cout, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'head_bwd')
+        check(_prep().pnnp_head_bwd_amax_f32(ptr(g), gcs, ptr(x), x.shape[3], cin, ptr(weight), ptr(gx), gx.shape[3], mode, ptr(dW), ptr(dbias),
+                                             B, H, W, cout, accumulate, ptr(ws), _i64(ws.numel()), ptr(amax_gx), stream()), 'head_bwd')
 
 
 def first_wgrad_supported(cin, cout, H, W):
@@ -608,13 +608,14 @@ def first_wgrad_workspace_floats(cout):
     return int(_prep().pnnp_first_wgrad_workspace_floats(int(cout)))
 
 
-def first_fwd(x, weight, bias, y, act):
-    """y [B,H,W,>=cout] = act(conv3x3(x [B,H,W,xcs>=4], zero in channels cin..3; weight [cout,cin,3,3]) + bias) on the streaming kernel."""
+def first_fwd(x, weight, bias, y, act, amax_y=None):
+    """y [B,H,W,>=cout] = act(conv3x3(x [B,H,W,xcs>=4], zero in channels cin..3; weight [cout,cin,3,3]) + bias) on the streaming kernel.
+    ``amax_y``: an amax slot of the fp16x2 family (max |y| is raised into it)."""
     require_cuda(x, weight, y)
     B, H, W, xcs = x.shape
     cout, cin = weight.shape[0], weight.shape[1]
     with _Timed('first_fwd', 2.0 * B * H * W * cout * cin * 9, 4.0 * B * H * W * (cin + cout)):
-        check(_prep().pnnp_first_fwd_f32(ptr(x), xcs, cin, ptr(weight), ptr(bias), ptr(y), y.shape[3], B, H, W, cout, act, stream()), 'first_fwd')
+        check(_prep().pnnp_first_fwd_amax_f32(ptr(x), xcs, cin, ptr(weight), ptr(bias), ptr(y), y.shape[3], B, H, W, cout, act, ptr(amax_y), stream()), 'first_fwd')
     return y
 
 
@@ -638,14 +639,17 @@ def maxpool_fwd(x, y, codes=None):
     return y
 
 
-def maxpool_bwd(x, gy, gx, act_mode, accumulate, codes=None):
-    """gx (+)= routed(gy) * act'(x); with the forward pass's ``codes`` the full-resolution x is not read again."""
+def maxpool_bwd(x, gy, gx, act_mode, accumulate, codes=None, amax_gx=None):
+    """gx (+)= routed(gy) * act'(x); with the forward pass's ``codes`` the full-resolution x is not read again.  ``amax_gx`` (an amax slot of
+    the fp16x2 family): fused into the codes kernel, a kernel of its own behind the other."""
     require_cuda(x, gy, gx, codes)
     B, H, W, Cc = x.shape
     if codes is not None:
-        check(_prep().pnnp_maxpool2_bwd_codes_f32(ptr(codes), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd_codes')
+        check(_prep().pnnp_maxpool2_bwd_codes_amax_f32(ptr(codes), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, ptr(amax_gx), stream()), 'maxpool_bwd_codes')
     else:
         check(_prep().pnnp_maxpool2_bwd_f32(ptr(x), ptr(gy), ptr(gx), B, H, W, Cc, act_mode, accumulate, stream()), 'maxpool_bwd')
+        if amax_gx is not None:
+            amax(gx, amax_gx)
 
 
 def nchw_to_nhwc(src, dst, cp, reflect_pad=0):
