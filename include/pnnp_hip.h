@@ -231,6 +231,11 @@ int pnnp_conv3x3_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_
                                  float* dx1, int C1, const float* mask1, const unsigned* bits1, int mode1, int accum1, unsigned* amax_dx1,
                                  float* dx2 /*or null*/, int C2, const float* mask2, const unsigned* bits2, int mode2, int accum2, unsigned* amax_dx2,
                                  int B, int H, int W, void* stream);
+/* backward-weight: both operands are split on the fly; same workspace (pnnp_x3_wgrad_workspace_floats), supported shapes
+ * (pnnp_x3_wgrad_supported, pnnp_x3_wgrad_fits) and contract as pnnp_conv3x3_x3_bwd_weight_f32 */
+int pnnp_conv3x3_h2_bwd_weight_f32(const float* g, int g_cs, int Cout, const unsigned* amax_g, const float* x1, int x1_cs, int C1, const unsigned* amax_x1,
+                                   const float* x2 /*or null*/, int x2_cs, int C2, const unsigned* amax_x2, float* dW, float* dbias /*or null*/,
+                                   int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
 int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
                                      float* dx, int C1, const float* addsrc, const float* mask, int mode, unsigned* amax_dx,
                                      int B, int H, int W, void* stream);
@@ -246,6 +251,11 @@ int pnnp_pack_jobs_add_x3_s2(PnnpPackJob* jobs, int* n, int cap, const float* w,
 int pnnp_convt2x2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, void* stream);
 int pnnp_convt2x2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
                                   int B, int H, int W, void* stream);
+/* ... the same two with max |output| raised into an amax slot of the fp16x2 family (see pnnp_conv3x3_h2_fwd_f32) */
+int pnnp_convt2x2_x3_fwd_amax_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, unsigned* amax_y /*or null*/,
+                                  int B, int H, int W, int Cout, void* stream);
+int pnnp_convt2x2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
+                                       unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
 int pnnp_conv1x1_x3_fwd_f32(const float* x1, int C1, const float* x2 /*or null*/, int C2, const void* w_x3, const float* bias, const float* residual,
                             float* y, int B, int H, int W, int Cout, int act, void* stream);
 int pnnp_conv1x1_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx1, int C1, const float* mask1, int mode1, int accum1,

@@ -38,9 +38,10 @@ class ConvPolicy:
         # (csrc/conv_h2s.hip, csrc/h2.h: half the matrix instructions of bf16x3; amax slots travel beside the tensors, the act' masks of the
         # backward pass are the forward kernels' sign bits).  Opt-in (default only once every float64 yardstick passes).
         self.h2 = bool(h2)
+        self.h2_wgrad = bool(h2) and os.environ.get('PNNP_H2_WGRAD', '1') != '0'      # (host-side A/B switch: backward-weight stays on bf16x3 with 0)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -100,7 +101,7 @@ class _EngineBase:
     the training forward whose activations it needs."""
 
     def _init_base(self):
-        self.policy = ConvPolicy(*DEFAULT_POLICY.key())
+        self.policy = ConvPolicy(*DEFAULT_POLICY.key()[:7])
         self._pol = self.policy      # the effective policy of the current forward (effective_policy)
         self.saved = None
         self.gen = 0                 # bumped by every forward that (re)writes an activation buffer set
@@ -114,7 +115,10 @@ class _EngineBase:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
             cur.update(kw)
+            h2w = cur.pop('h2_wgrad', None)
             policy = ConvPolicy(**cur)
+            if h2w is not None:
+                policy.h2_wgrad = bool(h2w) and policy.h2
         self.policy = self._pol = policy
         self._pack_key = None        # re-pack for the other kernel family
         self._jobs_key = None
@@ -458,10 +462,12 @@ class UNetEngine(_EngineBase):
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
             lvl = 9 - i
             if self._x3.get(f'upv{i}', (False, False))[0]:
-                u = ops.convt_x3_fwd(cur, self._wx(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
+                u = ops.convt_x3_fwd(cur, self._wx(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl],
+                                     amax_y=sl(f'upv{i}') if h2_on else None)
+                a[f'u{i}'] = produced(u, f'upv{i}', fused=True)
             else:
                 u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
-            a[f'u{i}'] = produced(u, f'upv{i}', fused=False)
+                a[f'u{i}'] = produced(u, f'upv{i}', fused=False)
             a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             cur = a[f'c{i}']
@@ -545,6 +551,12 @@ class UNetEngine(_EngineBase):
 
         def wgrad(name, gpre, cout, x1, c1, x2=None, taps=9):
             c2 = x2.shape[3] if x2 is not None else 0
+            if (taps == 9 and h2_on and self._pol.h2_wgrad and id(gpre) in gname and id(x1) in src_name and (x2 is None or id(x2) in src_name) and
+                    self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=B, cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0))):
+                ops.conv_h2_bwd_weight(gpre, gslot(gpre), cout, x1, slf(x1), c1, x2, slf(x2) if x2 is not None else None,
+                                       G(name + '.weight', P[name + '.weight'].shape), G(name + '.bias', (cout,)), wsf, accumulate=acc)
+                done(name)
+                return
             if taps == 9 and self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=B,
                                                     cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(name + '.weight', P[name + '.weight'].shape),
@@ -585,10 +597,11 @@ class UNetEngine(_EngineBase):
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
             if self._x3.get(f'upv{i}', (False, False))[1]:
-                ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
+                ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU, amax_dx=bufs.slot('b', f'upv{i}', dev) if h2_on else None)
+                gproduced(g_cur, f'upv{i}', fused=True)
             else:
                 ops.convt_bwd_data(g_u, self._w(f'upv{i}')[1], g_cur, mask=below, mode=LRELU)
-            gproduced(g_cur, f'upv{i}', fused=False)
+                gproduced(g_cur, f'upv{i}', fused=False)
         dx = None
         for i in range(5, 0, -1):          # encoder, bottom-up
             lvl = i - 1

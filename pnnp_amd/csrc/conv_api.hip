@@ -294,19 +294,30 @@ int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* a
 int pnnp_gemm_x3_supported(int K, int N) { return (K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0) ? 1 : 0; }
 
 int pnnp_convt2x2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, void* stream) {
+    return pnnp_convt2x2_x3_fwd_amax_f32(x, Cin, w_x3, bias, y, nullptr, B, H, W, Cout, stream);
+}
+// ... and max |y| into an amax slot of the fp16x2 family (csrc/h2.h: y is what the decoder's first 3x3 layer splits)
+int pnnp_convt2x2_x3_fwd_amax_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, unsigned* amax_y,
+                                  int B, int H, int W, int Cout, void* stream) {
     if (!x || !w_x3 || !y || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     IgemmArgs a;
     convt_fwd_args(a, x, Cin, w_x3, bias, y, B, H, W, Cout);
+    a.amax_out[0] = amax_y;
     return pnnp_gemm_x3_launch(a, Cin, as_stream(stream));
 }
 
 int pnnp_convt2x2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
                                   int B, int H, int W, void* stream) {
+    return pnnp_convt2x2_x3_bwd_data_amax_f32(g, Cout, w_x3_dgrad, dx, Cin, mask, mode, nullptr, B, H, W, stream);
+}
+int pnnp_convt2x2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_x3_dgrad, float* dx, int Cin, const float* mask, int mode,
+                                       unsigned* amax_dx, int B, int H, int W, void* stream) {
     if (!g || !w_x3_dgrad || !dx || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     IgemmArgs a;
     convt_bwd_args(a, g, Cout, w_x3_dgrad, dx, Cin, mask, mode, B, H, W);
+    a.amax_out[0] = amax_dx;
     return pnnp_gemm_x3_launch(a, Cout, as_stream(stream));
 }
 

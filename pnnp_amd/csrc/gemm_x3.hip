@@ -422,6 +422,7 @@ int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
         b.chunks_per_seg = chan_per_seg / 16;                       // csrc/gemm_x3s.hip walks K in 16-channel items
         return pnnp_gemm_x3s_launch(b, s);
     }
+    if (a.amax_out[0] || a.amax_out[1]) return PNNP_E_UNSUPPORTED;  // (only the specialised kernel reports amax)
     // 128-column tiles unless they leave CUs idle (single-crop forwards): then 64-column tiles, twice as many
     int cus = pnnp_device_cus();
     if (cus < 1) cus = 256;

@@ -302,6 +302,7 @@ gemm_x3s_kernel(const IgemmArgs a) {
     // ---- epilogue, straight from the accumulators (a lane holds 4 consecutive channels of one pixel): sub-pixel scatter of ConvTranspose2d
     // forward (n_sub), strided / offset outputs (out_mul, out_yoff / out_xoff), two destinations (n_split), bias, activation, act' mask,
     // residual, accumulation -- csrc/gemm_x3.hip's contract
+    float amx0 = 0.f;                                                // max |stored value| of this lane, destination 0 (a.amax_out[0]; the launcher refuses [1])
     auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
         const int b = tl.b;
         const int p16 = lane & 15, c4 = (lane >> 4) * 4;
@@ -343,6 +344,11 @@ gemm_x3s_kernel(const IgemmArgs a) {
             return o;
         };
         auto take = [&](int mb, int j) { const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f}; return v; };
+        // max |.| of a stored block into the lane's running maximum of destination du (uniform); lanes whose store is dropped do not count
+        auto track = [&](f32x4 o, bool valid, int du) {
+            const float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+            amx0 = fmaxf(amx0, (valid && !du) ? m : 0.f);
+        };
         if constexpr (EK == EK_FWD || EK == EK_BWD) {
             constexpr bool MASKED = EK == EK_BWD;
             // FULL-LINE memory pattern (csrc/conv_x3s.hip): the two 16-column blocks of a 32-column block trade halves between lanes p and p + 8
@@ -411,6 +417,7 @@ gemm_x3s_kernel(const IgemmArgs a) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
                         }
+                        track(o0, vo[k][i][h] != OOB, du_[k]); track(o1, vo[k][i][h] != OOB, du_[k]);
                         const f32x4 ox = ror8(sel(lo8, o1, o0));
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h][0], 0, GXS_STORE_AUX);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo[k][i][h][1], 0, GXS_STORE_AUX);
@@ -446,6 +453,7 @@ gemm_x3s_kernel(const IgemmArgs a) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] *= (m2[i][h][c] > 0.f || !mm2) ? 1.f : msl;
                         o += pr2[i][h];
+                        track(o, vo[k][i][h] != OOB, du);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
                     }
             }
@@ -470,6 +478,7 @@ gemm_x3s_kernel(const IgemmArgs a) {
         GXS_T(t_bar)
         ++it; st = st == NSTAGE - 1 ? 0 : st + 1;
     }
+    if (a.amax_out[0]) pnnp_amax_commit(amx0, a.amax_out[0]);
 #ifdef GXS_STAMPS
     __builtin_amdgcn_s_waitcnt(0x0f70);
     if (lane == 0) {
@@ -506,6 +515,7 @@ int launch_gxs_ek(const IgemmArgs& b, hipStream_t s) {
 
 // `b`: validated by pnnp_gemm_x3_launch (csrc/gemm_x3.hip), with chunks_per_seg = 16-channel items per K segment.
 int pnnp_gemm_x3s_launch(const IgemmArgs& b, hipStream_t s) {
+    if (b.amax_out[1]) return PNNP_E_UNSUPPORTED;                   // (amax of the first destination only: what ConvTranspose2d needs)
     int cus = pnnp_device_cus();
     if (cus < 1) cus = 256;
     // the widest tile that still gives 3/4 of the CUs a tile: 256 px x 128, 512 px x 64, 256 px x 64; N = 32 (mod 64): 512 px x 32

@@ -55,4 +55,6 @@ struct IgemmArgs {
     float* pool_dst;
     unsigned char* pool_codes;
     int pool_cs;
+    // (csrc/gemm_x3s.hip) max |stored value| per destination into an amax slot of the fp16x2 family (csrc/h2.h), or null
+    unsigned* amax_out[2];
 };

@@ -1,0 +1,311 @@
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on the fp16 matrix cores, float32 operands split into two scaled fp16 pieces
+// (csrc/h2.h) -- the workgroup of csrc/wgrad_x3s.hip (12 consumer waves: block (mo, no) x filter row tr x pixel split wk; 4 producer waves;
+// pixel-major LDS images read through ds_read_b64_tr_b16; slabs with alternating signs, one reduce) with THREE v_mfma_f32_32x32x16_f16 per
+// (16-pixel k-step, tap) where the bf16x3 kernel issues six: (hi, lo') (lo, hi') (hi, hi').  Both operands are activations / gradients split
+// on the fly: G with 2^se_g (odd pixel splits: -2^se_g, the alternating sign costs nothing), X with 2^se_x from the amax slots of the
+// tensors; the slab values are multiplied by 2^-(se_g + se_x) where they leave the accumulators.  The LDS images are two planes instead of
+// three, (taller pixel tiles would fit; the producers' registers do not allow them yet).
+#include "common.h"
+#include "h2.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct Wh2sArgs {                       // (Wh2sArgs of csrc/wgrad_x3s.hip + the amax slots)
+    const float* G; int Gcs;            // [B][H][W][Gcs], channels [0, M) used
+    const float* X[2]; int Xcs[2];      // n < n_split -> X[0][n], else X[1][n - n_split]
+    int n_split;
+    int B, H, W, M, N;
+    float* slab;                        // [Z][9][M][N]
+    float* bias_slab;                   // [Z][M] or null
+    int Z;
+    const unsigned* amax_g; const unsigned* amax_x[2];      // amax slots of G and of the X tensor(s) (csrc/h2.h); amax_x[1] null without a second one
+};
+int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s);
+int pnnp_wh2s_th(int M, int N);
+
+namespace {
+
+constexpr int NCW = 12, NPW = 4, NTHR = 64 * (NCW + NPW);
+constexpr int XC = 34;
+constexpr unsigned OOB = 0x80000000u;
+#define WHS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifndef WX3_ALT_SIGN
+#define WX3_ALT_SIGN 1                 // odd pixel splits accumulate -G * X (csrc/wgrad_x3.hip: the matrix core's accumulation rounds toward minus infinity)
+#endif
+
+template <int MO, int NO, int TH> struct WsCfg {
+    static constexpr int WK = 4 / (MO * NO);                       // consumers that share a (block, filter row): pixel split inside the workgroup
+    static constexpr int KS = TH * 2, KSW = KS / WK;               // 16-pixel k-steps per pixel tile; per consumer
+    static constexpr int GPIX = TH * 32, XPIX = (TH + 2) * XC;
+    static constexpr int G_BYTES = MO * 2 * GPIX * 64, X_BYTES = NO * 2 * XPIX * 64, IMG_BYTES = G_BYTES + X_BYTES, LDS_BYTES = 2 * IMG_BYTES;
+    static constexpr int GT = 256 / MO, XT = 256 / NO;             // producer threads per 32-channel block of G / X
+    static constexpr int NG = GPIX * 8 / GT, NX = (XPIX * 8 + XT - 1) / XT;      // float4 staging slots per producer thread
+    static_assert(MO * NO * WK == 4 && KSW * WK == KS, "wave layout");
+    static_assert((GPIX * 8) % GT == 0, "G slots divide evenly (the bias sums count every pixel once)");
+    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NCW * 16 * 64 * 4, "LDS budget (images; the final reduction aliases them)");
+};
+
+// hi = f16(a s), lo = f16(a s - hi) of two values, packed (csrc/conv_h2s.hip)
+__device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& hi, unsigned& lo) {
+    unsigned h, l;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(a0), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(a1), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(l) : "v"(a0), "v"(s), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(a1), "v"(s), "v"(h));
+    hi = h; lo = l;
+}
+
+template <int MO, int NO, int TH>
+__global__ void __launch_bounds__(NTHR, 1)
+wgrad_h2s_kernel(const Wh2sArgs a) {
+    using Cfg = WsCfg<MO, NO, TH>;
+    constexpr int WK = Cfg::WK, KSW = Cfg::KSW, GPIX = Cfg::GPIX, XPIX = Cfg::XPIX, G_BYTES = Cfg::G_BYTES, IMG_BYTES = Cfg::IMG_BYTES, NG = Cfg::NG, NX = Cfg::NX;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0 .. 11 consumers, 12 .. 15 producers
+
+    unsigned axb = a.amax_x[0] ? a.amax_x[0][0] : 0u;
+    if (a.amax_x[1]) { const unsigned a2 = a.amax_x[1][0]; axb = a2 > axb ? a2 : axb; }
+    const int se_x = __builtin_amdgcn_readfirstlane(pnnp_h2_scale_exp(axb));
+    const int se_g = __builtin_amdgcn_readfirstlane(a.amax_g ? pnnp_h2_scale_exp(a.amax_g[0]) : 0);
+    const int n_tiles = a.N / (32 * NO);
+    int id = blockIdx.x;
+    const int z = id % a.Z; id /= a.Z;
+    const int ni = id % n_tiles, mi = id / n_tiles;
+    const int m0 = mi * 32 * MO, n0 = ni * 32 * NO;
+    const int tiles_x = (a.W + 31) >> 5, tiles_y = (a.H + TH - 1) / TH;
+    const int ntile = tiles_x * tiles_y * a.B;
+    if (z >= ntile) return;                                          // (Z <= ntile: never)
+
+    if (wave >= NCW) {
+        // =============================================== PRODUCER ===============================================
+        const int pw = wave - NCW;
+        const int q8 = lane & 7;                                     // channel quad of the block (8 lanes read a pixel's 128 contiguous bytes)
+        // the waves that stage 32-channel block gblk of G (GT threads) / xblk of X (XT threads): wave-uniform, like the tensors behind them
+        const int gblk = MO == 2 ? pw >> 1 : 0, lg = MO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
+        const int xblk = NO == 2 ? pw >> 1 : 0, lx = NO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
+        unsigned g_off[NG]; int g_r[NG], g_c[NG], g_dst[NG];
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int pix = (lg + Cfg::GT * k) >> 3;
+            g_r[k] = pix >> 5; g_c[k] = pix & 31;
+            g_off[k] = (unsigned)((g_r[k] * a.W + g_c[k]) * a.Gcs + q8 * 4) * 4u;
+            g_dst[k] = (gblk * 2 * GPIX + pix) * 64 + q8 * 8;       // byte offset in an image; + piece * GPIX * 64
+        }
+        const int xd = (n0 + 32 * xblk >= a.n_split) ? 1 : 0;        // wave-uniform source of this wave's X block
+        const int xch0 = n0 + 32 * xblk - (xd ? a.n_split : 0);
+        const int xcs = a.Xcs[xd];
+        unsigned x_off[NX]; int x_r[NX], x_c[NX], x_dst[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            int j = lx + Cfg::XT * k;
+            if (j >= XPIX * 8) j -= Cfg::XT;                         // a slot past the end repeats the thread's previous one
+            const int pix = j >> 3;
+            x_r[k] = pix / XC; x_c[k] = pix - x_r[k] * XC;          // halo coordinates: image pixel (y0 - 1 + r, x0 - 1 + c)
+            x_off[k] = (unsigned)((x_r[k] * a.W + x_c[k]) * xcs + q8 * 4) * 4u;
+            x_dst[k] = G_BYTES + (xblk * 2 * XPIX + pix) * 64 + q8 * 8;
+        }
+        const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * gblk), 0, 0x7fffffff, 0x00020000);
+        const int xshift = (a.W + 1) * xcs;                          // the X resource starts one row + one pixel BEFORE the tensor
+        const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X[xd] + xch0 - xshift), 0, 0x7fffffff, 0x00020000);
+        f32x4 rg[NG], rx[NX];
+        float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+        // the scales as floats; odd pixel splits stage -G (the matrix core's accumulation rounds toward minus infinity: csrc/wgrad_x3.hip)
+        const float sgs = __uint_as_float(((unsigned)(se_g + 127) << 23) | ((WX3_ALT_SIGN && (z & 1)) ? 0x80000000u : 0u));
+        const float sxs = __uint_as_float((unsigned)(se_x + 127) << 23);
+        auto load_tile = [&](int tile) {
+            int q = tile;
+            const int tx = q % tiles_x; q /= tiles_x;
+            const int ty = q % tiles_y;
+            const int b = q / tiles_y;
+            const int x0 = tx * 32, y0 = ty * TH;
+            const int gso = (((b * a.H + y0) * a.W) + x0) * a.Gcs * 4;
+            const int xso = ((((b * a.H + y0 - 1) * a.W) + x0 - 1) * xcs + xshift) * 4;
+            const int rlim = a.H - y0, clim = a.W - x0;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                const int bad = (rlim - 1 - g_r[k]) | (clim - 1 - g_c[k]);                 // sign bit set <=> pixel outside the image
+                rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, bad < 0 ? OOB : g_off[k], gso, 0));
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                const int yy = y0 - 1 + x_r[k], xx = x0 - 1 + x_c[k];
+                const int bad = yy | (a.H - 1 - yy) | xx | (a.W - 1 - xx);
+                rx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, bad < 0 ? OOB : x_off[k], xso, 0));
+            }
+        };
+        auto stage = [&](f32x4 v, float sc, char* ib, int dst, int pstride) {
+            unsigned h0, l0, h1, l1;
+            split_h2(v.x, v.y, sc, h0, l0);
+            split_h2(v.z, v.w, sc, h1, l1);
+            *reinterpret_cast<u32x2*>(ib + dst) = u32x2{h0, h1};
+            *reinterpret_cast<u32x2*>(ib + dst + pstride) = u32x2{l0, l1};
+        };
+        auto stage_tile = [&](int img) {
+            char* ib = smem + img * IMG_BYTES;
+#pragma unroll
+            for (int k = 0; k < NG; ++k) {
+                f32x4 v = rg[k];
+                bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;     // bias gradient: column sums of G (unscaled, unsigned)
+                stage(v, sgs, ib, g_dst[k], GPIX * 64);
+            }
+#pragma unroll
+            for (int k = 0; k < NX; ++k) stage(rx[k], sxs, ib, x_dst[k], XPIX * 64);
+        };
+        // the first tile straight into image 0, the second into the registers
+        load_tile(z);
+        stage_tile(0);
+        if (z + a.Z < ntile) load_tile(z + a.Z);
+        int img = 0;
+        for (int tile = z; tile < ntile; tile += a.Z) {
+            WHS_BARRIER();                                          // image img is complete; every consumer is done with the other one
+            if (tile + a.Z < ntile) {
+                stage_tile(img ^ 1);                                // the next tile (requested a whole tile ago)
+                if (tile + 2 * a.Z < ntile) load_tile(tile + 2 * a.Z);
+            }
+            img ^= 1;
+        }
+        // ---- (the consumers' pixel-split reduction: 2 barriers per tap of a row when WK > 1) then the bias gradient of this pixel split: add up
+        // the threads that share (block, q8) through LDS (the images are dead)
+        if (WK > 1) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) WHS_BARRIER();
+        }
+        WHS_BARRIER();
+        constexpr int NSLOTS = Cfg::GT / 8;                           // threads per (block, quad)
+        if (a.bias_slab && ni == 0) {                               // block-uniform
+            float* bs = reinterpret_cast<float*>(smem);             // [MO blocks][8 quads][4][NSLOTS]
+            const int slot = lg >> 3;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) bs[((gblk * 8 + q8) * 4 + c) * NSLOTS + slot] = bsum[c];
+        }
+        WHS_BARRIER();
+        if (a.bias_slab && ni == 0 && pw < 1 && lane < 32 * MO) {    // one producer wave: 32 MO channels
+            float* bs = reinterpret_cast<float*>(smem);
+            const int b2 = lane >> 5, ch = lane & 31;
+            float s = 0.f;
+            for (int k = 0; k < NSLOTS; ++k) s += bs[((b2 * 8 + (ch >> 2)) * 4 + (ch & 3)) * NSLOTS + k];
+            a.bias_slab[(int64_t)z * a.M + m0 + b2 * 32 + ch] = (WX3_ALT_SIGN && (z & 1)) ? -s : s;      // (the reduce kernel adds odd splits with a minus sign)
+        }
+        return;
+    }
+
+    // =============================================== CONSUMER ===============================================
+    const int tr = wave % 3, rest = wave / 3;                        // filter row; (block, pixel split)
+    const int wk = rest % WK, no = (rest / WK) % NO, mo = rest / (WK * NO);
+    const int l31 = lane & 31, half = lane >> 5;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    // transposed-read lane geometry (csrc/wgrad_x3.hip): 16-lane group g reads channels 16 (g & 1) .., pixels 8 (g >> 1) ..; inside a group lane
+    // 4 q + p supplies the address of pixel row q, channel chunk 4 p
+    const int tr_lane = ((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    auto tr_read = [&](const char* base) {                           // 8 pixels x 1 channel per lane: two transposed reads
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * 64));
+        const u32x2 a0 = __builtin_bit_cast(u32x2, lo), a1 = __builtin_bit_cast(u32x2, hi);
+        return u32x4{a0.x, a0.y, a1.x, a1.y};
+    };
+    int img = 0;
+    for (int tile = z; tile < ntile; tile += a.Z) {
+        WHS_BARRIER();
+        const char* gimg = smem + img * IMG_BYTES;
+        const char* ximg = gimg + G_BYTES;
+        u32x4 av[2][2], bv[2][2];
+        auto gload = [&](int kl, u32x4 (&ax)[2]) {                   // kl: this consumer's kl-th k-step of the tile
+            const int ks = wk * KSW + kl;
+            const char* gbase = gimg + ((mo * 2) * GPIX + (ks >> 1) * 32 + (ks & 1) * 16) * 64 + tr_lane;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) ax[p] = tr_read(gbase + p * GPIX * 64);
+        };
+        auto xload = [&](int kl, int dx, u32x4 (&bx)[2]) {
+            const int ks = wk * KSW + kl;
+            const char* xbase = ximg + ((no * 2) * XPIX + ((ks >> 1) + tr) * XC + (ks & 1) * 16 + dx) * 64 + tr_lane;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bx[p] = tr_read(xbase + p * XPIX * 64);
+        };
+        gload(0, av[0]);
+        xload(0, 0, bv[0]);
+#pragma unroll
+        for (int kl = 0; kl < KSW; ++kl) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int s = kl * 3 + dx;
+                // the next step's X words (and, at a k-step's last tap, the next k-step's G words) one step ahead
+                if (s + 1 < KSW * 3) xload((s + 1) / 3, (s + 1) % 3, bv[(s + 1) & 1]);
+                if (dx == 2 && kl + 1 < KSW) gload(kl + 1, av[(kl + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+                const u32x4 (&ax)[2] = av[kl & 1];
+                const u32x4 (&bx)[2] = bv[s & 1];
+                // smallest terms first: (hi, lo') (lo, hi') (hi, hi')
+#define WHS_MFMA(PA, PB) acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[PA]), __builtin_bit_cast(f16x8, bx[PB]), acc[dx], 0, 0, 0)
+                WHS_MFMA(0, 1); WHS_MFMA(1, 0); WHS_MFMA(0, 0);
+#undef WHS_MFMA
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        img ^= 1;
+    }
+    // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one tap at a time), then the slab [z][tap][m][n]:
+    // 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
+    float* red = reinterpret_cast<float*>(smem);
+    const int dexp = -(se_g + se_x);                                 // undo the operand scales (exact: a power of two)
+    const int64_t slab_base = (int64_t)z * a.M * a.N * 9;
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+        f32x16 v = acc[dx];
+        if (WK > 1) {
+            WHS_BARRIER();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = v[r];
+            WHS_BARRIER();
+            if (wk == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < WK; ++k) s += red[((wave + 3 * k) * 16 + r) * 64 + lane];      // (the split index steps the wave number by 3)
+                    v[r] = s;
+                }
+            }
+        }
+        if (wk == 0) {
+            const int t = tr * 3 + dx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + no * 32 + l31, m = m0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = __builtin_ldexpf(v[r], dexp);
+            }
+        }
+    }
+    WHS_BARRIER();                                                  // (the producers' bias reduction: two more barriers for every wave)
+    WHS_BARRIER();
+}
+
+template <int MO, int NO, int TH>
+int launch_whs(const Wh2sArgs& a, hipStream_t s) {
+    using Cfg = WsCfg<MO, NO, TH>;
+    auto kern = wgrad_h2s_kernel<MO, NO, TH>;
+    static PnnpPerDevice lds_once;
+    if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
+    const int blocks = (a.M / (32 * MO)) * (a.N / (32 * NO)) * a.Z;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(NTHR), Cfg::LDS_BYTES, s, a);
+    return pnnp_launch_status();
+}
+
+}  // namespace
+
+// pixel-tile height of the configuration for (M, N): as csrc/wgrad_x3s.hip (taller tiles fit the LDS with two planes per operand, but the
+// producers' per-slot address registers do not fit 128 registers then)
+int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? 2 : 3) : ((N % 64 == 0) ? 2 : 4); }
+
+int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s) {
+    if (a.M % 64 == 0) return a.N % 64 == 0 ? launch_whs<2, 2, 2>(a, s) : launch_whs<2, 1, 3>(a, s);
+    return a.N % 64 == 0 ? launch_whs<1, 2, 2>(a, s) : launch_whs<1, 1, 4>(a, s);
+}

@@ -34,6 +34,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 struct Wx3sArgs { const float* G; int Gcs; const float* X[2]; int Xcs[2]; int n_split; int B, H, W, M, N; float* slab; float* bias_slab; int Z; };
 int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s);           // csrc/wgrad_x3s.hip
 int pnnp_wx3s_th(int M, int N);                                     // its pixel-tile height for (M, N)
+struct Wh2sArgs { const float* G; int Gcs; const float* X[2]; int Xcs[2]; int n_split; int B, H, W, M, N; float* slab; float* bias_slab; int Z;
+                  const unsigned* amax_g; const unsigned* amax_x[2]; };
+int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s);           // csrc/wgrad_h2s.hip (fp16x2: same tiles, same slabs, same reduce)
 
 namespace {
 
@@ -674,6 +677,35 @@ int pnnp_conv3x3_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
     const int64_t n = (int64_t)Cout * N * 9, ntot = n + (dbias ? Cout : 0);       // n % 32 == 0 (channels in multiples of 32)
     hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((ntot + 31) / 32 > 4096 ? 4096 : (ntot + 31) / 32)), dim3(256), 0, st,
                        a.slab, dW, n, a.Z, accumulate, (int64_t)Cout * N, 9, dbias ? a.bias_slab : nullptr, dbias, Cout);
+    return pnnp_launch_status();
+}
+
+// The same weight gradient on the fp16 matrix cores (csrc/wgrad_h2s.hip, csrc/h2.h): both operands are split into two scaled fp16 pieces
+// on the fly, so each comes with its amax slot.  Same tiles, slabs, workspace and reduce as the bf16x3 kernel above.
+int pnnp_conv3x3_h2_bwd_weight_f32(const float* g, int g_cs, int Cout, const unsigned* amax_g, const float* x1, int x1_cs, int C1, const unsigned* amax_x1,
+                                   const float* x2, int x2_cs, int C2, const unsigned* amax_x2, float* dW, float* dbias,
+                                   int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
+    if (!g || !x1 || !dW || !workspace || !amax_g || !amax_x1 || (x2 && !amax_x2) || B <= 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    const int N = C1 + (x2 ? C2 : 0);
+    if (!pnnp_x3_wgrad_supported(H, W, Cout, C1, x2 ? C2 : 0)) return PNNP_E_UNSUPPORTED;
+    if (g_cs < Cout || x1_cs < C1 || (x2 && x2_cs < C2) || (g_cs & 3) || (x1_cs & 3) || (x2 && (x2_cs & 3))) return PNNP_E_INVALID;
+    if ((((uintptr_t)g) | ((uintptr_t)x1) | ((uintptr_t)x2)) & 15) return PNNP_E_INVALID;
+    const int cmax = g_cs > x1_cs ? g_cs : x1_cs;
+    if (!pnnp_x3_wgrad_fits(B, H, W, cmax) || (x2 && !pnnp_x3_wgrad_fits(B, H, W, x2_cs))) return PNNP_E_UNSUPPORTED;
+    if (workspace_floats < pnnp_x3_wgrad_workspace_floats(B, H, W, Cout, N)) return PNNP_E_WORKSPACE;
+    hipStream_t st = as_stream(stream);
+    Wh2sArgs b{};
+    b.G = g; b.Gcs = g_cs; b.X[0] = x1; b.Xcs[0] = x1_cs; b.X[1] = x2 ? x2 : x1; b.Xcs[1] = x2 ? x2_cs : x1_cs; b.n_split = x2 ? C1 : (1 << 30);
+    b.B = B; b.H = H; b.W = W; b.M = Cout; b.N = N;
+    b.Z = wx3_splits(B, H, W, Cout, N);                              // (the specialised kernels share their tile heights)
+    b.slab = workspace;
+    b.bias_slab = dbias ? workspace + (int64_t)b.Z * 9 * Cout * N : nullptr;
+    b.amax_g = amax_g; b.amax_x[0] = amax_x1; b.amax_x[1] = x2 ? amax_x2 : nullptr;
+    const int rc = pnnp_wh2s_launch(b, st);
+    if (rc != PNNP_OK) return rc;
+    const int64_t n = (int64_t)Cout * N * 9, ntot = n + (dbias ? Cout : 0);
+    hipLaunchKernelGGL(wx3_reduce_kernel, dim3((unsigned)((ntot + 31) / 32 > 4096 ? 4096 : (ntot + 31) / 32)), dim3(256), 0, st,
+                       b.slab, dW, n, b.Z, accumulate, (int64_t)Cout * N, 9, dbias ? b.bias_slab : nullptr, dbias, Cout);
     return pnnp_launch_status();
 }
 

@@ -307,19 +307,19 @@ def x3mat_bytes(K, N):
     return int(_prep().pnnp_x3mat_bytes(int(K), int(N)))
 
 
-def convt_x3_fwd(x, w_x3, bias, y, cout):
+def convt_x3_fwd(x, w_x3, bias, y, cout, amax_y=None):
     require_cuda(x, w_x3, y)
     B, H, W, Cin = x.shape
     with _Timed('convt_fwd_x3', 8.0 * B * H * W * Cin * cout, 4.0 * B * H * W * (Cin + 4 * cout)):
-        check(_prep().pnnp_convt2x2_x3_fwd_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), B, H, W, cout, stream()), 'convt_x3_fwd')
+        check(_prep().pnnp_convt2x2_x3_fwd_amax_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), ptr(amax_y), B, H, W, cout, stream()), 'convt_x3_fwd')
     return y
 
 
-def convt_x3_bwd_data(g, w_x3_dgrad, dx, mask=None, mode=0):
+def convt_x3_bwd_data(g, w_x3_dgrad, dx, mask=None, mode=0, amax_dx=None):
     require_cuda(g, w_x3_dgrad, dx)
     B, H, W, Cin = dx.shape
     with _Timed('convt_dgrad_x3', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
-        check(_prep().pnnp_convt2x2_x3_bwd_data_f32(ptr(g), g.shape[3], ptr(w_x3_dgrad), ptr(dx), Cin, ptr(mask), mode, B, H, W, stream()),
+        check(_prep().pnnp_convt2x2_x3_bwd_data_amax_f32(ptr(g), g.shape[3], ptr(w_x3_dgrad), ptr(dx), Cin, ptr(mask), mode, ptr(amax_dx), B, H, W, stream()),
               'convt_x3_bwd_data')
 
 
@@ -376,6 +376,17 @@ def conv_x3_bwd_weight(g, cout, x1, c1, x2, dW, dbias, workspace, accumulate=0):
         check(_prep().pnnp_conv3x3_x3_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), c2, c2, ptr(dW), ptr(dbias),
                                                      B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
               'conv_x3_bwd_weight')
+
+
+def conv_h2_bwd_weight(g, amax_g, cout, x1, amax_x1, c1, x2, amax_x2, dW, dbias, workspace, accumulate=0):
+    """dW [cout][c1+c2][3][3] (+ dbias) on the fp16 matrix cores, both operands split in two scaled pieces (contract of conv_x3_bwd_weight + slots)."""
+    require_cuda(g, x1, dW, workspace, amax_g, amax_x1)
+    B, H, W, gcs = g.shape
+    c2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_wgrad_h2', 2.0 * B * H * W * cout * (c1 + c2) * 9, 4.0 * B * H * W * (gcs + x1.shape[3] + c2)):
+        check(_prep().pnnp_conv3x3_h2_bwd_weight_f32(ptr(g), gcs, cout, ptr(amax_g), ptr(x1), x1.shape[3], c1, ptr(amax_x1), ptr(x2), c2, c2, ptr(amax_x2),
+                                                     ptr(dW), ptr(dbias), B, H, W, int(accumulate), ptr(workspace), C.c_int64(workspace.numel()), stream()),
+              'conv_h2_bwd_weight')
 
 
 def wino_supported(K, N):

@@ -377,3 +377,56 @@ def test_h2_nan_and_inf_propagate():
         y = torch.zeros((B, H, W, Co), device='cuda')
         ops.conv_h2_fwd(xb, None, f, sw, None, y, Co, 0, _slot(xb))
         assert not torch.isfinite(y[0, 4:7, 6:9]).all()
+
+
+# ---- backward-weight on the fp16 matrix cores (csrc/wgrad_h2s.hip): the cases and bars of tests/test_gpu_x3.py::test_x3_bwd_weight / the float64 yardstick
+@pytest.mark.parametrize('case', [(2, 16, 48, 32, 0, 32), (1, 12, 40, 32, 0, 64), (1, 6, 70, 64, 0, 128), (2, 8, 32, 32, 32, 32),
+                                  (1, 8, 36, 64, 64, 64), (1, 5, 17, 128, 128, 128), (1, 4, 4, 256, 0, 256), (1, 16, 32, 32, 0, 256),
+                                  (3, 32, 64, 32, 0, 32), (2, 16, 32, 64, 64, 64), (3, 19, 50, 64, 32, 96), (1, 9, 33, 96, 0, 32)])
+def test_h2_bwd_weight(case):
+    from pnnp_amd import ops
+    B, H, W, C1, C2, Co = case
+    w = _rand(Co, C1 + C2, 3, 3, seed=3, scale=0.2).requires_grad_(True)
+    b = _rand(Co, seed=4).requires_grad_(True)
+    g = _rand(B, Co, H, W, seed=5)
+    x1 = _rand(B, C1, H, W, seed=1); x2 = _rand(B, C2, H, W, seed=2) if C2 else None
+    xin = torch.cat([x1, x2], 1) if C2 else x1
+    F.conv2d(xin, w, b, padding=1).backward(g)
+    assert ops.x3_wgrad_supported(H, W, Co, C1, C2)
+    ws = torch.empty(ops.x3_wgrad_workspace_floats(B, H, W, Co, C1 + C2), device='cuda')
+    gc, x1c, x2c = nhwc(g).cuda(), nhwc(x1).cuda(), nhwc(x2).cuda() if C2 else None
+    sg, s1, s2 = _slot(gc), _slot(x1c), _slot(x2c) if C2 else None
+    dW = torch.full(w.shape, float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_h2_bwd_weight(gc, sg, Co, x1c, s1, C1, x2c, s2, dW, db, ws)
+    close(dW, w.grad, rtol=2e-4, atol=2e-5, what=f'h2 wgrad {case}')
+    close(db, b.grad, rtol=2e-4, atol=2e-5, what=f'h2 bgrad {case}')
+    ops.conv_h2_bwd_weight(gc, sg, Co, x1c, s1, C1, x2c, s2, dW, db, ws, accumulate=1)
+    close(dW, 2 * w.grad, rtol=2e-4, atol=2e-5, what='h2 wgrad accumulate')
+    close(db, 2 * b.grad, rtol=2e-4, atol=4e-5, what='h2 bgrad accumulate')
+    dW2 = torch.full(w.shape, float('nan'), device='cuda')
+    ops.conv_h2_bwd_weight(gc, sg, Co, x1c, s1, C1, x2c, s2, dW2, None, ws)
+    close(dW2, w.grad, rtol=2e-4, atol=2e-5, what='h2 wgrad without dbias')
+
+
+@pytest.mark.parametrize('shape', [(16, 512, 512, 32, 32), (4, 128, 128, 64, 128)])
+def test_h2_wgrad_is_as_accurate_as_the_fp32_mfma_kernel(shape):
+    """K = 16 x 512 x 512 = 4.2 M terms per weight at the benchmark's top level, operands spanning 4 decades across channels: relative L2 AND
+    max-element error (per (co, ci) scale) within 2x the fp32-MFMA backward-weight kernel's, against float64 sums."""
+    from pnnp_amd import ops
+    from test_gpu_x3 import _f64_wgrad
+    B, H, W, Ci, Co = shape
+    gen = torch.Generator(device='cuda').manual_seed(2)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen) * torch.logspace(-2, 2, Ci, device='cuda').roll(5)
+    g = torch.randn(B, H, W, Co, device='cuda', generator=gen) * torch.logspace(-3, 1, Co, device='cuda')
+    ref = _f64_wgrad(g, x)
+    ws = torch.empty(max(ops.x3_wgrad_workspace_floats(B, H, W, Co, Ci), ops.wgrad_workspace_floats(B, H, W, Co, Ci, 9)), device='cuda')
+    d2 = torch.empty(Co, Ci, 3, 3, device='cuda'); d32 = torch.empty_like(d2)
+    ops.conv_h2_bwd_weight(g, _slot(g), Co, x, _slot(x), Ci, None, None, d2, None, ws)
+    ops.conv_bwd_weight(g, Co, x, Ci, None, d32, None, 9, ws)
+    rn = ref.norm()
+    e2, e32 = float((d2.double() - ref).norm() / rn), float((d32.double() - ref).norm() / rn)
+    scale = ref.abs().amax(dim=(2, 3), keepdim=True).clamp_min(1e-30)
+    m2, m32 = float(((d2.double() - ref).abs() / scale).max()), float(((d32.double() - ref).abs() / scale).max())
+    print(f'wgrad {shape} vs float64: rel L2 h2 {e2:.2e} fp32-MFMA {e32:.2e}; max-element (per (co,ci) scale) h2 {m2:.2e} fp32-MFMA {m32:.2e}')
+    assert e2 < 2.0 * e32 + 1e-8, (e2, e32)
+    assert m2 < 2.0 * m32 + 1e-7, (m2, m32)

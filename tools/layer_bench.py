@@ -79,6 +79,8 @@ def main():
         if a.h2:
             fns['fwd'] = lambda: ops.conv_h2_fwd(x1, x2, fh, sw, bias, y, Co, 1, s1, s2, amax_y=sy, bits_y=by)
             if C1 % 32 == 0:
+                ws3h = torch.empty(max(1, ops.x3_wgrad_workspace_floats(B, H, H, Co, C1 + C2)), device=dev)
+                fns['wgrad'] = lambda: ops.conv_h2_bwd_weight(g, sg, Co, x1, s1, C1, x2, s2, dW, db, ws3h)
                 if a.h2_fmask:
                     fns['dgrad'] = lambda: ops.conv_h2_bwd_data(g, sg, dh, sw, dx1, mask1=x1, mode1=1, amax_dx1=sd1, dx2=dx2, mask2=x2, mode2=1, amax_dx2=sd2)
                 else:
