@@ -337,6 +337,9 @@ def main():
         per_rank = torch.tensor([[1e3 * dt_own / args.steps, sum(waits) / len(waits), max(waits)]], dtype=torch.float64)
     dt = float(tmax.item())
     loss_val = float(loss[0])
+    if not np.isfinite(loss_val):
+        # a number measured on a diverged network is not a measurement (NaN / inf operands even run FASTER on this power-limited chip)
+        raise SystemExit(f'bench: the training loss is {loss_val} after {args.warmup + args.steps} steps: the step is broken, no throughput is reported')
     spread = ts.replica_checksum() if world > 1 else None      # 0.0: every rank holds bit-identical weights after the run
 
     if rank == 0:
@@ -345,7 +348,7 @@ def main():
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": ("f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the fp16 matrix cores through a per-tensor-scaled 2-way split, 22 significand bits per operand: csrc/h2.h; backward-weight and the pointwise layers on the bf16 matrix cores through the exact 3-way split)" if getattr(pol, 'h2', False) else "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)") if pol.x3 else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": ("f32 (operands, accumulation and results; 3x3 forward / backward-data / backward-weight multiply on the fp16 matrix cores through a per-tensor-scaled 2-way split, 22 significand bits per operand: csrc/h2.h; ConvTranspose2d on the bf16 matrix cores through the exact 3-way split)" if getattr(pol, 'h2', False) else "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)") if pol.x3 else "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else f"NoiseFlow.sample proxy (iso 6400, ratio in {{1,2,4,8,16}}, BatchNorm in {args.proxy_mode} mode)") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},

@@ -66,3 +66,7 @@ __device__ __forceinline__ void pnnp_amax_commit(float m, unsigned* slot) {
     for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(slot, __float_as_uint(m));
 }
+
+// Tensor.clamp / np.clip semantics: a NaN stays a NaN (fminf / fmaxf return the OTHER operand for a NaN, which would turn a diverged network's
+// output into a finite loss or PSNR).  Comparisons with a NaN are false, so it falls through both selects.
+__device__ __forceinline__ float pnnp_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

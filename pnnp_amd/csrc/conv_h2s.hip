@@ -25,12 +25,12 @@ namespace {
 constexpr int NCW = 8, NPW = 4, NTHR = 64 * (NCW + NPW);           // consumer / producer waves
 constexpr int MT = 2, TH = NCW * MT, HR = TH + 2, HC = 34, NPIX = HR * HC;     // 16-row x 32-px tile, 612 halo pixels
 // halo image in 16-byte words: [piece 2][k-octet 2][pixel, plane padded to a multiple of 16 words]; the 12 padding words of the hi planes are
-// ZERO (written once): the unpaired ninth tap's "other half" reads them
+// ZERO (written once; see the prologue)
 constexpr int NPIXP = (NPIX + 15) / 16 * 16;                       // 624
 constexpr int XS_F4 = 2 * 2 * NPIXP, XS_BYTES = XS_F4 * 16;        // 2496 words, 39936 bytes
 #define XS_PLANE(piece, oct) (((piece) * 2 + (oct)) * NPIXP)
-constexpr int WPLANE = 9 * 2 * 32 * 16;                            // one piece of one 32-channel block of one chunk: [tap 9][octet 2][32][16 B] = 9216
-constexpr int WBLK = 2 * WPLANE;                                   // [piece 2: hi', lo'] = 18432
+constexpr int WPLANE = 9 * 2 * 32 * 16;                            // the hi' piece of one 32-channel block of one chunk: [tap 9][octet 2][32][16 B] = 9216
+constexpr int WBLK = 2 * WPLANE + 1024;                            // [hi' 9 taps][lo' 9 taps + one tap of ZEROS: the unpaired ninth tap's partner] = 19456
 constexpr int PTHR = 64 * NPW;                                     // producer threads
 constexpr int NSLOT = (2 * NPIX + PTHR - 1) / PTHR;                // halo staging slots per producer thread: 1224 (pixel, octet) pairs / 256 -> 5
 constexpr unsigned OOB = 0x80000000u;
@@ -39,12 +39,12 @@ constexpr unsigned OOB = 0x80000000u;
 
 template <int BN> struct SCfg {
     static constexpr int NT = BN / 32;
-    static constexpr int WS_STAGE = NT * WBLK;                     // 18432 / 36864: one chunk's weights
-    static constexpr int NDMA = WS_STAGE / 1024;                   // 1 KB LDS-DMA pieces per stage: 18 / 36
-    static constexpr int DPW = (NDMA + NPW - 1) / NPW;             // LDS-DMA instructions per producer wave and chunk: 5 / 9
+    static constexpr int WS_STAGE = NT * WBLK;                     // 19456 / 38912: one chunk's weights
+    static constexpr int NDMA = WS_STAGE / 1024;                   // 1 KB LDS-DMA pieces per stage: 19 / 38
+    static constexpr int DPW = (NDMA + NPW - 1) / NPW;             // LDS-DMA instructions per producer wave and chunk: 5 / 10
     static constexpr int NSTAGE = 2;
     static constexpr int BIAS_MAX = 1024;                          // the layer's bias vector lives in LDS: at most this many output channels (the launcher checks)
-    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (BIAS_MAX + 64) * 4;      // 157952 / 121088
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (BIAS_MAX + 64) * 4;      // 162048 / 123136
     static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
 };
 
@@ -82,10 +82,10 @@ enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3, EK_BWDB = 4 };
 
 // The 14 matrix instructions of a (chunk, 16 x 16 block): kind 0 = tap t0, pixels [hi | lo] x weights [hi' | hi'];  kind 1 / 2 = taps (t0, t0 + 1),
 // pixels [hi @ t0 | hi @ t0 + 1] x weights [lo' @ t0 | lo' @ t0 + 1] (the second tap's halo offset is + 1 pixel, or + 32 from tap 2 to tap 3);
-// kind 3 = tap 8 alone: the other half reads a zero word of the image.
+// tap 8 has no partner: its pair is (8, "9"), where the pack holds a tenth lo' tap of zeros (the pixel half reads one pixel on: finite x 0).
 constexpr int NGRP = 14;
 __device__ constexpr int grp_t0(int g) { constexpr int t[NGRP] = {0, 1, 0, 2, 3, 2, 4, 5, 4, 6, 7, 6, 8, 8}; return t[g]; }
-__device__ constexpr int grp_kind(int g) { constexpr int k[NGRP] = {0, 0, 1, 0, 0, 2, 0, 0, 1, 0, 0, 1, 0, 3}; return k[g]; }
+__device__ constexpr int grp_kind(int g) { constexpr int k[NGRP] = {0, 0, 1, 0, 0, 2, 0, 0, 1, 0, 0, 1, 0, 1}; return k[g]; }
 
 template <int BN, int EK>
 __global__ void __launch_bounds__(NTHR, 1)
@@ -210,7 +210,7 @@ igemm_h2s_kernel(const H2Args ha) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const int ins = min(pw + NPW * i, Cfg::NDMA - 1);
-                const int j = ins / 18, r = ins - 18 * j;
+                const int j = ins / 19, r = ins - 19 * j;
                 const int nb = (tl.n0 >> 5) + j;
                 const bool ok = valid && nb * 32 < a.Ntot;        // (an invalid request still issues: the vmcnt counts below count instructions)
                 const int soff = ok ? ((nb * K16 + gq) * WBLK + r * 1024) : 0;
@@ -218,7 +218,8 @@ igemm_h2s_kernel(const H2Args ha) {
                                                          16, ok ? (unsigned)lane * 16u : OOB, soff, 0, 0);
             }
         };
-        // ---- prologue: the bias vector, the zero words, the weights of chunk 0, chunk 0's halo straight into image 0, chunk 1's halo into the registers
+        // ---- prologue: the bias vector, the padding words of the hi planes (the unpaired ninth tap's second half reads one pixel past tap 8: word 612
+        // for the last lane of the last row -- multiplied by the pack's zero tap, so it must be FINITE, not whatever bit pattern the LDS held), the weights of chunk 0, chunk 0's halo straight into image 0, chunk 1's halo into the registers
         for (int i = ptid; i < Cfg::BIAS_MAX + 64; i += PTHR) bias_lds[i] = (a.bias && i < a.Ntot) ? a.bias[i] : 0.f;
         if (ptid < 48) xs[(ptid / 24) * XS_F4 + XS_PLANE(0, (ptid / 12) & 1) + NPIX + ptid % 12] = u32x4{0u, 0u, 0u, 0u};
         dma_weights(cur, 0, 0, true);
@@ -274,30 +275,31 @@ igemm_h2s_kernel(const H2Args ha) {
     for (int i = 0; i < MB; ++i)
 #pragma unroll
         for (int j = 0; j < NB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int r16 = lane & 15, q16 = lane >> 4, oct16 = q16 & 1, ps16 = q16 >> 1;
-    // lane bases (16-byte words of an image / bytes of a weight block); k-block q16 of an instruction = (octet q16 & 1, K half q16 >> 1)
-    const int rowbase = wave * MT * HC + r16;
-    const int a_main = XS_PLANE(ps16, oct16) + rowbase;              // [hi | lo]
-    const int a_hi = XS_PLANE(0, oct16) + rowbase;
-    const int a_p1 = a_hi + ps16, a_p32 = a_hi + 32 * ps16;          // [hi @ t | hi @ t + 1]: the second tap is one pixel (taps 2 -> 3: 32 pixels) on
-    const int a_zero = XS_PLANE(0, oct16) + NPIX;                    // a zero word
-    const int b_main = (oct16 * 32 + r16) * 16, b_p1 = b_main + ps16 * 1024;
     // MFMAs of one chunk (halo image img, weight stage st): group by group (grp_*), per group pass j (16 output channels) x pixel block mb.
     // The 4 pixel words of the NEXT group and the weight word of the NEXT pass are read between the MFMAs into the other register set.
     auto mfma_chunk = [&](int st, int img) {
+        // lane bases (16-byte words of an image / bytes of a weight block); k-block q16 of an instruction = (octet q16 & 1, K half q16 >> 1).
+        // Derived from an OPAQUE copy of the lane number per chunk: five registers that would otherwise live (spilled, in the 64-column forward
+        // kernel) across the epilogue
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        const int r16 = lane_m & 15, q16 = lane_m >> 4, oct16 = q16 & 1, ps16 = q16 >> 1;
+        const int rowbase = wave * MT * HC + r16;
+        const int a_main = XS_PLANE(ps16, oct16) + rowbase;          // [hi | lo]
+        const int a_hi = XS_PLANE(0, oct16) + rowbase;
+        const int a_p1 = a_hi + ps16, a_p32 = a_hi + 32 * ps16;      // [hi @ t | hi @ t + 1]: the second tap is one pixel (taps 2 -> 3: 32 pixels) on
+        const int b_main = (oct16 * 32 + r16) * 16, b_p1 = b_main + ps16 * 1024;
         const char* wst = wsb + st * Cfg::WS_STAGE;
         const u32x4* xim = xs + img * XS_F4;
         u32x4 A[2][MB], Bv[2];
         auto a_read = [&](auto gtag, int mb) {
             constexpr int gg = decltype(gtag)::value, t0 = grp_t0(gg), kind = grp_kind(gg);
             const int off = ((mb >> 1) + t0 / 3) * HC + t0 % 3 + 16 * (mb & 1);
-            int idx = (kind == 0 ? a_main : (kind == 1 ? a_p1 : (kind == 2 ? a_p32 : a_hi))) + off;
-            if constexpr (kind == 3) idx = ps16 ? a_zero : idx;
-            A[gg & 1][mb] = xim[idx];
+            A[gg & 1][mb] = xim[(kind == 0 ? a_main : (kind == 1 ? a_p1 : a_p32)) + off];
         };
         auto b_read = [&](auto ptag) {
             constexpr int pp = decltype(ptag)::value, gg = pp / NB, j = pp % NB, t0 = grp_t0(gg), kind = grp_kind(gg);
-            const int base = (kind == 1 || kind == 2) ? b_p1 : b_main;
+            const int base = kind == 0 ? b_main : b_p1;
             Bv[pp & 1] = *reinterpret_cast<const u32x4*>(wst + base + (kind == 0 ? 0 : WPLANE) + (j >> 1) * WBLK + t0 * 1024 + (j & 1) * 256);
         };
 #pragma unroll
@@ -367,7 +369,12 @@ igemm_h2s_kernel(const H2Args ha) {
     auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
         const EpiArgs ea = epi_args();
         const int b = tl.b, n0 = tl.n0;
-        const int p16 = lane & 15, c4 = (lane >> 4) * 4;
+        // the lane number as an OPAQUE value: everything the epilogue derives from it is then computed here, per tile (a dozen instructions),
+        // instead of being hoisted in front of the K loop and carried through it in ~50 registers (19 of them spilled to scratch in the
+        // 64-column forward kernel: cycle stamps 14 600 cycles per forward tile against 10 000 for the spill-free backward-data kernel)
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        const int p16 = lane_e & 15, c4 = (lane_e >> 4) * 4;
         const int py0 = tl.y0 + wave * MT, px0 = tl.x0 + p16;
         int du_[NT], chw_[NT], cs_[NT]; bool blk_[NT];
 #pragma unroll
@@ -398,7 +405,7 @@ igemm_h2s_kernel(const H2Args ha) {
         };
         // this lane's word of the tile-private bit layout (csrc/h2.h) for 32-column block k of a tensor with nblk channel blocks, in bytes
         const int tile_id = (b * tiles_y + tl.y0 / TH) * tiles_x + (tl.x0 >> 5);
-        auto bits_off = [&](int k, int nblk) { return (unsigned)((((tile_id * nblk + (chw_[k] >> 5)) * NCW + wave) * 64 + lane) * 4); };
+        auto bits_off = [&](int k, int nblk) { return (unsigned)((((tile_id * nblk + (chw_[k] >> 5)) * NCW + wave) * 64 + lane_e) * 4); };
         auto bits_rsrc = [&](const unsigned* base, int nblk) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, a.B * tiles_y * tiles_x * nblk * NCW * 64 * 4, 0x00020000);
         };
@@ -513,7 +520,7 @@ igemm_h2s_kernel(const H2Args ha) {
                             code |= cj << (8 * c);
                         }
                         const int px = px0 + 16 * h;
-                        const bool ok2 = !(lane & 1) && blk_[k] && py0 < ea.DH && px < ea.DW;      // even sizes: the whole window is inside or outside
+                        const bool ok2 = !(lane_e & 1) && blk_[k] && py0 < ea.DH && px < ea.DW;      // even sizes: the whole window is inside or outside
                         const unsigned po = (unsigned)(((py0 >> 1) * pwd + (px >> 1)) * ea.pool_cs + n0 + 16 * j + c4);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, mx), rp, ok2 ? po * 4u : OOB, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b32(code, rc, ok2 ? po : OOB, 0, 0);

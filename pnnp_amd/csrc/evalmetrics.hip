@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(256)
 illum_partial_kernel(const float* __restrict__ pred, const float* __restrict__ src, double* __restrict__ partial, int64_t n) {
     double num = 0.0, den = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float p = fminf(fmaxf(pred[i], 0.f), 1.f), s = src[i];
+        const float p = pnnp_clampf(pred[i], 0.f, 1.f), s = src[i];
         if (s != 1.f) { num += (double)p * s; den += (double)p * p; }
     }
     __shared__ double r1[256], r2[256];
@@ -39,12 +39,12 @@ illum_apply_kernel(const float* __restrict__ pred, float* __restrict__ out, cons
     }
     __syncthreads();
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = scale * fminf(fmaxf(pred[i], 0.f), 1.f);
+        out[i] = scale * pnnp_clampf(pred[i], 0.f, 1.f);
 }
 
 // torch.clamp(0, 1): a NaN stays a NaN (fminf / fmaxf return the OTHER operand for a NaN, which would turn a diverged network's
 // output into 0 and its PSNR into a finite number); comparisons with a NaN are false, so it falls through both selects.
-__device__ __forceinline__ float clamp01_nan(float v) { return v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+__device__ __forceinline__ float clamp01_nan(float v) { return pnnp_clampf(v, 0.f, 1.f); }
 
 // The elementwise tail of the eval iteration in ONE pass (trainer_SID.py:226-235): crop the padded network output back, add the input
 // residual of a `res` network (left out of the padded forward: (f(pad x) + pad x)[crop] = f(pad x)[crop] + x), `ori`: x ratio on both
@@ -79,8 +79,8 @@ psnr_ssim_partial_kernel(const float* __restrict__ a, const float* __restrict__ 
         const int r = i / 38, q = i % 38;
         const int gy = ty0 + r - 3, gx = tx0 + q - 3;
         const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        xs[r][q] = in ? fminf(fmaxf(ac[(int64_t)gy * W + gx] * 255.f, 0.f), 255.f) : 0.f;    // tensor2im: x255, clip
-        ys[r][q] = in ? fminf(fmaxf(bc[(int64_t)gy * W + gx] * 255.f, 0.f), 255.f) : 0.f;
+        xs[r][q] = in ? pnnp_clampf(ac[(int64_t)gy * W + gx] * 255.f, 0.f, 255.f) : 0.f;    // tensor2im: x255, clip
+        ys[r][q] = in ? pnnp_clampf(bc[(int64_t)gy * W + gx] * 255.f, 0.f, 255.f) : 0.f;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 38 * 32; i += 256) {                 // row sums: hs[.][r][q] = sum_v f(r, q + v)

@@ -266,11 +266,11 @@ l1_clamp_kernel(const float* __restrict__ pred, const float* __restrict__ hr, co
         for (int c = 0; c < C; ++c) {
             const int64_t i = ((int64_t)b * C + c) * hw + s;
             const float p = pred[i] * sc, t0 = hr[i];
-            const float t = clamp_target ? fminf(fmaxf(t0, 0.f), 1.f) : t0;      // preprocess: imgs_hr.clamp(0, 1) when dst.clip (trainer_SID.py:485)
-            const float pc = fminf(fmaxf(p, 0.f), 1.f);
+            const float t = clamp_target ? pnnp_clampf(t0, 0.f, 1.f) : t0;      // preprocess: imgs_hr.clamp(0, 1) when dst.clip (trainer_SID.py:485)
+            const float pc = pnnp_clampf(p, 0.f, 1.f);             // (a NaN prediction gives a NaN loss, as pred.clamp(0, 1) does: trainer_SID.py:99)
             const float d = pc - t;
             l1 += fabsf(d);
-            const float tc = fminf(fmaxf(t, 0.f), 1.f);          // PSNR uses clamped hr (trainer_SID.py:112-114)
+            const float tc = pnnp_clampf(t, 0.f, 1.f);            // PSNR uses clamped hr (trainer_SID.py:112-114)
             sse += (pc - tc) * (pc - tc);
             const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
             if (c < 8) g[c] = (p >= 0.f && p <= 1.f) ? sgn * gsc : 0.f;     // clamp passes grad on [0,1]

@@ -135,7 +135,8 @@ __device__ __forceinline__ void x3mat_job(const PnnpPackJob& j, int64_t blk, int
     }
 }
 
-// fp16x2 pack of a 3x3 Conv2d weight for csrc/conv_h2s.hip:  dst (fp16) [N/32][K16][piece 2: hi', lo'][tap 9][octet 2][32][8]
+// fp16x2 pack of a 3x3 Conv2d weight for csrc/conv_h2s.hip:  dst (fp16) [N/32][K16] x { hi' [tap 9][octet 2][32][8], lo' [tap 10][octet 2][32][8] }
+//   (the tenth lo' tap is ZERO: the partner of the unpaired ninth tap; 19456 bytes per 32-column block and chunk)
 //   element (k, n, tap) as in x3_job;  W s with s = 2^pnnp_h2_scale_exp(*amax) (amax >= max |w|: a kind-5 job), hi' = f16(W s), lo' = f16(W s - hi')
 //   (round to nearest even; the residual is exact in float32).  job: K = Cout, N = Cin, T = dgrad, Kvalid = padded K, amax = the slot.
 __device__ __forceinline__ void h2_job(const PnnpPackJob& j, int64_t blk, int nblk) {
@@ -145,6 +146,8 @@ __device__ __forceinline__ void h2_job(const PnnpPackJob& j, int64_t blk, int nb
     const int Kp = j.Kvalid, K16 = Kp / 16;
     const float s = __uint_as_float((unsigned)(pnnp_h2_scale_exp(j.amax[0]) + 127) << 23);
     const int64_t total = (int64_t)Kp * ((N + 31) / 32 * 32) * 9;
+    for (int64_t t = blk * 256 + threadIdx.x; t < (int64_t)((N + 31) / 32) * K16 * 512; t += (int64_t)nblk * 256)       // the zero taps
+        u[(t >> 9) * 9728 + 18 * 512 + (t & 511)] = 0;
     for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
         const int e = (int)(t & 7);                                // destination order: coalesced 2-byte stores of one piece plane
         int64_t r = t >> 3;
@@ -159,7 +162,7 @@ __device__ __forceinline__ void h2_job(const PnnpPackJob& j, int64_t blk, int nb
         const float vs = v * s;
         const _Float16 h = (_Float16)vs;
         const _Float16 l = (_Float16)(vs - (float)h);
-        unsigned short* o = u + (((int64_t)nb * K16 + c) * 2 * 9 + tap) * 512 + oct * 256 + nn * 8 + e;
+        unsigned short* o = u + ((int64_t)nb * K16 + c) * 9728 + tap * 512 + oct * 256 + nn * 8 + e;
         o[0] = __builtin_bit_cast(unsigned short, h); o[9 * 512] = __builtin_bit_cast(unsigned short, l);
     }
 }
@@ -317,8 +320,8 @@ int pnnp_pack_jobs_add_amax(PnnpPackJob* jobs, int* n, int cap, const float* x, 
     j.src = x; j.dst = reinterpret_cast<float*>(slot); j.kind = 5; j.sk = count; j.K = 1; j.N = 1;
     return push(jobs, n, cap, j) ? PNNP_OK : PNNP_E_WORKSPACE;
 }
-// bytes of one h2 pack: K (rounded up to 16) x N (rounded up to 32) x 9 taps x 2 pieces x 2 B
-int64_t pnnp_h2_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16 * 16) * ((N + 31) / 32 * 32) * 9 * 4; }
+// bytes of one h2 pack: per (K rounded up to 16) / 16 chunks and (N rounded up to 32) / 32 column blocks 19 taps x 1024 B (9 hi', 9 lo', 1 zero)
+int64_t pnnp_h2_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16) * ((N + 31) / 32) * 19456; }
 
 // max |x[0 .. count)| -> atomicMax into *slot, as a launch of its own: for tensors whose producer has no fused amax (csrc/h2.h)
 int pnnp_amax_f32(const float* x, int64_t count, unsigned* slot, void* stream) {

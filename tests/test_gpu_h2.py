@@ -60,7 +60,7 @@ def _decode_bits(bits, B, H, W, C):
 
 def test_h2_pack_reconstructs_the_scaled_weights_to_22_bits():
     """hi' + lo' == w 2^se to 2^-22 relative (elements within 2^-18 of the maximum), the scale is the power of two that puts max |w| into
-    [2^14, 2^15), and the pack order is the one the kernel streams: [N/32][K16][piece][tap][octet][32][8]."""
+    [2^14, 2^15), and the pack order is the one the kernel streams: [N/32][K16] x (9 hi' taps, 9 lo' taps, 1 tap of zeros) x [octet][32][8]."""
     from pnnp_amd import ops
     w = (_rand(64, 24, 3, 3, seed=3) * torch.logspace(-3, 1, 64 * 24 * 9).reshape(64, 24, 3, 3)).cuda()
     f, d, sw = _packs(w)
@@ -69,7 +69,9 @@ def test_h2_pack_reconstructs_the_scaled_weights_to_22_bits():
     se = 14 - int(np.floor(np.log2(amax)))
     def unpack(buf, K, N):
         K16 = (K + 15) // 16
-        a = buf.view(torch.float16).cpu().numpy().astype(np.float64).reshape(N // 32, K16, 2, 9, 2, 32, 8)
+        a = buf.view(torch.float16).cpu().numpy().astype(np.float64).reshape(N // 32, K16, 19, 2, 32, 8)       # 9 hi' taps, 9 lo' taps, 1 tap of zeros
+        assert not a[:, :, 18].any()
+        a = a[:, :, :18].reshape(N // 32, K16, 2, 9, 2, 32, 8)
         return a.transpose(2, 1, 4, 6, 0, 5, 3).reshape(2, K16 * 16, N, 9)          # [piece][k][n][tap]
     wn = w.cpu().numpy().astype(np.float64) * 2.0 ** se
     pf = unpack(f, 24, 64)

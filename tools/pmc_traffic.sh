@@ -11,7 +11,7 @@ import csv, sys
 # keep only the conv kernels' rows (the full files are tens of MB)
 for src, dst in ((sys.argv[1], 'gpurun_out/pmc_fetch_size.csv'), (sys.argv[2], 'gpurun_out/pmc_write_size.csv')):
     rows = list(csv.DictReader(open(src)))
-    keep = [r for r in rows if any(k in r['Kernel_Name'] for k in ('wino_kernel', 'wino_wgrad_kernel', 'igemm_kernel<9', 'wgrad_kernel<9', 'igemm_x3_kernel', 'igemm_x3s_kernel'))]
+    keep = [r for r in rows if any(k in r['Kernel_Name'] for k in ('wino_kernel', 'wino_wgrad_kernel', 'igemm_kernel<9', 'wgrad_kernel<9', 'igemm_x3_kernel', 'igemm_x3s_kernel', 'igemm_h2s_kernel', 'wgrad_h2s_kernel', 'wgrad_x3s_kernel'))]
     w = csv.DictWriter(open(dst, 'w', newline=''), fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(keep)
 PY
 python tools/traffic_from_pmc.py gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_size.csv gpurun_out/traffic.json "$1"

@@ -19,7 +19,8 @@ def load(path, name):
     return agg
 f = load(fetch_csv, 'FETCH_SIZE'); w = load(write_csv, 'WRITE_SIZE')
 res = {}
-for cls, pred in (('x3', lambda k: k.startswith('igemm_x3_kernel') or k.startswith('igemm_x3s_kernel')), ('igemm9', lambda k: k.startswith('igemm_kernel<9')), ('wgrad9', lambda k: k.startswith('wgrad_kernel<9')),
+for cls, pred in (('x3', lambda k: k.startswith('igemm_x3_kernel') or k.startswith('igemm_x3s_kernel')), ('h2', lambda k: k.startswith('igemm_h2s_kernel')),
+                  ('wgrad_h2', lambda k: k.startswith('wgrad_h2s_kernel')), ('wgrad_x3', lambda k: k.startswith('wgrad_x3s_kernel')), ('igemm9', lambda k: k.startswith('igemm_kernel<9')), ('wgrad9', lambda k: k.startswith('wgrad_kernel<9')),
                   ('wino', lambda k: k.startswith('wino_kernel')), ('wino_wgrad', lambda k: k.startswith('wino_wgrad_kernel'))):
     n = sum(v[0] for k, v in f.items() if pred(k))
     if not n:
