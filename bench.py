@@ -202,7 +202,7 @@ def main():
     ap.add_argument('--proxy-mode', default='train', choices=['train', 'eval'],
                     help='NoiseFlow proxy BatchNorm mode while sampling: train = trainer_LRID (config 5), eval = trainer_SID')
     ap.add_argument('--family', default='h2', choices=['h2', 'x3', 'wino', 'direct'],
-                    help='3x3 kernel family: h2 = fp16x2 split on the fp16 matrix cores (csrc/h2.h; default; where it does not apply -- and in the ResUnet engine -- x3), x3 = bf16x3 split on the bf16 matrix cores, wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
+                    help='3x3 kernel family: h2 = fp16x2 split on the fp16 matrix cores (csrc/h2.h; default; where it does not apply: x3), x3 = bf16x3 split on the bf16 matrix cores, wino = Winograd on the fp32 matrix cores, direct = fp32 implicit GEMM')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-baseline-seconds', type=float, default=240.0,
                     help='time budget of the CPU baseline legs (BASELINE.md section 3 protocol: B=16, 2 warm-up + 5 timed steps, all physical cores + 1 thread); '
@@ -262,8 +262,6 @@ def main():
         proxy = proxy.to(dev)
         proxy = proxy.train() if args.proxy_mode == 'train' else proxy.eval()
     net = net.to(dev)
-    if args.arch == 'resunet' and args.family == 'h2':
-        args.family = 'x3'                       # the fp16x2 family is wired into the UNet engine only (so far): config 5 runs bf16x3
     net.engine.set_policy(x3=args.family in ('x3', 'h2'), wino=args.family != 'direct', h2=args.family == 'h2')
     B, S = args.batch, args.size
     global_batch = B * world

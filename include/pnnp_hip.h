@@ -263,6 +263,10 @@ int pnnp_conv1x1_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgra
 int pnnp_conv3x3s2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, int act, void* stream);
 int pnnp_conv3x3s2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
                                    int B, int H, int W, void* stream);
+int pnnp_conv3x3s2_x3_fwd_amax_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, unsigned* amax_y /*or null*/,
+                                   int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3s2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
+                                        unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
 /* backward-weight of the same layers (csrc/wgrad_x3.hip; pixel-major LDS images read with ds_read_b64_tr_b16): same contract
  * as pnnp_conv_bwd_weight_f32 with taps = 9; channel counts in multiples of 32; workspace from the query. */
 int pnnp_x3_wgrad_supported(int H, int W, int Cout, int C1, int C2);

@@ -76,6 +76,7 @@ class ResUnetEngine(_EngineBase):
         jobs = ops.PackJobs(cap=512)
         W = {}
         self.WU, self.WX = {}, {}
+        self.WH, self.WS = {}, {}              # fp16x2 packs (forward, backward-data) per layer; the weight tensor's amax slot (csrc/h2.h)
         def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True, c1=None):
             w = P[pname]
             co, ci, kh, kw = w.shape
@@ -84,6 +85,13 @@ class ResUnetEngine(_EngineBase):
             bwd = train and dgrad
             xf, xd = self._pol.use_x3(co, cip, t, c1)
             xd = xd and bwd
+            hf, hd = self._pol.use_h2(co, cip, t, c1)
+            hf, hd = hf and xf, hd and xd
+            if hf or hd:                                               # the fp16x2 kernel takes what bf16x3 would have taken
+                self.WH[name] = (self._buf(name + ':h2f', ops.h2_weight_bytes(cip, co), dev, torch.uint8) if hf else None,
+                                 self._buf(name + ':h2d', ops.h2_weight_bytes(co, ci), dev, torch.uint8) if hd else None)
+                self.WS[name] = jobs.add_h2(w, self.WH[name][0], self.WH[name][1], cin_pad=(cip + 15) // 16 * 16)
+                xf, xd = xf and not hf, xd and not hd
             p1 = t == 1 and self._pol.use_x3_pointwise(ci, co) and self._pol.use_x3_pointwise(co, ci) and (c1 is None or c1 % 32 == 0)
             if p1:                                                     # 1x1 (ResidualBlock shortcut) on the pointwise bf16x3 kernel
                 x3f = self._buf(name + ':x3f', ops.x3mat_bytes(ci, co), dev, torch.uint8)
@@ -92,8 +100,8 @@ class ResUnetEngine(_EngineBase):
                 W[name] = (None, None); self.WU[name] = (None, None); self.WX[name] = (x3f, x3d if bwd else x3f)
                 return
             wf, wd = self._wino(co, ci, t)
-            wf, wd = wf and not xf, wd and bwd and not xd
-            df, dd = not (xf or wf), bwd and not (xd or wd)        # what is left for the direct fp32 kernels
+            wf, wd = wf and not (xf or hf), wd and bwd and not (xd or hd)
+            df, dd = not (xf or wf or hf), bwd and not (xd or wd or hd)        # what is left for the direct fp32 kernels
             f = self._buf(name + ':f', t * cip * co, dev) if df else None
             d = self._buf(name + ':d', t * (cout_pad or co) * ci, dev) if dd else None
             if df or dd:
@@ -204,40 +212,69 @@ class ResUnetEngine(_EngineBase):
         hs = [H >> i for i in range(5)]; ws = [Wd >> i for i in range(5)]
         a = {}
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
+        # fp16x2 family (csrc/h2.h): amax slots of the activations, keyed by the layer that wrote the tensor; sign bits of the ReLU outputs
+        # that backward-data will need as masks
+        h2_on = bool(self.WH)
+        if h2_on:
+            bufs.slots('f', dev).zero_()
+        sl = lambda n: bufs.slot('f', n, dev)
+        src_name = {}
+
+        def produced(t, name, fused):
+            src_name[id(t)] = name
+            if h2_on and not fused:
+                ops.amax(t, sl(name))
+            return t
+
+        def cf(name, src, src2, bias, out, cout, act, residual=None):
+            hp = self.WH.get(name, (None, None))[0]
+            if hp is None:
+                return produced(self._cf(name, src, src2, bias, out, cout, act, residual=residual), name, fused=False)
+            bits = None
+            if train and act != 0 and residual is None:
+                bits = a['bits:' + name] = bufs.bits(name, B, out.shape[1], out.shape[2], cout, dev)
+            if id(src) not in src_name:                                # (the zero-padded network input: a kernel of its own fills its slot)
+                produced(src, 'in:' + name, fused=False)
+            ops.conv_h2_fwd(src, src2, hp, self.WS[name], bias, out, cout, act, sl(src_name[id(src)]),
+                            sl(src_name[id(src2)]) if src2 is not None else None, amax_y=sl(name), bits_y=bits, residual=residual)
+            return produced(out, name, fused=True)
+
         if self._pol.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
-            a['t0'] = ops.first_fwd(a['x8'], P['conv_in.weight'], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), RELU)
+            a['t0'] = produced(ops.first_fwd(a['x8'], P['conv_in.weight'], P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), RELU,
+                                             amax_y=sl('conv_in') if h2_on else None), 'conv_in', fused=True)
         else:
-            a['t0'] = self._cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
+            a['t0'] = cf('conv_in', a['x8'], None, P['conv_in.bias'], g('t0', (B, H, Wd, ch[0])), ch[0], RELU)
         xin = a['t0']
         for l in range(1, 6):
             lv = l - 1
             shp = (B, hs[lv], ws[lv], ch[lv])
-            a[f't{l}'] = self._cf(f'b{l}_0', xin, None, None, g(f't{l}', shp), ch[lv], RELU)
-            a[f'c{l}'] = self._cf(f'b{l}_1', a[f't{l}'], None, None, g(f'c{l}', shp), ch[lv], 0, residual=xin)
+            a[f't{l}'] = cf(f'b{l}_0', xin, None, None, g(f't{l}', shp), ch[lv], RELU)
+            a[f'c{l}'] = cf(f'b{l}_1', a[f't{l}'], None, None, g(f'c{l}', shp), ch[lv], 0, residual=xin)
             if l < 5:
                 if f'pool{l}' in self.WX:
-                    a[f'd{l}'] = ops.conv_s2_x3_fwd(a[f'c{l}'], self.WX[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
-                                                    g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
+                    a[f'd{l}'] = produced(ops.conv_s2_x3_fwd(a[f'c{l}'], self.WX[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
+                                                             g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l], amax_y=sl(f'pool{l}') if h2_on else None), f'pool{l}', fused=True)
                 else:
-                    a[f'd{l}'] = ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
-                                                 g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l])
+                    a[f'd{l}'] = produced(ops.conv_s2_fwd(a[f'c{l}'], W[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
+                                                          g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l]), f'pool{l}', fused=False)
                 xin = a[f'd{l}']
         cur = a['c5']
         for i in range(6, 10):
             lv = 9 - i
             shp = (B, hs[lv], ws[lv], ch[lv])
             if f'upv{i}' in self.WX:
-                u = ops.convt_x3_fwd(cur, self.WX[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
+                u = produced(ops.convt_x3_fwd(cur, self.WX[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv],
+                                              amax_y=sl(f'upv{i}') if h2_on else None), f'upv{i}', fused=True)
             else:
-                u = ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv])
+                u = produced(ops.convt_fwd(cur, W[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv]), f'upv{i}', fused=False)
             skip = a[f'c{lv + 1}']
             a[f'u{i}'] = u
-            a[f't{i}'] = self._cf(f'b{i}_0', u, skip, None, g(f't{i}', shp), ch[lv], RELU)
+            a[f't{i}'] = cf(f'b{i}_0', u, skip, None, g(f't{i}', shp), ch[lv], RELU)
             if self.WX.get(f'sc{i}', (None, None))[0] is not None:
                 sc = ops.conv1x1_x3_fwd(u, skip, self.WX[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 0)
             else:
                 sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
-            a[f'c{i}'] = self._cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
+            a[f'c{i}'] = cf(f'b{i}_1', a[f't{i}'], None, None, g(f'c{i}', shp), ch[lv], 0, residual=sc)
             cur = a[f'c{i}']
         out = torch.empty((B, self.cout, H, Wd), dtype=torch.float32, device=dev)
         if self._pol.use_thin_head(ch[0], self.cout, B * H * Wd):
@@ -247,6 +284,7 @@ class ResUnetEngine(_EngineBase):
             ops.nhwc_to_nchw(o, out, residual=x if (self.m.res and add_residual) else None)
         if train:
             a['_pol'] = self._pol
+            a['_src_name'] = src_name
             self.saved = (a, (B, H, Wd, dev), gen)
         return out
 
@@ -266,8 +304,49 @@ class ResUnetEngine(_EngineBase):
             if on_ready is not None:
                 on_ready(self.params.slices[pname][0])
 
+        # fp16x2 family: amax slots of the gradients (zeroed per backward), the activations' slots are the forward's
+        h2_on = bool(self.WH)
+        if h2_on:
+            bufs.slots('b', dev).zero_()
+        src_name = a.get('_src_name', {})
+        slf = lambda t: bufs.slot('f', src_name[id(t)], dev)
+        gname = {}
+        gslot = lambda t: bufs.slot('b', gname[id(t)], dev)
+        bslot = lambda n: bufs.slot('b', n, dev) if h2_on else None
+
+        def gproduced(t, name, fused):
+            gname[id(t)] = name
+            if h2_on and not fused:
+                ops.amax(t, bufs.slot('b', name, dev))
+            return t
+
+        def dg(name, gsrc, dx1, **kw):
+            hp = self.WH.get(name, (None, None))[1]
+            dx2 = kw.get('dx2')
+            if hp is None:
+                self._dg(name, gsrc, dx1, **kw)
+                gproduced(dx1, 'd1:' + name, fused=False)
+                if dx2 is not None:
+                    gproduced(dx2, 'd2:' + name, fused=False)
+                return
+            for k_mask, k_bits in (('mask1', 'bits1'), ('mask2', 'bits2')):      # act' masks as the forward kernels' sign bits
+                m = kw.get(k_mask)
+                if m is not None and ('bits:' + src_name.get(id(m), '?')) in a:
+                    kw[k_bits] = a['bits:' + src_name[id(m)]]
+                    kw[k_mask] = None
+            gname[id(dx1)] = 'd1:' + name
+            if dx2 is not None:
+                gname[id(dx2)] = 'd2:' + name
+            ops.conv_h2_bwd_data(gsrc, gslot(gsrc), hp, self.WS[name], dx1, amax_dx1=gslot(dx1), amax_dx2=gslot(dx2) if dx2 is not None else None, **kw)
+
         def wgrad(pname, gpre, cout, x1, c1, x2=None, taps=9, bias=None):
             c2 = x2.shape[3] if x2 is not None else 0
+            if (taps == 9 and h2_on and self._pol.h2_wgrad and id(gpre) in gname and id(x1) in src_name and (x2 is None or id(x2) in src_name) and
+                    self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=gpre.shape[0],
+                                           cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0))):
+                ops.conv_h2_bwd_weight(gpre, gslot(gpre), cout, x1, slf(x1), c1, x2, slf(x2) if x2 is not None else None,
+                                       G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+                return
             if taps == 9 and self._pol.use_x3_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, batch=gpre.shape[0],
                                                     cs=max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
@@ -282,10 +361,12 @@ class ResUnetEngine(_EngineBase):
         # head
         g = gb('c9', a['c9'])
         if self._pol.use_thin_head(ch[0], self.cout, B * H * Wd):
-            ops.head_bwd(g_out8, a['c9'], P['conv10.weight'], g, G('conv10.weight'), G('conv10.bias'), wsf, mode=0, accumulate=acc)
+            ops.head_bwd(g_out8, a['c9'], P['conv10.weight'], g, G('conv10.weight'), G('conv10.bias'), wsf, mode=0, accumulate=acc, amax_gx=bslot('head'))
+            gproduced(g, 'head', fused=True)
         else:
             wgrad('conv10.weight', g_out8, self.cout, a['c9'], ch[0], taps=1, bias='conv10.bias')
             ops.conv_bwd_data(g_out8, W['conv10'][1], g, taps=1)
+            gproduced(g, 'head', fused=False)
         done('conv10.weight')
         for i in range(9, 5, -1):                    # decoder blocks, top-down
             lv = 9 - i
@@ -293,11 +374,14 @@ class ResUnetEngine(_EngineBase):
             wgrad(f'conv{i}.short_cut.0.conv.conv.weight', g, ch[lv], u, ch[lv], x2=skip, taps=1)
             wgrad(f'conv{i}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
             g_t = gb(f't{i}', t)
-            self._dg(f'b{i}_1', g, g_t, mask1=t, mode1=RELU)
+            dg(f'b{i}_1', g, g_t, mask1=t, mode1=RELU)
             wgrad(f'conv{i}.block.0.conv.conv.weight', g_t, ch[lv], u, ch[lv], x2=skip)
             done(f'conv{i}.block.0.conv.conv.weight')
             g_u, g_skip = gb(f'u{i}', u), gb(f'c{lv + 1}', skip)
-            self._dg(f'b{i}_0', g_t, g_u, dx2=g_skip)
+            dg(f'b{i}_0', g_t, g_u, dx2=g_skip)
+            # (the shortcut's gradient is ACCUMULATED into g_u and g_skip next: their slots are stale from here on -- no fp16x2 kernel reads
+            #  them before ConvTranspose2d's backward / the stride-2 backward rewrite or finish them)
+            gname.pop(id(g_u), None); gname.pop(id(g_skip), None)
             if self.WX.get(f'sc{i}', (None, None))[0] is not None:
                 ops.conv1x1_x3_bwd_data(g, self.WX[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1)
             else:
@@ -309,23 +393,28 @@ class ResUnetEngine(_EngineBase):
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
             if f'upv{i}' in self.WX:
-                ops.convt_x3_bwd_data(g_u, self.WX[f'upv{i}'][1], g)
+                ops.convt_x3_bwd_data(g_u, self.WX[f'upv{i}'][1], g, amax_dx=bslot(f'upv{i}'))
+                gproduced(g, f'upv{i}', fused=True)
             else:
                 ops.convt_bwd_data(g_u, W[f'upv{i}'][1], g)
+                gproduced(g, f'upv{i}', fused=False)
         for l in range(5, 0, -1):                    # encoder blocks, bottom-up; g = dL/d c_l
             lv = l - 1
             t = a[f't{l}']
             xin = a['t0'] if l == 1 else a[f'd{l - 1}']
             wgrad(f'conv{l}.block.1.conv.conv.weight', g, ch[lv], t, ch[lv])
             g_t = gb(f't{l}', t)
-            self._dg(f'b{l}_1', g, g_t, mask1=t, mode1=RELU)
+            dg(f'b{l}_1', g, g_t, mask1=t, mode1=RELU)
             wgrad(f'conv{l}.block.0.conv.conv.weight', g_t, ch[lv], xin, ch[lv])
             done(f'conv{l}.block.0.conv.conv.weight')
             g_x = gb('t0' if l == 1 else f'd{l - 1}', xin)
             # identity shortcut: d/d(xin) = dgrad(block) + g ; xin = t0 is a ReLU output (mask), d_l is not
             ud = self.WU.get(f'b{l}_0', (None, None))[1]
             x3d = self.WX.get(f'b{l}_0', (None, None))[1]
-            if x3d is not None:
+            h2d = self.WH.get(f'b{l}_0', (None, None))[1]
+            if h2d is not None:
+                ops.conv_h2_bwd_data_res(g_t, gslot(g_t), h2d, self.WS[f'b{l}_0'], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+            elif x3d is not None:
                 ops.conv_x3_bwd_data_res(g_t, x3d, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
             elif ud is not None:
                 ops.conv_wino_bwd_data_res(g_t, ud, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
@@ -339,9 +428,11 @@ class ResUnetEngine(_EngineBase):
                 done(f'pool{l - 1}.conv.weight')
                 g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
                 if f'pool{l - 1}' in self.WX:
-                    ops.conv_s2_x3_bwd_data(g_x, self.WX[f'pool{l - 1}'][1], g, accum=1)
+                    ops.conv_s2_x3_bwd_data(g_x, self.WX[f'pool{l - 1}'][1], g, accum=1, amax_dx=bslot(f'pool{l - 1}'))
+                    gproduced(g, f'pool{l - 1}', fused=True)           # (the sums it stored: skip gradient + this layer's)
                 else:
                     ops.conv_s2_bwd_data(g_x, W[f'pool{l - 1}'][1], g, accum=1)
+                    gproduced(g, f'pool{l - 1}', fused=False)
             else:
                 if self._pol.use_thin_first(self.cin, ch[0], H, Wd, a['x8'].shape[3]):
                     ops.first_bwd_weight(g_x, ch[0], a['x8'], self.cin, G('conv_in.weight'), G('conv_in.bias'), wsf, accumulate=acc)

@@ -340,21 +340,33 @@ int pnnp_conv1x1_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_dgra
 }
 
 int pnnp_conv3x3s2_x3_fwd_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, int B, int H, int W, int Cout, int act, void* stream) {
+    return pnnp_conv3x3s2_x3_fwd_amax_f32(x, Cin, w_x3, bias, y, nullptr, B, H, W, Cout, act, stream);
+}
+// ... with max |y| raised into an amax slot of the fp16x2 family (csrc/h2.h)
+int pnnp_conv3x3s2_x3_fwd_amax_f32(const float* x, int Cin, const void* w_x3, const float* bias, float* y, unsigned* amax_y,
+                                   int B, int H, int W, int Cout, int act, void* stream) {
     if (!x || !w_x3 || !y || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     IgemmArgs a;
     s2_fwd_args(a, x, Cin, w_x3, bias, y, B, H, W, Cout, act);
+    a.amax_out[0] = amax_y;
     return pnnp_gemm_x3_launch(a, Cin, as_stream(stream));
 }
 
 int pnnp_conv3x3s2_x3_bwd_data_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
                                    int B, int H, int W, void* stream) {
+    return pnnp_conv3x3s2_x3_bwd_data_amax_f32(g, Cout, w_x3_s2dgrad, dx, Cin, mask, mode, accum, nullptr, B, H, W, stream);
+}
+// ... with max |dx| (of the sums stored, when accumulating) raised into an amax slot: the four parity-class launches share it
+int pnnp_conv3x3s2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_x3_s2dgrad, float* dx, int Cin, const float* mask, int mode, int accum,
+                                        unsigned* amax_dx, int B, int H, int W, void* stream) {
     if (!g || !w_x3_s2dgrad || !dx || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     int slice = 0;
     for (int cls = 0; cls < 4; ++cls) {
         IgemmArgs a;
         const int ns = s2_bwd_args(a, cls, g, Cout, dx, Cin, mask, mode, accum, B, H, W);
+        a.amax_out[0] = amax_dx;
         a.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_x3_s2dgrad) + (int64_t)slice * Cout * Cin * 6);
         const int rc = pnnp_gemm_x3_launch(a, Cout, as_stream(stream));
         if (rc != PNNP_OK) return rc;

@@ -343,20 +343,20 @@ def conv1x1_x3_bwd_data(g, w_x3_dgrad, dx1, mask1=None, mode1=0, accum1=0, dx2=N
                                                    ptr(dx2), C2, ptr(mask2), mode2, accum2, B, H, W, stream()), 'conv1x1_x3_bwd_data')
 
 
-def conv_s2_x3_fwd(x, w_x3, bias, y, cout, act=0):
+def conv_s2_x3_fwd(x, w_x3, bias, y, cout, act=0, amax_y=None):
     require_cuda(x, w_x3, y)
     B, H, W, Cin = x.shape
     with _Timed('conv9s2_fwd_x3', 2.0 * B * (H // 2) * (W // 2) * cout * Cin * 9):
-        check(_prep().pnnp_conv3x3s2_x3_fwd_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), B, H, W, cout, act, stream()), 'conv3x3s2_x3_fwd')
+        check(_prep().pnnp_conv3x3s2_x3_fwd_amax_f32(ptr(x), Cin, ptr(w_x3), ptr(bias), ptr(y), ptr(amax_y), B, H, W, cout, act, stream()), 'conv3x3s2_x3_fwd')
     return y
 
 
-def conv_s2_x3_bwd_data(g, w_x3_s2dgrad, dx, mask=None, mode=0, accum=0):
+def conv_s2_x3_bwd_data(g, w_x3_s2dgrad, dx, mask=None, mode=0, accum=0, amax_dx=None):
     require_cuda(g, w_x3_s2dgrad, dx)
     B, H, W, Cin = dx.shape
     with _Timed('conv9s2_dgrad_x3', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
-        check(_prep().pnnp_conv3x3s2_x3_bwd_data_f32(ptr(g), g.shape[3], ptr(w_x3_s2dgrad), ptr(dx), Cin, ptr(mask), mode, accum,
-                                                     B, H, W, stream()), 'conv3x3s2_x3_bwd_data')
+        check(_prep().pnnp_conv3x3s2_x3_bwd_data_amax_f32(ptr(g), g.shape[3], ptr(w_x3_s2dgrad), ptr(dx), Cin, ptr(mask), mode, accum, ptr(amax_dx),
+                                                          B, H, W, stream()), 'conv3x3s2_x3_bwd_data')
 
 
 def x3_wgrad_supported(H, W, cout, c1, c2=0):

@@ -73,8 +73,6 @@ def test_512_crop_backward_vs_reference_golden(golden_dir, arch, family):
     the 1024 probe positions, within 6x the reference-float32-vs-float64 error of the float64 truth (+1e-5), the median
     ratio over tensors <= 2, and every L2 norm within 2e-3 of the reference's."""
     from pnnp_amd.trainer import HipTrainStep
-    if family == 'h2' and arch != 'unet':
-        pytest.skip('the fp16x2 family is wired into the UNet engine only')
     g = np.load(os.path.join(golden_dir, f'{arch}_nf32_512_bwd.npz'))
     net, sd = _he_net(arch)
     gen = torch.Generator().manual_seed(2)
