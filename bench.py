@@ -397,6 +397,9 @@ def main():
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
                                "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
+            if fam == 'h2':
+                # informational: a bare register-only loop of v_mfma_f32_16x16x32_f16 on random operands (the power-limited clock), 2 waves per SIMD
+                out["roofline"]["sustained_bare_mfma_loop"] = {"random_operands": 1803.0, "unit": "TFLOP/s", "source": "tools/ubench/h2_probe.hip (profiles/r5/h2_probe.txt)"}
             if fam == 'x3':
                 # informational: what a bare loop of the 32x32x16 MFMA sustains on this chip (the 16x16x32 shape the kernel uses: ~1950; tools/ubench/mfma_shape.hip, 8 waves per CU, operands
                 # re-read from LDS): 1790 TFLOP/s on random operands (power-limited clock), 2250 on zero operands; `peak` stays the 2.4 GHz figure
