@@ -39,7 +39,9 @@ int pnnp_device_cus(void);
  * the tiles).  n > 1 launches n per CU with 1/n share each; the surplus waits in the hardware dispatcher and goes to whichever CU frees up
  * first, so a kernel resident on some CUs beside the convolution (an RCCL collective overlapping the backward pass: replaces what
  * nn.DataParallel's reduce did behind autograd, base_trainer.py:115-118) stretches a layer by ~CUs / (CUs - k) instead of doubling it.
- * Process-wide setting, 1 <= n <= 16; the only state the library keeps. */
+ * Process-wide setting, 1 <= n <= 16: the ONE deliberate exception to "no global mutable state"  -- it changes grid sizes, never a
+ * result bit (tests/test_gpu_overlap.py), and a per-launch argument would have to thread through every convolution entry point.  Callers
+ * scope it: HipTrainStep sets it around the backward pass of a step whose all-reduce overlaps and restores the previous value. */
 void pnnp_set_persistent_split(int n);
 int pnnp_get_persistent_split(void);
 
@@ -295,7 +297,7 @@ int pnnp_conv1x1_x3_bwd_weight_f32(const float* g, int g_cs, int Cout, const flo
 
 /* (The Winograd kernel's cycle-stamp hook `pnnp_wino_set_debug` exists only in profiling builds, -DPNNP_WINO_DEBUG=1: the shipped
  * library exports no debug hook, reads no environment variable and keeps no state between calls besides idempotent per-device
- * caches of device facts.) */
+ * caches of device facts and the persistent-split setting above.) */
 int pnnp_wino_wgrad_supported(int H, int W, int Cout, int C1, int C2);
 int64_t pnnp_wino_wgrad_workspace_floats(int B, int H, int W, int Cout, int Cin);
 int pnnp_conv3x3_wino_bwd_weight_f32(const float* g, int g_cs, int Cout, const float* x1, int x1_cs, int C1,

@@ -421,18 +421,55 @@ igemm_h2s_kernel(const H2Args ha) {
             for (int c = 0; c < 4; ++c) o[c] = fmaxf(o[c], t[c]);
             return o;
         };
-        auto take = [&](int mb, int j) {                             // the block, un-scaled (exact: a power of two), and the accumulator zeroed for the next tile
+        // Undoing the operand scales: x 2^dexp (exact).  As ONE multiplier (fused with the bias add where there is one) while 2^dexp is a normal
+        // float32; tensors so small / large that it is not (|dexp| > 126: max |x| max |w| beyond 2^+-98) first take the remainder in a pass over the
+        // accumulators -- a wave-uniform branch that the networks' tensors never take (tests/test_gpu_h2.py::test_h2_dynamic_range does).
+        const int dexp_c = ea.dexp < -126 ? -126 : (ea.dexp > 127 ? 127 : ea.dexp);
+        const float dsc = __uint_as_float((unsigned)(dexp_c + 127) << 23);
+        if (ea.dexp != dexp_c) {
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc[mb][j][c] = __builtin_ldexpf(acc[mb][j][c], ea.dexp - dexp_c);
+        }
+        auto take = [&](int mb, int j) {                             // the block, un-scaled, and the accumulator zeroed for the next tile
             const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            return f32x4{__builtin_ldexpf(v.x, ea.dexp), __builtin_ldexpf(v.y, ea.dexp), __builtin_ldexpf(v.z, ea.dexp), __builtin_ldexpf(v.w, ea.dexp)};
+            return v * dsc;
+        };
+        auto take_bias = [&](int mb, int j, f32x4 bias) {            // ... with the bias: one fma per element
+            const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return f32x4{__builtin_fmaf(v.x, dsc, bias.x), __builtin_fmaf(v.y, dsc, bias.y), __builtin_fmaf(v.z, dsc, bias.z), __builtin_fmaf(v.w, dsc, bias.w)};
         };
         // max |.| of a stored block into the lane's running maximum of destination du (uniform); lanes whose store is dropped do not count
         auto track = [&](f32x4 o, bool valid, int du) {
-            const float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
-            const float mv = valid ? m : 0.f;
-            if (du) amx1 = fmaxf(amx1, mv); else amx0 = fmaxf(amx0, mv);
+            const float cur_ = du ? amx1 : amx0;
+            const float m = fmaxf(fmaxf(fmaxf(cur_, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
+            const float mv = valid ? m : cur_;
+            if (du) amx1 = mv; else amx0 = mv;
         };
-        auto signs4 = [&](f32x4 o, int pos) {                        // 4 sign bits (o > 0) at bit position pos
-            return ((o.x > 0.f ? 1u : 0u) | (o.y > 0.f ? 2u : 0u) | (o.z > 0.f ? 4u : 0u) | (o.w > 0.f ? 8u : 0u)) << pos;
+        // Sign bits: element n = ((i 2 + h) 2 + jj) 4 + c of a 32-column block sits at bit 31 - n of the lane's word -- the order in which the
+        // forward epilogue produces the values, so that it can SHIFT them in (sb = 2 sb + (o > 0): a compare and an add-with-carry per element) and
+        // the backward epilogue can shift them out (carry of sb + sb).  signs4: the generic form (pool and tests).
+        auto signs4 = [&](f32x4 o, int pos) {
+            return ((o.x > 0.f ? 8u : 0u) | (o.y > 0.f ? 4u : 0u) | (o.z > 0.f ? 2u : 0u) | (o.w > 0.f ? 1u : 0u)) << (28 - pos);
+        };
+        // one element of the forward epilogue: shift (o > 0) into sb; with an activation o = (o > 0) ? o : slope o on the same compare
+        auto act_sign = [](float& o, unsigned& sb, float slope_, auto act_tag) __attribute__((always_inline)) {
+            unsigned long long cout_;
+            if constexpr (decltype(act_tag)::value) {
+                float t;
+                asm("v_cmp_lt_f32 vcc, 0, %0\n\tv_addc_co_u32 %1, %2, %1, %1, vcc\n\tv_mul_f32 %3, %4, %0\n\tv_cndmask_b32 %0, %3, %0, vcc"
+                    : "+v"(o), "+v"(sb), "=s"(cout_), "=&v"(t) : "v"(slope_) : "vcc");
+            } else {
+                asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, %1, %0, %0, vcc" : "+v"(sb), "=s"(cout_) : "v"(o) : "vcc");
+            }
+        };
+        // one element of the bit-masked backward epilogue: the next bit of mb out (carry of mb + mb), o = bit ? o : msl o
+        auto mask_bit = [](float& o, unsigned& mb_, float msl) __attribute__((always_inline)) {
+            float t;
+            asm("v_add_co_u32 %1, vcc, %1, %1\n\tv_mul_f32 %2, %3, %0\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(o), "+v"(mb_), "=&v"(t) : "v"(msl) : "vcc");
         };
         // ---- full-line memory pattern (FWD / BWD / POOL: see csrc/conv_x3s.hip)
         const bool lo8 = p16 < 8;
@@ -444,6 +481,20 @@ igemm_h2s_kernel(const H2Args ha) {
             return f32x4{r0, r1, r2, r3};
         };
         auto sel = [&](bool c, f32x4 x, f32x4 y) { return f32x4{c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w}; };
+        // The trade of the two 16-column blocks of a pair IN PLACE: afterwards o0 is what store instruction 1 writes (lanes p < 8: their own lower
+        // quad, lanes p >= 8: the upper quad of pixel p - 8) and o1 what instruction 2 writes.  A DPP row rotation by 8 whose bank mask enables
+        // only the receiving half of each 16-lane row: two moves per register pair + one copy (the select-rotate-select form took four + four).
+        auto trade = [&](f32x4& o0, f32x4& o1) __attribute__((always_inline)) {
+            float a0 = o0.x, a1 = o0.y, a2 = o0.z, a3 = o0.w, b0 = o1.x, b1 = o1.y, b2 = o1.z, b3 = o1.w;
+            const float t0 = b0, t1 = b1, t2 = b2, t3 = b3;
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                         "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0x3\n\tv_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0x3"
+                         : "+v"(b0), "+v"(b1), "+v"(b2), "+v"(b3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3));
+            asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_mov_b32_dpp %1, %5 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+                         "v_mov_b32_dpp %2, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\tv_mov_b32_dpp %3, %7 row_ror:8 row_mask:0xf bank_mask:0xc"
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+            o0 = f32x4{a0, a1, a2, a3}; o1 = f32x4{b0, b1, b2, b3};
+        };
         // this lane's byte offset in instruction 1 of block k: pixel (row i, half h, p16 & 7), quad q16 of the lower / upper 16 columns
         unsigned wo[NT][MT][2];
         const int pxl = tl.x0 + (p16 & 7);
@@ -560,7 +611,6 @@ igemm_h2s_kernel(const H2Args ha) {
                 }
             }
             auto body = [&](auto act_tag) __attribute__((always_inline)) {
-                constexpr bool ACT = decltype(act_tag)::value;
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
                     const __amdgpu_buffer_rsrc_t rd = rsrc(ea.dst(du_[k]), k);
@@ -571,9 +621,16 @@ igemm_h2s_kernel(const H2Args ha) {
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
-                            f32x4 o0 = take(2 * i + h, 2 * k), o1 = take(2 * i + h, 2 * k + 1);
-                            if constexpr (EK == EK_FWD) { o0 += bias4[2 * k]; o1 += bias4[2 * k + 1]; }      // (backward-data has no bias: the launcher checks)
-                            if constexpr (ACT) { o0 = act4(o0); o1 = act4(o1); }
+                            f32x4 o0, o1;
+                            if constexpr (EK == EK_FWD) {            // (backward-data has no bias: the launcher checks)
+                                o0 = take_bias(2 * i + h, 2 * k, bias4[2 * k]); o1 = take_bias(2 * i + h, 2 * k + 1, bias4[2 * k + 1]);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) { float e = o0[c]; act_sign(e, sb, aslope, act_tag); o0[c] = e; }
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) { float e = o1[c]; act_sign(e, sb, aslope, act_tag); o1[c] = e; }
+                            } else {
+                                o0 = take(2 * i + h, 2 * k); o1 = take(2 * i + h, 2 * k + 1);
+                            }
                             if constexpr (MASKED) {
                                 const f32x4 m1 = mk[2 * i + h][2 * k], m2 = mk[2 * i + h][2 * k + 1], mx = ror8(sel(lo8, m2, m1));
                                 const f32x4 q0 = sel(lo8, m1, mx), q1 = sel(lo8, mx, m2);      // the masks of this lane's lower / upper block
@@ -582,19 +639,15 @@ igemm_h2s_kernel(const H2Args ha) {
                                 for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
                             }
                             if constexpr (BITS) {
-                                const f32x4 t0 = o0 * msl, t1 = o1 * msl;
-                                const int pos = ((i * 2 + h) * 2) * 4;
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) {
-                                    o0[c] = ((mbits[k] >> (pos + c)) & 1u) ? o0[c] : t0[c];
-                                    o1[c] = ((mbits[k] >> (pos + 4 + c)) & 1u) ? o1[c] : t1[c];
-                                }
+                                for (int c = 0; c < 4; ++c) { float e = o0[c]; mask_bit(e, mbits[k], msl); o0[c] = e; }
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) { float e = o1[c]; mask_bit(e, mbits[k], msl); o1[c] = e; }
                             }
                             track(o0, blk_[k] && okp[i][h], du_[k]); track(o1, blk_[k] && okp[i][h], du_[k]);
-                            if constexpr (EK == EK_FWD) sb |= signs4(o0, ((i * 2 + h) * 2) * 4) | signs4(o1, ((i * 2 + h) * 2 + 1) * 4);
-                            const f32x4 ox = ror8(sel(lo8, o1, o0));
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, o0, ox)), rd, wo[k][i][h], 0, H2S_STORE_AUX);
-                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sel(lo8, ox, o1)), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
+                            trade(o0, o1);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rd, wo[k][i][h], 0, H2S_STORE_AUX);
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
                         }
                     if constexpr (EK == EK_FWD) {
                         const __amdgpu_buffer_rsrc_t rb = bits_rsrc(ea.bits_out, ea.nblk0);
@@ -672,10 +725,7 @@ igemm_h2s_kernel(const H2Args ha) {
 #pragma unroll
     for (int du = 0; du < 2; ++du) {
         if (!ha.amax_out[du]) continue;
-        float m = du ? amx1 : amx0;
-#pragma unroll
-        for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
-        if (lane == 0) atomicMax(ha.amax_out[du], __float_as_uint(m));
+        pnnp_amax_commit(du ? amx1 : amx0, ha.amax_out[du]);
     }
 #ifdef H2S_STAMPS
     __builtin_amdgcn_s_waitcnt(0x0f70);

@@ -33,7 +33,7 @@ struct H2Args {
     int bits_nblk[2];                        // 32-channel blocks of the tensor behind bits_out ([0]) / bits_in[du]
 };
 // Tile-private bit layout: the 16-row x 32-px x 32-channel block (image b, tile row ty, tile column tx, channel block cb) of a tensor with
-// nblk 32-channel blocks is 512 words; word 64 w + l belongs to lane l of consumer wave w, bit ((i 2 + h) 2 + jj) 4 + c = element
+// nblk 32-channel blocks is 512 words; word 64 w + l belongs to lane l of consumer wave w, bit 31 - (((i 2 + h) 2 + jj) 4 + c) = element
 // (row 2 w + i, pixel 16 h + (l & 15), channel 16 jj + 4 (l >> 4) + c) > 0.  Forward and backward-data tiles of the same tensor coincide,
 // so a lane reads back exactly the word the same lane position wrote: 4 bytes per lane instead of 8 x 16.
 int pnnp_igemm_h2s_launch(const H2Args& a, int chan_per_seg, hipStream_t s);

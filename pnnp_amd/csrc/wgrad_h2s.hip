@@ -4,7 +4,7 @@
 // (16-pixel k-step, tap) where the bf16x3 kernel issues six: (hi, lo') (lo, hi') (hi, hi').  Both operands are activations / gradients split
 // on the fly: G with 2^se_g (odd pixel splits: -2^se_g, the alternating sign costs nothing), X with 2^se_x from the amax slots of the
 // tensors; the slab values are multiplied by 2^-(se_g + se_x) where they leave the accumulators.  The LDS images are two planes instead of
-// three, (taller pixel tiles would fit; the producers' registers do not allow them yet).
+// three, so pixel tiles could be taller; only the 32 x 64 tile's (3 rows instead of 2) fit the producers' registers without spilling.
 #include "common.h"
 #include "h2.h"
 #include <type_traits>
@@ -88,27 +88,27 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         // the waves that stage 32-channel block gblk of G (GT threads) / xblk of X (XT threads): wave-uniform, like the tensors behind them
         const int gblk = MO == 2 ? pw >> 1 : 0, lg = MO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
         const int xblk = NO == 2 ? pw >> 1 : 0, lx = NO == 2 ? (pw & 1) * 64 + lane : pw * 64 + lane;
-        unsigned g_off[NG]; int g_r[NG], g_c[NG], g_dst[NG];
-#pragma unroll
-        for (int k = 0; k < NG; ++k) {
-            const int pix = (lg + Cfg::GT * k) >> 3;
-            g_r[k] = pix >> 5; g_c[k] = pix & 31;
-            g_off[k] = (unsigned)((g_r[k] * a.W + g_c[k]) * a.Gcs + q8 * 4) * 4u;
-            g_dst[k] = (gblk * 2 * GPIX + pix) * 64 + q8 * 8;       // byte offset in an image; + piece * GPIX * 64
-        }
+        // Staging slots WITHOUT per-slot address registers (with them -- 4 per slot -- the taller pixel tiles that two planes per operand leave room
+        // for did not fit 128 registers).  G: slot k of a thread is pixel gp0 + GSTEP k of the 32-wide tile, i.e. row (GSTEP k) >> 5 (a compile-time
+        // number) and column gp0 + (GSTEP k & 31): one base offset, the rest is a scalar.  X: the (TH + 2) x 34 halo does not divide that way: one
+        // packed (row << 8 | column) per slot, everything else derived per tile.
+        constexpr int GSTEP = Cfg::GT / 8, XSTEP = Cfg::XT / 8;
+        const int gp0 = lg >> 3;                                     // < GSTEP <= 32
+        const unsigned g_base = (unsigned)(gp0 * a.Gcs + q8 * 4) * 4u;
+        const int g_dst0 = (gblk * 2 * GPIX + gp0) * 64 + q8 * 8;   // byte offset in an image; + GSTEP k * 64; + piece * GPIX * 64
         const int xd = (n0 + 32 * xblk >= a.n_split) ? 1 : 0;        // wave-uniform source of this wave's X block
         const int xch0 = n0 + 32 * xblk - (xd ? a.n_split : 0);
         const int xcs = a.Xcs[xd];
-        unsigned x_off[NX]; int x_r[NX], x_c[NX], x_dst[NX];
+        int x_rc[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) {
             int j = lx + Cfg::XT * k;
             if (j >= XPIX * 8) j -= Cfg::XT;                         // a slot past the end repeats the thread's previous one
             const int pix = j >> 3;
-            x_r[k] = pix / XC; x_c[k] = pix - x_r[k] * XC;          // halo coordinates: image pixel (y0 - 1 + r, x0 - 1 + c)
-            x_off[k] = (unsigned)((x_r[k] * a.W + x_c[k]) * xcs + q8 * 4) * 4u;
-            x_dst[k] = G_BYTES + (xblk * 2 * XPIX + pix) * 64 + q8 * 8;
+            const int r = pix / XC;
+            x_rc[k] = (r << 8) | (pix - r * XC);                     // halo coordinates: image pixel (y0 - 1 + r, x0 - 1 + c)
         }
+        (void)XSTEP;
         const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc((void*)(a.G + m0 + 32 * gblk), 0, 0x7fffffff, 0x00020000);
         const int xshift = (a.W + 1) * xcs;                          // the X resource starts one row + one pixel BEFORE the tensor
         const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.X[xd] + xch0 - xshift), 0, 0x7fffffff, 0x00020000);
@@ -128,14 +128,17 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             const int rlim = a.H - y0, clim = a.W - x0;
 #pragma unroll
             for (int k = 0; k < NG; ++k) {
-                const int bad = (rlim - 1 - g_r[k]) | (clim - 1 - g_c[k]);                 // sign bit set <=> pixel outside the image
-                rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, bad < 0 ? OOB : g_off[k], gso, 0));
+                constexpr int dummy_ = 0; (void)dummy_;
+                const int gr = (GSTEP * k) >> 5, gc = gp0 + ((GSTEP * k) & 31);
+                const int bad = (rlim - 1 - gr) | (clim - 1 - gc);                         // sign bit set <=> pixel outside the image
+                rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, bad < 0 ? OOB : g_base, gso + (gr * a.W + ((GSTEP * k) & 31)) * a.Gcs * 4, 0));
             }
 #pragma unroll
             for (int k = 0; k < NX; ++k) {
-                const int yy = y0 - 1 + x_r[k], xx = x0 - 1 + x_c[k];
+                const int xr = x_rc[k] >> 8, xc = x_rc[k] & 255;
+                const int yy = y0 - 1 + xr, xx = x0 - 1 + xc;
                 const int bad = yy | (a.H - 1 - yy) | xx | (a.W - 1 - xx);
-                rx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, bad < 0 ? OOB : x_off[k], xso, 0));
+                rx[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, bad < 0 ? OOB : (unsigned)((xr * a.W + xc) * xcs + q8 * 4) * 4u, xso, 0));
             }
         };
         auto stage = [&](f32x4 v, float sc, char* ib, int dst, int pstride) {
@@ -151,10 +154,11 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             for (int k = 0; k < NG; ++k) {
                 f32x4 v = rg[k];
                 bsum[0] += v.x; bsum[1] += v.y; bsum[2] += v.z; bsum[3] += v.w;     // bias gradient: column sums of G (unscaled, unsigned)
-                stage(v, sgs, ib, g_dst[k], GPIX * 64);
+                stage(v, sgs, ib, g_dst0 + GSTEP * k * 64, GPIX * 64);
             }
 #pragma unroll
-            for (int k = 0; k < NX; ++k) stage(rx[k], sxs, ib, x_dst[k], XPIX * 64);
+            for (int k = 0; k < NX; ++k)
+                stage(rx[k], sxs, ib, G_BYTES + (xblk * 2 * XPIX + (x_rc[k] >> 8) * XC + (x_rc[k] & 255)) * 64 + q8 * 8, XPIX * 64);
         };
         // the first tile straight into image 0, the second into the registers
         load_tile(z);
@@ -301,11 +305,23 @@ int launch_whs(const Wh2sArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// pixel-tile height of the configuration for (M, N): as csrc/wgrad_x3s.hip (taller tiles fit the LDS with two planes per operand, but the
-// producers' per-slot address registers do not fit 128 registers then)
-int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? 2 : 3) : ((N % 64 == 0) ? 2 : 4); }
+// pixel-tile height of the configuration for (M, N)
+#ifndef WH2S_TH22
+#define WH2S_TH22 2                    // A/B knobs: the tile heights of the four configurations.  Measured (profiles/r5/ab_wgrad_tile_heights.txt): 3 / 4 / 6 rows for the
+                                       // 64x64 / 64x32 / 32x32 tiles spill 11-18 registers in the producers and are 8-25 % SLOWER; 32x64 at 3 rows fits: -8 %
+#endif
+#ifndef WH2S_TH21
+#define WH2S_TH21 3
+#endif
+#ifndef WH2S_TH12
+#define WH2S_TH12 3
+#endif
+#ifndef WH2S_TH11
+#define WH2S_TH11 4
+#endif
+int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? WH2S_TH22 : WH2S_TH21) : ((N % 64 == 0) ? WH2S_TH12 : WH2S_TH11); }
 
 int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s) {
-    if (a.M % 64 == 0) return a.N % 64 == 0 ? launch_whs<2, 2, 2>(a, s) : launch_whs<2, 1, 3>(a, s);
-    return a.N % 64 == 0 ? launch_whs<1, 2, 2>(a, s) : launch_whs<1, 1, 4>(a, s);
+    if (a.M % 64 == 0) return a.N % 64 == 0 ? launch_whs<2, 2, WH2S_TH22>(a, s) : launch_whs<2, 1, WH2S_TH21>(a, s);
+    return a.N % 64 == 0 ? launch_whs<1, 2, WH2S_TH12>(a, s) : launch_whs<1, 1, WH2S_TH11>(a, s);
 }

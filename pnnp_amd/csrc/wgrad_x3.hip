@@ -36,7 +36,8 @@ int pnnp_wx3s_launch(const Wx3sArgs& a, hipStream_t s);           // csrc/wgrad_
 int pnnp_wx3s_th(int M, int N);                                     // its pixel-tile height for (M, N)
 struct Wh2sArgs { const float* G; int Gcs; const float* X[2]; int Xcs[2]; int n_split; int B, H, W, M, N; float* slab; float* bias_slab; int Z;
                   const unsigned* amax_g; const unsigned* amax_x[2]; };
-int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s);           // csrc/wgrad_h2s.hip (fp16x2: same tiles, same slabs, same reduce)
+int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s);           // csrc/wgrad_h2s.hip (fp16x2: same output tiles, same slabs, same reduce)
+int pnnp_wh2s_th(int M, int N);                                     // its (taller) pixel tiles
 
 namespace {
 
@@ -697,7 +698,12 @@ int pnnp_conv3x3_h2_bwd_weight_f32(const float* g, int g_cs, int Cout, const uns
     Wh2sArgs b{};
     b.G = g; b.Gcs = g_cs; b.X[0] = x1; b.Xcs[0] = x1_cs; b.X[1] = x2 ? x2 : x1; b.Xcs[1] = x2 ? x2_cs : x1_cs; b.n_split = x2 ? C1 : (1 << 30);
     b.B = B; b.H = H; b.W = W; b.M = Cout; b.N = N;
-    b.Z = wx3_splits(B, H, W, Cout, N);                              // (the specialised kernels share their tile heights)
+    b.Z = wx3_splits(B, H, W, Cout, N);                              // (same output tiles: never more splits than the workspace was sized for)
+    {
+        const int th = pnnp_wh2s_th(Cout, N);
+        const int tiles = ((W + 31) / 32) * ((H + th - 1) / th) * B;    // ... and at most one per pixel tile of THIS kernel
+        if (b.Z > tiles) b.Z = tiles;
+    }
     b.slab = workspace;
     b.bias_slab = dbias ? workspace + (int64_t)b.Z * 9 * Cout * N : nullptr;
     b.amax_g = amax_g; b.amax_x[0] = amax_x1; b.amax_x[1] = x2 ? amax_x2 : nullptr;

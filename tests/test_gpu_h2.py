@@ -47,7 +47,7 @@ def _decode_bits(bits, B, H, W, C):
         for h in range(2):
             for jj in range(2):
                 for c in range(4):
-                    bit = ((i * 2 + h) * 2 + jj) * 4 + c
+                    bit = 31 - (((i * 2 + h) * 2 + jj) * 4 + c)          # (shifted in in production order: csrc/conv_h2s.hip)
                     v = (a >> bit) & 1                                            # [B, ty, tx, nb, wave, lane]
                     for wv in range(8):
                         rows = np.arange(ty) * 16 + 2 * wv + i
