@@ -181,7 +181,7 @@ int pnnp_conv_bwd_data_res_f32(const float* g, int Cout, const float* w_dgrad, f
 // ---------------------------------------------------------------- 3x3 / stride 1 / pad 1 on the bf16 matrix cores (bf16x3 split)
 // Same contracts as pnnp_conv_fwd_f32 / pnnp_conv_bwd_data_f32 / pnnp_conv_bwd_data_res_f32 with taps = 9; the weights are the x3
 // packs of pnnp_pack_jobs_add_x3 (C1 < 16 allowed: the pack's reduction length is padded to 16).
-int pnnp_x3_supported(int K, int N) { return (K > 0 && (K % 8) == 0 && N > 0 && (N % 32) == 0) ? 1 : 0; }
+int pnnp_x3_supported(int K, int N) { return (K > 0 && (K % 8) == 0 && N > 0 && (N % 32) == 0 && N <= 1024) ? 1 : 0; }      // (<= 1024 channels written: the kernels keep the bias vector in LDS)
 // The bf16x3 forward / backward-data / pointwise launchers address ONE image of a map through a 32-bit byte offset (bit 31 = "outside"):
 // does a [H][W][cstride] fp32 image fit?  (the limit pnnp_igemm_x3_launch / pnnp_gemm_x3_launch enforce with PNNP_E_UNSUPPORTED;
 // callers choose the kernel family with this BEFORE packing weights)

@@ -152,14 +152,21 @@ def test_x3_bwd_data_mask_on_the_second_destination_only(case):
 
 
 def test_x3_more_output_channels_than_the_bias_buffer_holds():
-    """csrc/conv_x3s.hip keeps the bias vector in LDS (1024 channels); wider layers take round 3's kernel: same results, same contract."""
+    """The matrix-core 3x3 kernels keep the layer's bias vector in LDS (1024 channels): a wider layer is refused up front (pnnp_x3_supported /
+    pnnp_h2_supported, PNNP_E_UNSUPPORTED from the entry point) and runs on the fp32-MFMA kernel -- same results, same contract.  (Until round 5
+    round 3's kernel took these layers; it is gone: DESIGN Appendix A.)"""
     from pnnp_amd import ops
+    from pnnp_amd._lib import PnnpError
     B, H, W, Ci, Co = 1, 16, 32, 32, 1088
+    assert not ops.x3_supported(Ci, Co) and not ops.h2_supported(Ci, Co) and ops.x3_supported(Ci, 1024)
     x = _rand(B, Ci, H, W, seed=1); w = _rand(Co, Ci, 3, 3, seed=3, scale=0.2); b = _rand(Co, seed=4)
     f, _ = _packs(w.cuda(), dgrad=False)
     y = torch.full((B, H, W, Co), float('nan'), device='cuda')
-    ops.conv_x3_fwd(nhwc(x).cuda(), None, f, b.cuda(), y, Co, 1)
-    close(nchw(y), F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2), what='x3 fwd 1088 output channels')
+    with pytest.raises(PnnpError):
+        ops.conv_x3_fwd(nhwc(x).cuda(), None, f, b.cuda(), y, Co, 1)
+    f32 = torch.empty(w.numel(), device='cuda'); ops.pack_conv_weight(w.cuda(), f32, None)
+    ops.conv_fwd(nhwc(x).cuda(), None, f32, b.cuda(), y, Co, 9, 1)
+    close(nchw(y), F.leaky_relu(F.conv2d(x, w, b, padding=1), 0.2), what='fp32-MFMA fwd 1088 output channels')
 
 
 @pytest.mark.parametrize('case', [(2, 16, 48, 32, 0, 32), (1, 12, 40, 32, 0, 64), (1, 6, 70, 64, 0, 128), (2, 8, 32, 32, 32, 32),
