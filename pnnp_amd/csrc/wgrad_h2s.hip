@@ -37,16 +37,19 @@ constexpr unsigned OOB = 0x80000000u;
 #define WX3_ALT_SIGN 1                 // odd pixel splits accumulate -G * X (csrc/wgrad_x3.hip: the matrix core's accumulation rounds toward minus infinity)
 #endif
 
-template <int MO, int NO, int TH> struct WsCfg {
-    static constexpr int WK = 4 / (MO * NO);                       // consumers that share a (block, filter row): pixel split inside the workgroup
+template <int MO, int NO, int TH, int MW = 1> struct WsCfg {
+    // MW: 32 x 32 blocks along M that ONE consumer owns (1, or 2 = both of a 64-row tile: the X words of a tap then feed two blocks, 20 transposed
+    // reads per 18 MFMAs instead of 16 per 9 -- this kernel is LDS-bandwidth-bound with one block per wave: 12 waves x 16 reads x 512 B per k-step
+    // are 89 % of the LDS's 128 B / clk at full matrix rate)
+    static constexpr int WK = 4 * MW / (MO * NO);                  // consumers that share a (block, filter row): pixel split inside the workgroup
     static constexpr int KS = TH * 2, KSW = KS / WK;               // 16-pixel k-steps per pixel tile; per consumer
     static constexpr int GPIX = TH * 32, XPIX = (TH + 2) * XC;
     static constexpr int G_BYTES = MO * 2 * GPIX * 64, X_BYTES = NO * 2 * XPIX * 64, IMG_BYTES = G_BYTES + X_BYTES, LDS_BYTES = 2 * IMG_BYTES;
     static constexpr int GT = 256 / MO, XT = 256 / NO;             // producer threads per 32-channel block of G / X
     static constexpr int NG = GPIX * 8 / GT, NX = (XPIX * 8 + XT - 1) / XT;      // float4 staging slots per producer thread
-    static_assert(MO * NO * WK == 4 && KSW * WK == KS, "wave layout");
+    static_assert(MO * NO * WK == 4 * MW && KSW * WK == KS && (MW == 1 || MW == MO), "wave layout");
     static_assert((GPIX * 8) % GT == 0, "G slots divide evenly (the bias sums count every pixel once)");
-    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NCW * 16 * 64 * 4, "LDS budget (images; the final reduction aliases them)");
+    static_assert(LDS_BYTES <= 160 * 1024 && LDS_BYTES >= NCW * 16 * 64 * 4, "LDS budget (images; the final reduction aliases them, one accumulator block at a time)");
 };
 
 // hi = f16(a s), lo = f16(a s - hi) of two values, packed (csrc/conv_h2s.hip)
@@ -59,10 +62,10 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
     hi = h; lo = l;
 }
 
-template <int MO, int NO, int TH>
+template <int MO, int NO, int TH, int MW>
 __global__ void __launch_bounds__(NTHR, 1)
 wgrad_h2s_kernel(const Wh2sArgs a) {
-    using Cfg = WsCfg<MO, NO, TH>;
+    using Cfg = WsCfg<MO, NO, TH, MW>;
     constexpr int WK = Cfg::WK, KSW = Cfg::KSW, GPIX = Cfg::GPIX, XPIX = Cfg::XPIX, G_BYTES = Cfg::G_BYTES, IMG_BYTES = Cfg::IMG_BYTES, NG = Cfg::NG, NX = Cfg::NX;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -177,7 +180,7 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         // the threads that share (block, q8) through LDS (the images are dead)
         if (WK > 1) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) WHS_BARRIER();
+            for (int i = 0; i < 6 * MW; ++i) WHS_BARRIER();
         }
         WHS_BARRIER();
         constexpr int NSLOTS = Cfg::GT / 8;                           // threads per (block, quad)
@@ -200,13 +203,15 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
 
     // =============================================== CONSUMER ===============================================
     const int tr = wave % 3, rest = wave / 3;                        // filter row; (block, pixel split)
-    const int wk = rest % WK, no = (rest / WK) % NO, mo = rest / (WK * NO);
+    const int wk = rest % WK, no = (rest / WK) % NO, mo = MW == 1 ? rest / (WK * NO) : 0;      // (MW = 2: the wave owns blocks mo = 0 and 1)
     const int l31 = lane & 31, half = lane >> 5;
-    f32x16 acc[3];
+    f32x16 acc[MW][3];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int mb = 0; mb < MW; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][t][r] = 0.f;
     // transposed-read lane geometry (csrc/wgrad_x3.hip): 16-lane group g reads channels 16 (g & 1) .., pixels 8 (g >> 1) ..; inside a group lane
     // 4 q + p supplies the address of pixel row q, channel chunk 4 p
     const int tr_lane = ((8 * (lane >> 5) + ((lane & 15) >> 2)) * 64) + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
@@ -221,12 +226,19 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         WHS_BARRIER();
         const char* gimg = smem + img * IMG_BYTES;
         const char* ximg = gimg + G_BYTES;
-        u32x4 av[2][2], bv[2][2];
-        auto gload = [&](int kl, u32x4 (&ax)[2]) {                   // kl: this consumer's kl-th k-step of the tile
+        // MW = 1: operand words double-buffered (the next step's are read while this step's MFMAs issue).  MW = 2: 96 accumulator registers
+        // leave room for ONE set (128 registers per wave at 16 waves): the next step's words are requested right BEHIND this step's MFMAs --
+        // the matrix core has captured its operands by then -- and the LDS latency is covered by the SIMD's other two consumer waves.
+        constexpr int NBUF = MW == 1 ? 2 : 1;
+        u32x4 av[NBUF][MW][2], bv[NBUF][2];
+        auto gload = [&](int kl, u32x4 (&ax)[MW][2]) {               // kl: this consumer's kl-th k-step of the tile
             const int ks = wk * KSW + kl;
-            const char* gbase = gimg + ((mo * 2) * GPIX + (ks >> 1) * 32 + (ks & 1) * 16) * 64 + tr_lane;
 #pragma unroll
-            for (int p = 0; p < 2; ++p) ax[p] = tr_read(gbase + p * GPIX * 64);
+            for (int mb = 0; mb < MW; ++mb) {
+                const char* gbase = gimg + (((mo + mb) * 2) * GPIX + (ks >> 1) * 32 + (ks & 1) * 16) * 64 + tr_lane;
+#pragma unroll
+                for (int p = 0; p < 2; ++p) ax[mb][p] = tr_read(gbase + p * GPIX * 64);
+            }
         };
         auto xload = [&](int kl, int dx, u32x4 (&bx)[2]) {
             const int ks = wk * KSW + kl;
@@ -241,29 +253,39 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int s = kl * 3 + dx;
-                // the next step's X words (and, at a k-step's last tap, the next k-step's G words) one step ahead
-                if (s + 1 < KSW * 3) xload((s + 1) / 3, (s + 1) % 3, bv[(s + 1) & 1]);
-                if (dx == 2 && kl + 1 < KSW) gload(kl + 1, av[(kl + 1) & 1]);
-                __builtin_amdgcn_sched_barrier(0);
-                const u32x4 (&ax)[2] = av[kl & 1];
-                const u32x4 (&bx)[2] = bv[s & 1];
+                if constexpr (NBUF == 2) {
+                    // the next step's X words (and, at a k-step's last tap, the next k-step's G words) one step ahead
+                    if (s + 1 < KSW * 3) xload((s + 1) / 3, (s + 1) % 3, bv[(s + 1) & 1]);
+                    if (dx == 2 && kl + 1 < KSW) gload(kl + 1, av[(kl + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const u32x4 (&ax)[MW][2] = av[NBUF == 2 ? (kl & 1) : 0];
+                const u32x4 (&bx)[2] = bv[NBUF == 2 ? (s & 1) : 0];
                 // smallest terms first: (hi, lo') (lo, hi') (hi, hi')
-#define WHS_MFMA(PA, PB) acc[dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[PA]), __builtin_bit_cast(f16x8, bx[PB]), acc[dx], 0, 0, 0)
-                WHS_MFMA(0, 1); WHS_MFMA(1, 0); WHS_MFMA(0, 0);
+#define WHS_MFMA(MB, PA, PB) acc[MB][dx] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ax[MB][PA]), __builtin_bit_cast(f16x8, bx[PB]), acc[MB][dx], 0, 0, 0)
+#pragma unroll
+                for (int mb = 0; mb < MW; ++mb) { WHS_MFMA(mb, 0, 1); WHS_MFMA(mb, 1, 0); WHS_MFMA(mb, 0, 0); }
 #undef WHS_MFMA
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NBUF == 1) {
+                    if (s + 1 < KSW * 3) xload((s + 1) / 3, (s + 1) % 3, bv[0]);
+                    if (dx == 2 && kl + 1 < KSW) gload(kl + 1, av[0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         img ^= 1;
     }
-    // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one tap at a time), then the slab [z][tap][m][n]:
-    // 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
+    // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one accumulator block at a time), then the slab
+    // [z][tap][m][n]: 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
     float* red = reinterpret_cast<float*>(smem);
     const int dexp = -(se_g + se_x);                                 // undo the operand scales (exact: a power of two)
     const int64_t slab_base = (int64_t)z * a.M * a.N * 9;
 #pragma unroll
+    for (int mb = 0; mb < MW; ++mb)
+#pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-        f32x16 v = acc[dx];
+        f32x16 v = acc[mb][dx];
         if (WK > 1) {
             WHS_BARRIER();
 #pragma unroll
@@ -283,7 +305,7 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             const int t = tr * 3 + dx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int n = n0 + no * 32 + l31, m = m0 + mo * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int n = n0 + no * 32 + l31, m = m0 + (mo + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = __builtin_ldexpf(v[r], dexp);
             }
         }
@@ -292,10 +314,10 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
     WHS_BARRIER();
 }
 
-template <int MO, int NO, int TH>
+template <int MO, int NO, int TH, int MW = 1>
 int launch_whs(const Wh2sArgs& a, hipStream_t s) {
-    using Cfg = WsCfg<MO, NO, TH>;
-    auto kern = wgrad_h2s_kernel<MO, NO, TH>;
+    using Cfg = WsCfg<MO, NO, TH, MW>;
+    auto kern = wgrad_h2s_kernel<MO, NO, TH, MW>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
     const int blocks = (a.M / (32 * MO)) * (a.N / (32 * NO)) * a.Z;
@@ -306,6 +328,9 @@ int launch_whs(const Wh2sArgs& a, hipStream_t s) {
 }  // namespace
 
 // pixel-tile height of the configuration for (M, N)
+#ifndef WH2S_MW2
+#define WH2S_MW2 1                     // 64-row output tiles: one consumer owns both 32-row blocks (see WsCfg)
+#endif
 #ifndef WH2S_TH22
 #define WH2S_TH22 2                    // A/B knobs: the tile heights of the four configurations.  Measured (profiles/r5/ab_wgrad_tile_heights.txt): 3 / 4 / 6 rows for the
                                        // 64x64 / 64x32 / 32x32 tiles spill 11-18 registers in the producers and are 8-25 % SLOWER; 32x64 at 3 rows fits: -8 %
@@ -319,9 +344,12 @@ int launch_whs(const Wh2sArgs& a, hipStream_t s) {
 #ifndef WH2S_TH11
 #define WH2S_TH11 4
 #endif
-int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? WH2S_TH22 : WH2S_TH21) : ((N % 64 == 0) ? WH2S_TH12 : WH2S_TH11); }
+int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? (WH2S_MW2 ? 2 : WH2S_TH22) : WH2S_TH21) : ((N % 64 == 0) ? WH2S_TH12 : WH2S_TH11); }
 
 int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s) {
+#if WH2S_MW2                          // (measured, profiles/r5/ab_wgrad_two_blocks_per_wave.txt: 64 x 64 tiles -3 ... -6 % per layer; 64 x 32 tiles +6 %: they keep one block per wave)
+    if (a.M % 64 == 0 && a.N % 64 == 0) return launch_whs<2, 2, 2, 2>(a, s);
+#endif
     if (a.M % 64 == 0) return a.N % 64 == 0 ? launch_whs<2, 2, WH2S_TH22>(a, s) : launch_whs<2, 1, WH2S_TH21>(a, s);
     return a.N % 64 == 0 ? launch_whs<1, 2, WH2S_TH12>(a, s) : launch_whs<1, 1, WH2S_TH11>(a, s);
 }
