@@ -71,6 +71,9 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #ifndef H2S_STORE_AUX
 #define H2S_STORE_AUX 2              // cache-policy bits of the epilogue's full-resolution stores: 2 = nt (csrc/conv_x3s.hip, profiles/r4/ab_store_policy.txt)
 #endif
+#ifndef H2S_TURNS
+#define H2S_TURNS 0                  // 1: the two consumer waves of a SIMD take turns with a tile's epilogue (see the consumers' loop): measured 1-3 % SLOWER, off
+#endif
 #ifdef H2S_STAMPS                 // debug build: cycle sums per wave, dumped into dst[0] (tools/x3s_stamps.py)
 #define H2S_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
 #else
@@ -713,12 +716,24 @@ igemm_h2s_kernel(const H2Args ha) {
 #endif
         mfma_chunk(st, img);
         H2S_T(t_mfma)
-        if (g == nchunks - 1) epilogue(cur);
+        // Experiment (H2S_TURNS, off): the two consumer waves of a SIMD (w, w + 4) TAKE TURNS with the epilogue of a tile -- waves 4-7 run it in
+        // front of the chunk barrier as always, waves 0-3 pass the barrier first and run it behind it, while their SIMD partner already issues
+        // the next tile's first MFMAs.  Measured (profiles/r5/ab_epilogue_turns.txt): forward layers +0.7 %, backward-data +2.9 %, step -0.9 %:
+        // one wave alone feeds the matrix pipe at 2/3 of the rate of two, and the waiting partner's idle time replaces the overlap.
+        const bool last_chunk = g == nchunks - 1;
+        const bool barrier_first = H2S_TURNS && last_chunk && n1.ok && wave < NCW / 2;
+        if (barrier_first) {
+            H2S_BARRIER();
+            H2S_T(t_bar)
+        }
+        if (last_chunk) epilogue(cur);
         H2S_T(t_epi)
         if (!n1.ok) break;
-        H2S_BARRIER();
-        H2S_T(t_bar)
-        if (g == nchunks - 1) next_tile(); else ++g;
+        if (!barrier_first) {
+            H2S_BARRIER();
+            H2S_T(t_bar)
+        }
+        if (last_chunk) next_tile(); else ++g;
         img ^= 1; st ^= 1;
     }
     // ---- max |stored value| of the wave per destination -> the amax slots (non-negative floats order like their bit patterns)

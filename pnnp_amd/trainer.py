@@ -50,8 +50,9 @@ class BucketedAllReduce:
     hazard itself for the forward / backward-data kernels: with ``ops.set_persistent_split(4)`` (HipTrainStep sets it around the
     backward pass of a step when ``overlap_allreduce`` is on, and restores the previous value) they launch quarter shares that the hardware dispatcher hands to whichever CU is free -- measured with a
     kernel squatting on 8 / 32 / 64 CUs beside conv2_2: x 1.05 / 1.04 / 1.21 instead of x 1.45 (tests/test_gpu_overlap.py,
-    tools/squat_test.py); alone on the chip the split costs 6-14 % of a layer, hence not the default.  The backward-weight kernels keep
-    their static pixel splits (their summation order is part of the bit-reproducibility contract)."""
+    tools/squat_test.py); alone on the chip the split costs 6-14 % of a layer, hence not the default.  Round 5: the 3x3 backward-weight kernels
+    follow the same setting (four times the slabs, summed by slab index in a fixed order: deterministic for a given share, another pixel
+    partition -- i.e. other rounding -- than with static shares; tests/test_gpu_overlap.py)."""
 
     def __init__(self, flat, bucket_bytes=8 << 20, group=None, force=False, overlap=False):
         import torch.distributed as dist

@@ -28,3 +28,33 @@ def test_persistent_split_is_bit_identical_and_reports_the_cost_of_occupied_cus(
     print(r)
     assert r['same_result']
     assert r['beside_4'] < 1.5 * r['beside_1'], r
+
+
+def test_persistent_split_covers_the_weight_gradient_too():
+    """Round 5: with pnnp_set_persistent_split(4) the 3x3 backward-weight kernels launch four quarter-share workgroups
+    per CU as well (four times the slabs, reduced by slab INDEX in a fixed order), so an all-reduce overlapping any part of the backward pass finds
+    dynamic shares.  Contract: deterministic for a given share (two runs bit-identical), and the same sums as with static shares up to the rounding
+    of another pixel partition; both kernel families (fp16x2, bf16x3)."""
+    from pnnp_amd import ops
+    B, S, Ci, Co = 4, 128, 64, 64
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.randn(B, S, S, Ci, device='cuda', generator=g); gy = torch.randn(B, S, S, Co, device='cuda', generator=g)
+    ws = torch.empty(ops.x3_wgrad_workspace_floats(B, S, S, Co, Ci), device='cuda')
+    slot = lambda t: ops.amax(t, torch.zeros(1, dtype=torch.int32, device='cuda'))
+    sg, sx = slot(gy), slot(x)
+    def run(split, h2):
+        ops.set_persistent_split(split)
+        try:
+            dW = torch.empty(Co, Ci, 3, 3, device='cuda'); db = torch.empty(Co, device='cuda')
+            if h2:
+                ops.conv_h2_bwd_weight(gy, sg, Co, x, sx, Ci, None, None, dW, db, ws)
+            else:
+                ops.conv_x3_bwd_weight(gy, Co, x, Ci, None, dW, db, ws)
+            return dW, db
+        finally:
+            ops.set_persistent_split(1)
+    for h2 in (True, False):
+        w1, b1 = run(1, h2); w4, b4 = run(4, h2); w4b, b4b = run(4, h2)
+        assert torch.equal(w4, w4b) and torch.equal(b4, b4b)                                   # deterministic
+        assert float((w4 - w1).abs().max()) <= 2e-5 * float(w1.abs().max()) and not torch.equal(w4, w1)      # another partition: rounding only
+        assert float((b4 - b1).abs().max()) <= 2e-5 * float(b1.abs().max())
