@@ -386,6 +386,8 @@ int pnnp_nchw_to_nhwc_f32(const float* src, float* dst, int B, int C, int H, int
  * F.pad(imgs_lr, (4,4,4,4), mode='reflect') for frames whose width is not a multiple of 16 (trainer_SID.py:221-226), folded into the
  * layout change the network input goes through anyway */
 int pnnp_nchw_to_nhwc_reflect_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, void* stream);
+/* ... with max |element| raised into an amax slot of the fp16x2 family (the network input's scale: conv1_1 on pnnp_conv3x3_h2_fwd_f32) */
+int pnnp_nchw_to_nhwc_reflect_amax_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, unsigned* amax /*or null*/, void* stream);
 int pnnp_nhwc_to_nchw_f32(const float* src, const float* residual /*or null*/, float* dst,
                           int B, int C, int H, int W, int Cp, void* stream);
 /* out[c] (+)= sum over pixels (bias gradient of a ConvTranspose2d); workspace >= 1024*C floats */

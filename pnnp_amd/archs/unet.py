@@ -378,7 +378,6 @@ class UNetEngine(_EngineBase):
         ch = self.ch
         g = lambda n, s: bufs.get(n, s, dev)
         a = {}
-        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
         # fp16x2 family: amax slots of the activations (keyed by the name of the layer that wrote the tensor; a pooled map shares its
         # full-resolution map's slot) and, in a training forward, the sign bits of every LeakyReLU output that backward-data will need
         h2_on = bool(self._h2)
@@ -386,6 +385,11 @@ class UNetEngine(_EngineBase):
             bufs.slots('f', dev).zero_()
         sl = lambda n: bufs.slot('f', n, dev)
         src_name = {}                          # id(tensor) -> the layer name its amax slot is keyed by
+
+        # the zero-padded NHWC copy of the network input; its amax rides on the layout pass when conv1_1 runs on the fp16x2 kernel
+        first_h2 = self._h2.get('conv1_1', (None, None))[0] is not None
+        a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, W, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad, amax=sl('x8') if first_h2 else None)
+        src_name[id(a['x8'])] = 'x8'
 
         def produced(t, name, fused):
             """`t` was just written by layer `name`; without a fused amax (and if an fp16x2 kernel will read it) a kernel of its own fills the slot."""
@@ -420,8 +424,10 @@ class UNetEngine(_EngineBase):
         cur = a['x8']
         for lvl in range(5):               # encoder: conv{l}_1, conv{l}_2, pool
             i = lvl + 1
-            if lvl == 0 and self._pol.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
-                # conv1_1 on the streaming kernel: its 4 input channels are not worth a (padded) GEMM chunk
+            if lvl == 0 and not first_h2 and self._pol.use_thin_first(self.cin, ch[0], H, W, cur.shape[3]):
+                # conv1_1 on the streaming kernel: its 4 input channels are not worth a (padded) GEMM chunk.  (With the fp16x2 family the
+                # matrix-core kernel is as fast -- a padded chunk is 14 instructions, not 27 -- and writes the sign bits that make conv1_2's
+                # backward-data read 1/32 of the bytes: the streaming kernel keeps conv1_1's weight gradient only.)
                 a['c1a'] = produced(ops.first_fwd(cur, P['conv1_1.weight'], P['conv1_1.bias'], g('conv1_1', (B, H, W, ch[0])), LRELU,
                                                   amax_y=sl('conv1_1') if h2_on else None), 'conv1_1', fused=True)
             else:

@@ -16,7 +16,8 @@ int grid1d(int64_t n, int cap = 256 * 8) {
 
 // [B][C][H][W] -> [B][H][W][Cp], channels >= C zero-filled (Cp multiple of 4).
 __global__ void __launch_bounds__(256)
-nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int Cp, int pad) {
+nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int C, int H, int W, int Cp, int pad, unsigned* __restrict__ amax) {
+    float amx = 0.f;                                                 // max |element| (csrc/h2.h: the network input's scale when conv1_1 runs on the fp16x2 kernel)
     // dst is [B][H + 2 pad][W + 2 pad][Cp]: pad > 0 reflects the frame (F.pad(..., mode='reflect'): index -k -> k, H-1+k -> H-1-k)
     const int Ho = H + 2 * pad, Wo = W + 2 * pad;
     const int64_t hw = (int64_t)H * W, hwo = (int64_t)Ho * Wo, total = (int64_t)B * hwo * (Cp / 4);
@@ -38,7 +39,9 @@ nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int 
             v[k] = c < C ? src[(b * C + c) * hw + s] : 0.f;
         }
         *reinterpret_cast<float4*>(dst + p * Cp + 4 * cq) = make_float4(v[0], v[1], v[2], v[3]);
+        amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
+    if (amax) pnnp_amax_commit(amx, amax);
 }
 
 // [B][H][W][Cp] -> [B][C][H][W] (+ residual NCHW, archs/Unet.py:95-98)
@@ -341,10 +344,14 @@ adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restric
 extern "C" {
 
 int pnnp_nchw_to_nhwc_reflect_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, void* stream) {
+    return pnnp_nchw_to_nhwc_reflect_amax_f32(src, dst, B, C, H, W, Cp, pad, nullptr, stream);
+}
+// ... with max |element| raised into an amax slot of the fp16x2 family
+int pnnp_nchw_to_nhwc_reflect_amax_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, unsigned* amax, void* stream) {
     if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3) || pad < 0 || pad >= H || pad >= W) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
     hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * (H + 2 * pad) * (W + 2 * pad) * (Cp / 4))), dim3(256), 0, as_stream(stream),
-                       src, dst, B, C, H, W, Cp, pad);
+                       src, dst, B, C, H, W, Cp, pad, amax);
     return pnnp_launch_status();
 }
 

@@ -663,11 +663,12 @@ def maxpool_bwd(x, gy, gx, act_mode, accumulate, codes=None, amax_gx=None):
             amax(gx, amax_gx)
 
 
-def nchw_to_nhwc(src, dst, cp, reflect_pad=0):
-    """NCHW -> zero-padded-channel NHWC; ``reflect_pad`` > 0: dst is the frame reflect-padded by that many pixels on every side."""
+def nchw_to_nhwc(src, dst, cp, reflect_pad=0, amax=None):
+    """NCHW -> zero-padded-channel NHWC; ``reflect_pad`` > 0: dst is the frame reflect-padded by that many pixels on every side.
+    ``amax``: an amax slot of the fp16x2 family (max |element| is raised into it)."""
     require_cuda(src, dst)
     B, Cc, H, W = src.shape
-    check(_prep().pnnp_nchw_to_nhwc_reflect_f32(ptr(src), ptr(dst), B, Cc, H, W, cp, int(reflect_pad), stream()), 'nchw_to_nhwc')
+    check(_prep().pnnp_nchw_to_nhwc_reflect_amax_f32(ptr(src), ptr(dst), B, Cc, H, W, cp, int(reflect_pad), ptr(amax), stream()), 'nchw_to_nhwc')
     return dst
 
 
