@@ -12,7 +12,7 @@ cp gpurun_out/traffic.json gpurun_out/pmc_fetch_size.csv gpurun_out/pmc_write_si
 cp gpurun_out/traffic.json profiles/traffic.json
 # 2. tests
 if [ -z "$SKIP_TESTS" ]; then
-timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -25 > $OUT/pytest.log
+timeout 2400 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|FAILED|ERROR" > $OUT/pytest.log
 timeout 400 python -m pytest tests/test_gpu_h2.py tests/test_gpu_x3.py tests/test_gpu_fullsize.py tests/test_gpu_unet.py -q -m gpu -s -k "accurate or golden or cancellation or dynamic_range or below or signed or tiny or wide_range or trajectory" 2>&1 | grep -i "relative L2\|worst HIP\|vs float64\|cancellation\|scale x\|below the\|signed mean\|convT wgrad\|x at 1e-36\|one channel\|over 40 steps" > $OUT/accuracy.log
 fi
 # 3. the bench line (default flags: h2 family, complete CPU-baseline protocol) and the rocprofv3 kernel statistics of the same command
