@@ -10,6 +10,7 @@
 // ISO gain is folded into the 4x4 inverse matrix on the host.  NCHW fp32, like the reference.
 #include "common.h"
 #include <string.h>
+#include <type_traits>
 
 struct NfStep {              // 317 floats, passed by value as a kernel argument
     float w1[4][2][9], b1[4], s1[4], o1[4];   // conv2d_1, eval-mode BatchNorm folded to y = s*x + o
@@ -79,94 +80,191 @@ normal_fill_kernel(float* __restrict__ out, int64_t n, uint32_t k0, uint32_t k1,
     }
 }
 
+// The launcher's re-arrangement of NfStep for nf_step_kernel: OUTPUT channel innermost, so that the weights of two output channels are an
+// aligned register pair and one v_pk_fma_f32 advances both (the vector fp32 peak is the packed rate; the plain v_fma is half).
+struct NfStepDev {
+    float w1[2][9][4], b1[4], s1[4], o1[4];
+    float w2[4][4], b2[4], s2[4], o2[4];      // w2[c][o]
+    float w3[5][9][4], b3[4], e3[4];
+    float winv[4][4];                         // winv[c][o]
+    float scale;                              // (last: every group of four above is 16-byte aligned)
+};
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk_fma(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 ld2(const float* q) { return f2{q[0], q[1]}; }
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+// tanh and exp on the hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each).  tanh(v) = 1 - 2 / (1 + e^{2v}): absolute error
+// ~1e-7, which exp(-scale tanh) turns into a RELATIVE 1e-7 of the sample (the sampling tests' bar is 2e-4; the density direction,
+// whose log-likelihood is compared at 2e-5, keeps libm: nf_fwd_step_kernel).  libm's tanhf + expf were ~200 instructions per pixel.
+__device__ __forceinline__ float fast_tanh(float v) { return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __expf(2.f * v)); }
+
 __global__ void __launch_bounds__(256)
-nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, const NfStep p,
+nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, const NfStepDev pk,
                const float* __restrict__ clean, float sdn_a, float sdn_b, float out_mul, const NfMix mx) {
-    __shared__ float z0s[2][ZW][ZW + 1];
-    __shared__ float hs[4][HW_][HW_ + 1];
+    __shared__ f2 z0s[ZW][ZW + 1];              // (channel 0, channel 1) of a position: one 8-byte read per tap
+    __shared__ float4 hs[HW_][HW_ + 1];         // the four hidden channels of a position: one 16-byte read per tap
+    // The coupling network's 317 parameters live in LDS and are read as broadcast 8 / 16-byte loads next to their use.  As scalar
+    // registers (a by-value kernel argument) they do not fit -- a phase needs 112 / 212 of them, a wave has 102 -- and the compiler
+    // parked the overflow in vector-register lanes: 700 v_readlane_b32 in the per-pixel loops, more than the arithmetic.
+    __shared__ __attribute__((aligned(16))) float wsh[(sizeof(NfStepDev) / 4 + 3) & ~3];
+    const NfStepDev& p = *reinterpret_cast<const NfStepDev*>(wsh);
     const int b = blockIdx.z, ty0 = blockIdx.y * TS, tx0 = blockIdx.x * TS;
     const int64_t plane = (int64_t)H * W;
     const float* xb = x + (int64_t)b * 4 * plane;
-    float s1l[4], o1l[4], s2l[4], o2l[4];          // BatchNorm as y = s x + o: folded on the host (eval) or from the batch statistics
-#pragma unroll
-    for (int o = 0; o < 4; ++o) {
-        if (mx.bn_stats) {
-            const float sa = p.s1[o] * mx.bn_stats[4 + o], sb = p.s2[o] * mx.bn_stats[16 + o];
-            s1l[o] = sa; o1l[o] = p.o1[o] - (mx.bn_stats[o] + p.b1[o]) * sa;
-            s2l[o] = sb; o2l[o] = p.o2[o] - (mx.bn_stats[12 + o] + p.b2[o]) * sb;
-        } else {
-            s1l[o] = p.s1[o]; o1l[o] = p.o1[o]; s2l[o] = p.s2[o]; o2l[o] = p.o2[o];
-        }
+    for (int i = threadIdx.x; i < (int)(sizeof(NfStepDev) / 4); i += 256) wsh[i] = reinterpret_cast<const float*>(&pk)[i];
+    __syncthreads();
+    // BatchNorm as y = s x + o: folded on the host (eval) or, here, from the batch statistics (then s1 / o1 / s2 / o2 hold gamma / beta)
+    if (mx.bn_stats && threadIdx.x < 4) {
+        NfStepDev& pw = *reinterpret_cast<NfStepDev*>(wsh);
+        const int o = threadIdx.x;
+        const float sa = p.s1[o] * mx.bn_stats[4 + o], sb = p.s2[o] * mx.bn_stats[16 + o];
+        pw.o1[o] = p.o1[o] - (mx.bn_stats[o] + p.b1[o]) * sa; pw.s1[o] = sa;
+        pw.o2[o] = p.o2[o] - (mx.bn_stats[12 + o] + p.b2[o]) * sb; pw.s2[o] = sb;
     }
     // z0 tile (channels 0,1) with halo 2; zero outside the image (conv2d_1 pads with zeros)
-    for (int i = threadIdx.x; i < 2 * ZW * ZW; i += 256) {
-        const int c = i / (ZW * ZW), r = (i / ZW) % ZW, q = i % ZW;
+    for (int i = threadIdx.x; i < ZW * ZW; i += 256) {
+        const int r = i / ZW, q = i % ZW;
         const int gy = ty0 + r - 2, gx = tx0 + q - 2;
-        z0s[c][r][q] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? xb[c * plane + (int64_t)gy * W + gx] : 0.f;
+        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int64_t pix = (int64_t)gy * W + gx;
+        z0s[r][q] = in ? f2{xb[pix], xb[plane + pix]} : f2{0.f, 0.f};
     }
     __syncthreads();
-    // hidden map h2 (4 channels) on the tile + halo 1; positions outside the image are the zero pad
-    for (int i = threadIdx.x; i < HW_ * HW_; i += 256) {
-        const int r = i / HW_, q = i % HW_;
-        const int gy = ty0 + r - 1, gx = tx0 + q - 1;
-        float h2[4] = {0.f, 0.f, 0.f, 0.f};
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            float h1[4];
+    // hidden map h2 (4 channels) on the tile + halo 1; positions outside the image are the zero pad.  NP positions per thread AT ONCE
+    // with the weight loops outside the position loop: each weight pair is loaded into scalar registers once and used NP times.  (With
+    // the position loop outside, the 112 / 212 weights a phase needs were all live across it -- more than the 102 scalar registers --
+    // and the compiler parked them in vector-register lanes: 700 v_readlane_b32 in the loop bodies, more than the arithmetic.)
+    auto hidden = [&](auto np_tag, int i0) {
+        constexpr int NP = decltype(np_tag)::value;
+        int opq = 0;
+        asm volatile("" : "+v"(opq));              // (an offset the compiler cannot see through: the parameter reads stay inside this call
+        const NfStepDev& p = *reinterpret_cast<const NfStepDev*>(wsh + 4 * opq);   //  instead of being hoisted -- 112 registers -- above the loop around it)
+        int rr[NP], qq[NP];
+        bool in[NP];
+        f2 a01[NP], a23[NP];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float s = p.b1[o];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) s += p.w1[o][c][t] * z0s[c][r + t / 3][q + t % 3];
-                h1[o] = fmaxf(s1l[o] * s + o1l[o], 0.f);
-            }
-#pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                float s = p.b2[o];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) s += p.w2[o][c] * h1[c];
-                h2[o] = fmaxf(s2l[o] * s + o2l[o], 0.f);
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int i = min(i0 + 256 * k, HW_ * HW_ - 1);
+            rr[k] = i / HW_; qq[k] = i % HW_;
+            const int gy = ty0 + rr[k] - 1, gx = tx0 + qq[k] - 1;
+            in[k] = gy >= 0 && gy < H && gx >= 0 && gx < W;
+            a01[k] = ld2(p.b1); a23[k] = ld2(p.b1 + 2);
         }
 #pragma unroll
-        for (int o = 0; o < 4; ++o) hs[o][r][q] = h2[o];
-    }
-    __syncthreads();
-    // outputs: 4 pixels per thread
-    for (int i = threadIdx.x; i < TS * TS; i += 256) {
-        const int r = i / TS, q = i % TS;
-        const int gy = ty0 + r, gx = tx0 + q;
-        if (gy >= H || gx >= W) continue;
-        float o3[4];
+        for (int t = 0; t < 9; ++t) {
+            f2 z[NP];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            float s = p.b3[o];
+            for (int k = 0; k < NP; ++k) z[k] = z0s[rr[k] + t / 3][qq[k] + t % 3];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const f2 wa = ld2(p.w1[c][t]), wb = ld2(p.w1[c][t] + 2);
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    const f2 zz = splat(c ? z[k].y : z[k].x);
+                    a01[k] = pk_fma(wa, zz, a01[k]); a23[k] = pk_fma(wb, zz, a23[k]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);          // (keeps the scheduler from hoisting every tap's LDS reads to the top: 186 registers)
+        }
+        f2 g01[NP], g23[NP];
+        float h1[NP][4];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            a01[k] = pk_fma(ld2(p.s1), a01[k], ld2(p.o1));
+            a23[k] = pk_fma(ld2(p.s1 + 2), a23[k], ld2(p.o1 + 2));
+            h1[k][0] = fmaxf(a01[k].x, 0.f); h1[k][1] = fmaxf(a01[k].y, 0.f); h1[k][2] = fmaxf(a23[k].x, 0.f); h1[k][3] = fmaxf(a23[k].y, 0.f);
+            g01[k] = ld2(p.b2); g23[k] = ld2(p.b2 + 2);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f2 wa = ld2(p.w2[c]), wb = ld2(p.w2[c] + 2);
+#pragma unroll
+            for (int k = 0; k < NP; ++k) { g01[k] = pk_fma(wa, splat(h1[k][c]), g01[k]); g23[k] = pk_fma(wb, splat(h1[k][c]), g23[k]); }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            g01[k] = pk_fma(ld2(p.s2), g01[k], ld2(p.o2));
+            g23[k] = pk_fma(ld2(p.s2 + 2), g23[k], ld2(p.o2 + 2));
+            const float4 h2 = make_float4(fmaxf(g01[k].x, 0.f), fmaxf(g01[k].y, 0.f), fmaxf(g23[k].x, 0.f), fmaxf(g23[k].y, 0.f));
+            hs[rr[k]][qq[k]] = in[k] ? h2 : make_float4(0.f, 0.f, 0.f, 0.f);      // (lanes past the end redo the LAST position: same value, and no branch for the arithmetic to sink into)
+        }
+    };
+    static_assert(HW_ * HW_ > 4 * 256 && HW_ * HW_ <= 5 * 256, "hidden tile: four full rounds and a tail");
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) hidden(std::integral_constant<int, 2>{}, threadIdx.x + 512 * half);
+    if ((threadIdx.x & ~63) + 1024 < HW_ * HW_) hidden(std::integral_constant<int, 1>{}, threadIdx.x + 1024);      // (wave-uniform: waves 0 .. 2)
+    __syncthreads();
+    // outputs: 2 + 2 pixels per thread (same column, rows 8 apart), for the same reason
+    constexpr int NPX = 2;
+    static_assert(TS * TS == 2 * NPX * 256, "two rounds of NPX pixels");
+    const int q = threadIdx.x % TS;
+    const float cdiv = mx.clean_div ? mx.clean_div[b] : mx.clean_div_s;
+    const float mmul = mx.mix_mul ? mx.mix_mul[b] : mx.mix_mul_s;
+    bool neg = false;
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+    const int r0 = threadIdx.x / TS + 16 * half;
+    int opq = 0;
+    asm volatile("" : "+v"(opq));
+    const NfStepDev& p = *reinterpret_cast<const NfStepDev*>(wsh + 4 * opq);
+    const int gx = tx0 + q;
+    f2 s01[NPX], s23[NPX];
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) { s01[k] = ld2(p.b3); s23[k] = ld2(p.b3 + 2); }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float4 h[NPX];
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) h[k] = hs[r0 + 8 * k + t / 3][q + t % 3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f2 wa = ld2(p.w3[c][t]), wb = ld2(p.w3[c][t] + 2);
+#pragma unroll
+            for (int k = 0; k < NPX; ++k) {
+                const float hv = c == 0 ? h[k].x : (c == 1 ? h[k].y : (c == 2 ? h[k].z : h[k].w));
+                s01[k] = pk_fma(wa, splat(hv), s01[k]); s23[k] = pk_fma(wb, splat(hv), s23[k]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // channel 4: ones on the border ring of the padded map, i.e. exactly the out-of-image taps (only image-border pixels have one)
+    {
+        bool edge = gx == 0 || gx == W - 1;
+#pragma unroll
+        for (int k = 0; k < NPX; ++k) { const int gy = ty0 + r0 + 8 * k; edge |= gy == 0 || gy == H - 1; }
+        if (edge) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int yy = gy + t / 3 - 1, xx = gx + t % 3 - 1;
+                const f2 wa = ld2(p.w3[4][t]), wb = ld2(p.w3[4][t] + 2);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) s += p.w3[o][c][t] * hs[c][r + t / 3][q + t % 3];
-                // channel 4: ones on the border ring of the padded map, i.e. exactly the out-of-image taps
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) s += p.w3[o][4][t];
+                for (int k = 0; k < NPX; ++k) {
+                    const int yy = ty0 + r0 + 8 * k + t / 3 - 1, xx = gx + t % 3 - 1;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) { s01[k] += wa; s23[k] += wb; }
+                }
             }
-            o3[o] = s * p.e3[o];
         }
+    }
+#pragma unroll
+    for (int k = 0; k < NPX; ++k) {
+        const int r = r0 + 8 * k, gy = ty0 + r;
+        if (gy >= H || gx >= W) continue;
+        const f2 o01 = s01[k] * ld2(p.e3), o23 = s23[k] * ld2(p.e3 + 2);                   // o3[0..3]
         const int64_t pix = (int64_t)gy * W + gx;
-        const float z0a = z0s[0][r + 2][q + 2], z0b = z0s[1][r + 2][q + 2];
+        const f2 z0 = z0s[r + 2][q + 2];
         const float z1a = xb[2 * plane + pix], z1b = xb[3 * plane + pix];
-        const float v[4] = {z0a, z0b,
-                            (z1a - o3[0]) * expf(-(p.scale * tanhf(o3[2]))),
-                            (z1b - o3[1]) * expf(-(p.scale * tanhf(o3[3])))};
+        const float v[4] = {z0.x, z0.y,
+                            (z1a - o01.x) * __expf(-(p.scale * fast_tanh(o23.x))),
+                            (z1b - o01.y) * __expf(-(p.scale * fast_tanh(o23.y)))};
+        f2 r01 = {0.f, 0.f}, r23 = {0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            r01 = pk_fma(ld2(p.winv[c]), splat(v[c]), r01);
+            r23 = pk_fma(ld2(p.winv[c] + 2), splat(v[c]), r23);
+        }
+        const float rs[4] = {r01.x, r01.y, r23.x, r23.y};
         float post = out_mul;
-        const float cdiv = mx.clean_div ? mx.clean_div[b] : mx.clean_div_s;
-        const float mmul = mx.mix_mul ? mx.mix_mul[b] : mx.mix_mul_s;
-        bool neg = false;
 #pragma unroll
         for (int o = 0; o < 4; ++o) {
-            float s = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) s += p.winv[o][c] * v[c];
             if (clean) {
                 float cl = clean[((int64_t)b * 4 + o) * plane + pix];
                 if (cdiv != 1.f) cl = __fdiv_rn(cl, cdiv);               // imgs_hr / ratio, rounded like the tensor op
@@ -174,15 +272,16 @@ nf_step_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W,
                 neg = neg || sc2 < 0.f;
                 post = out_mul * sqrtf(sc2);
             }
-            float r = s * post;
+            float rr = rs[o] * post;
             if (mx.mix_base) {                                           // imgs_hr + noise * ratio, two roundings like the tensor ops, then the clamp
-                r = mul_then_add(mx.mix_base[((int64_t)b * 4 + o) * plane + pix], r, mmul);
-                if (r == r) r = fminf(fmaxf(r, mx.lo), mx.hi);              // (a NaN stays a NaN, as in Tensor.clamp)
+                rr = mul_then_add(mx.mix_base[((int64_t)b * 4 + o) * plane + pix], rr, mmul);
+                if (rr == rr) rr = fminf(fmaxf(rr, mx.lo), mx.hi);          // (a NaN stays a NaN, as in Tensor.clamp)
             }
-            y[((int64_t)b * 4 + o) * plane + pix] = r;
+            y[((int64_t)b * 4 + o) * plane + pix] = rr;
         }
-        if (neg && mx.flag) atomicOr(mx.flag, 1);
     }
+    }
+    if (neg && mx.flag) atomicOr(mx.flag, 1);
 }
 
 // nn.BatchNorm2d's buffer update for the two BatchNorm layers of a coupling whose batch statistics pnnp_nf_train_stats_f32 left on the
@@ -342,9 +441,18 @@ int pnnp_nf_step_mix_f32(const float* x, float* y, int B, int H, int W, const fl
                          float clamp_lo, float clamp_hi, int* flag, const float* bn_stats, void* stream) {
     if (!x || !y || !step || B < 0 || H <= 0 || W <= 0 || x == y || y == mix_base) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    NfStep p;
-    static_assert(sizeof(NfStep) == 317 * sizeof(float), "NfStep layout");
-    memcpy(&p, step, sizeof p);
+    NfStep hp;
+    static_assert(sizeof(NfStep) == 317 * sizeof(float) && sizeof(NfStepDev) == sizeof(NfStep), "NfStep layout");
+    memcpy(&hp, step, sizeof hp);
+    NfStepDev p;
+    for (int o = 0; o < 4; ++o) {
+        for (int c = 0; c < 2; ++c) for (int t = 0; t < 9; ++t) p.w1[c][t][o] = hp.w1[o][c][t];
+        for (int c = 0; c < 5; ++c) for (int t = 0; t < 9; ++t) p.w3[c][t][o] = hp.w3[o][c][t];
+        for (int c = 0; c < 4; ++c) { p.w2[c][o] = hp.w2[o][c]; p.winv[c][o] = hp.winv[o][c]; }
+        p.b1[o] = hp.b1[o]; p.s1[o] = hp.s1[o]; p.o1[o] = hp.o1[o]; p.b2[o] = hp.b2[o]; p.s2[o] = hp.s2[o]; p.o2[o] = hp.o2[o];
+        p.b3[o] = hp.b3[o]; p.e3[o] = hp.e3[o];
+    }
+    p.scale = hp.scale;
     NfMix mx{clean_div, clean_div_s, mix_base, mix_mul, mix_mul_s, clamp_lo, clamp_hi, flag, bn_stats};
     hipLaunchKernelGGL(nf_step_kernel, dim3((W + TS - 1) / TS, (H + TS - 1) / TS, B), dim3(256), 0, as_stream(stream),
                        x, y, H, W, p, clean, sdn_a, sdn_b, out_mul, mx);
