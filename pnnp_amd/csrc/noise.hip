@@ -21,16 +21,25 @@
 // Poisson: lam < 10 sequential inversion; lam >= 10 Hoermann's PTRS transformed rejection
 // (exact, no Gaussian approximation).  Specification: oracle/pnnp_oracle.c.
 //
-// Thread layout: one thread owns 4 consecutive pixels of a row (float4 load/store, fully
-// coalesced); the row-noise normal is drawn once by the first lane of each run of lanes that
-// share a row and broadcast inside the wavefront (ballot + shuffle), never per pixel.
+// Thread layout: one thread owns 4 consecutive pixels of a row (float4 load/store, fully coalesced).  The kernel is bound by VECTOR
+// INSTRUCTION ISSUE, not by HBM (profiles/r5/noise_sampler_pmc.txt: ~100 % of the SIMDs' issue slots, 40 - 50 of 64 lanes alive), so its
+// shape follows from keeping lanes alive:
+//   * straight-line work (Philox blocks, Box-Muller pairs, PTRS's quick acceptance) is done for the 4 pixels of every lane;
+//   * data-dependent work -- the inversion loop, PTRS's logarithm test and its retries -- goes through wave-private LDS queues and is run
+//     on dense groups of 64 pixels (see the kernel);
+//   * the row-noise normal -- one draw per (crop, channel, row) -- is drawn for all rows of a block side by side, not by one lane per wave;
+//   * index arithmetic is 32-bit with multiply-shift division (the 64-bit / and % are software routines).
 #include "common.h"
 
 namespace {
 
-struct Philox {
-    uint32_t k0, k1;
+// Division of a 31-bit index by a run-time constant (Granlund-Montgomery, round-up variant): q = (mulhi(t, m) + t) >> l with
+// l = ceil(log2 d), m = ceil(2^(32+l) / d) - 2^32.  Exact for t < 2^31 (the sum cannot wrap).  The 64-bit / and % the index
+// arithmetic used before are software routines on this hardware: four of them were ~600 instructions per quad, as much as the sampling.
+struct FastDiv {
+    uint32_t m, l, d;
 };
+__device__ __forceinline__ uint32_t fd_div(uint32_t t, const FastDiv f) { return (__umulhi(t, f.m) + t) >> f.l; }
 
 __device__ __forceinline__ uint4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
     // one 64-bit product per multiplier and round (v_mad_u64_u32 runs at the full VALU rate on gfx950: tools/ubench/intmul_rate.hip;
@@ -136,11 +145,8 @@ __device__ __forceinline__ float poisson_small(float lam, float u_in, bool take)
     return k;
 }
 
-__device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
-    const bool small = lam > 0.f && lam < 10.f;
-    const float ks = poisson_small(lam, u01(r0), small);          // (convergent: every lane of the wave comes through here)
-    if (!(lam > 0.f)) return 0.f;
-    if (small) return ks;
+// Hoermann's PTRS for lam >= 10, all rounds (the oracle's loop).  Round 0 uses (r0, r1); later rounds draw their own blocks.
+__device__ float poisson_ptrs(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
     const float slam = fast_sqrt(lam), loglam = fast_log(lam);
     const float b = 0.931f + 2.53f * slam;
     const float a = -0.059f + 0.02483f * b;
@@ -162,6 +168,26 @@ __device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0
     }
     return floorf(lam + 0.5f);
 }
+// PTRS round 0, the quick acceptance only (86 % of the pixels at lam >= 10 leave here): no logarithm, no retry.  A pixel this does not
+// accept is finished by poisson_ptrs, which repeats the round -- the same operations on the same inputs -- and goes on from there.
+__device__ __forceinline__ bool ptrs_quick(float lam, uint32_t r0, uint32_t r1, float& k) {
+    const float b = 0.931f + 2.53f * fast_sqrt(lam);
+    const float a = -0.059f + 0.02483f * b;
+    const float vr = 0.9277f - fast_div(3.6224f, b - 2.f);
+    const float U = u01(r0) - 0.5f, V = u01(r1);
+    const float us = 0.5f - fabsf(U);
+    k = floorf((fast_div(2.f * a, us) + b) * U + lam + 0.43f);
+    return us >= 0.07f && V <= vr;
+}
+
+// one pixel on its own (sna_kernel): every lane of the wave must come through here (poisson_small is wave-convergent)
+__device__ float poisson_f32(float lam, uint32_t elem, const Ctx& c, uint32_t r0, uint32_t r1) {
+    const bool small = lam > 0.f && lam < 10.f;
+    const float ks = poisson_small(lam, u01(r0), small);
+    if (!(lam > 0.f)) return 0.f;
+    if (small) return ks;
+    return poisson_ptrs(lam, elem, c, r0, r1);
+}
 
 __device__ __forceinline__ float tukey_lambda(float u, float lam) {
     // (u^lam - (1-u)^lam)/lam, evaluated through expm1 so the cancellation for small |lam|
@@ -174,53 +200,67 @@ __device__ __forceinline__ float tukey_lambda(float u, float lam) {
 __global__ void __launch_bounds__(256)
 noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int C, int H, int W,
                     const float* __restrict__ params, unsigned flags, float mfm,
-                    uint32_t k0, uint32_t k1, uint32_t off, uint32_t crop_base) {
-    const int wq = (W + 3) >> 2;
-    const int64_t rows = (int64_t)B * C * H;
-    const int64_t total = rows * wq;
+                    uint32_t k0, uint32_t k1, uint32_t off, uint32_t crop_base, const FastDiv dwq, const FastDiv dH, const FastDiv dC) {
+    const uint32_t wq = (uint32_t)(W + 3) >> 2;
+    const uint32_t total = (uint32_t)B * C * H * wq;              // < 2^31: the launcher splits larger batches
     const bool torch_mode = flags & PNNP_NOISE_MODE_TORCH;
     const bool use_p = flags & PNNP_NOISE_P, use_g = flags & PNNP_NOISE_G, use_r = flags & PNNP_NOISE_R;
     const bool use_q = flags & PNNP_NOISE_Q, use_d = flags & PNNP_NOISE_D, use_b = flags & PNNP_NOISE_B;
     const bool extras = torch_mode || !use_b;        // OBS: 'b' removes read, row, quant and bias
     const int lane = threadIdx.x & 63;
+    // Wave-private queues (the header's "Poisson" paragraph): entry = (lam, shot uniform, first-round V, element), tag = slot | crop << 8.
+    // PTRS pixels fill q_ent from the front, inversion pixels from the back; a wave has 256 pixels in flight, so they never meet.
+    __shared__ uint4 q_ent_all[4][256];
+    __shared__ uint32_t q_tag_all[4][256];
+    __shared__ float q_res_all[4][256];
+    __shared__ float row_n[256];                 // the row-noise normals of the rows this block touches
+    uint4* const q_ent = q_ent_all[threadIdx.x >> 6];
+    uint32_t* const q_tag = q_tag_all[threadIdx.x >> 6];
+    float* const q_res = q_res_all[threadIdx.x >> 6];
     // grid-stride with the SAME trip count for all lanes of a wave (shuffles below)
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t iters = (total + stride - 1) / stride;
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t t = t0 + it * stride;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint32_t t0 = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t iters = (total + stride - 1) / stride;
+    for (uint32_t it = 0; it < iters; ++it) {
+        const uint32_t t = t0 + it * stride;
         const bool live = t < total;
-        const int64_t tt = live ? t : total - 1;
-        const int xq = (int)(tt % wq);
-        const int64_t row = tt / wq;                     // (b*C + c)*H + h
-        const int h = (int)(row % H);
-        const int c = (int)((row / H) % C);
-        const int b = (int)(row / ((int64_t)H * C));
+        const uint32_t tt = live ? t : total - 1;
+        const uint32_t row = fd_div(tt, dwq);            // (b*C + c)*H + h
+        const int xq = (int)(tt - row * wq);
+        const uint32_t bc = fd_div(row, dH);
+        const int h = (int)(row - bc * (uint32_t)H);
+        const int b = (int)fd_div(bc, dC);
+        const int c = (int)(bc - (uint32_t)b * (uint32_t)C);
         const float* P = params + (int64_t)b * PNNP_NPARAM;
         const float K = P[PNNP_P_K], ratio = P[PNNP_P_RATIO], wp = P[PNNP_P_WP], bl = P[PNNP_P_BL];
         const float span = wp - bl;
         Ctx ctx{k0, k1, crop_base + (uint32_t)b, off};
 
-        // ---- row noise: one draw per run of lanes sharing `row`, broadcast in-wave
+        uint32_t row_first = 0;
+        // ---- row noise: ONE draw per (crop, channel, row).  The rows this block's 256 quads touch are drawn side by side by its first
+        // threads -- thread j: row_first + j -- and handed round through LDS.  (Drawn by the first lane of each run of lanes sharing a row,
+        // the Philox block and the Box-Muller ran once per WAVE with one lane alive: ~220 issue slots of the ~720 a dark quad costs.)
         float row_noise = 0.f;
         if (use_r && extras) {
-            const int64_t prev = __shfl_up(row, 1);
-            const bool leader = (lane == 0) || (prev != row);
-            float n = 0.f;
-            if (leader) {
-                const uint4 r = philox4x32_10((uint32_t)(c * H + h), ctx.crop, 0x40000000u, off, k0, k1);
-                n = box_muller(r.x, r.y);
+            const uint32_t tb = blockIdx.x * blockDim.x + it * stride;
+            row_first = fd_div(tb < total ? tb : total - 1, dwq);
+            const uint32_t row_last = fd_div(tb + 255 < total ? tb + 255 : total - 1, dwq);
+            if (it) __syncthreads();
+            const uint32_t rj = row_first + threadIdx.x;
+            if (rj <= row_last) {
+                const uint32_t bcj = fd_div(rj, dH), bj = fd_div(bcj, dC);
+                const uint32_t chj = rj - bj * (uint32_t)C * (uint32_t)H;            // c * H + h
+                const uint4 r = philox4x32_10(chj, crop_base + bj, 0x40000000u, off, k0, k1);
+                float n0, n1;
+                box_muller2(r.x, r.y, n0, n1);
+                row_n[threadIdx.x] = n0;
             }
-            const unsigned long long leaders = __ballot(leader);
-            const unsigned long long upto = leaders & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-            const int src = 63 - __clzll(upto);
-            n = __shfl(n, src);
-            row_noise = __fdiv_rn(__fmul_rn(n, P[PNNP_P_SIGR]), mfm);
+            // (read back just before the stores, behind a barrier THERE: by then the drawing wave is long done and nobody waits for it)
         }
-        if (!live) continue;
-
+        // (lanes past the end stay in the loop -- the queues below are drained by ALL lanes of the wave -- on the last quad's inputs; they
+        //  neither queue nor store)
         const int nx = min(4, W - 4 * xq);
-        const int64_t base = row * W + 4 * xq;
+        const int64_t base = (int64_t)row * W + 4 * xq;
         float v[4];
         if (nx == 4 && ((((uintptr_t)(y + base)) & 15) == 0)) {
             const float4 q = *reinterpret_cast<const float4*>(y + base);
@@ -251,6 +291,86 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
             V[0] = b2.x; V[1] = b2.y; V[2] = b2.z; V[3] = b2.w;
         }
         if (!use_p) { box_muller2(b0.x, b0.y, shn[0], shn[1]); box_muller2(b0.z, b0.w, shn[2], shn[3]); }
+        // ---- Poisson counts of the quad.  Straight-line part: lam <= 0 -> 0; lam >= 10 -> PTRS round 0's quick acceptance.  Everything
+        // data-dependent -- the inversion loop of lam < 10, PTRS's logarithm test and its retries -- is queued and run by the wave on
+        // dense groups of 64 pixels: the 4 x 64 pixels a wave holds need 1 + 1 such passes on a mid-grey crop where running pixel i of
+        // all lanes under its own branches needed 4 x (1 + 1 + retries), each with a seventh or a tenth of the lanes alive.
+        float kp[4] = {0.f, 0.f, 0.f, 0.f};
+        unsigned queued = 0;
+        if (use_p) {
+            int n_big = 0, n_small = 0;                                     // wave-uniform
+            const bool wave_big = __builtin_amdgcn_ballot_w64(big) != 0;
+            // inversion pixels: through the queue when that saves passes (<= 128 of the wave's 256: 1 - 2 dense passes), in place
+            // otherwise (a dark crop: every pixel is one, the queue would only add its traffic to the same 4 passes)
+            int tot_small = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tot_small += __popcll(__builtin_amdgcn_ballot_w64(live && lam[i] > 0.f && lam[i] < 10.f));
+            const bool queue_small = tot_small <= 128;
+            if (!queue_small) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bool sm = live && lam[i] > 0.f && lam[i] < 10.f;
+                    const float ks = poisson_small(lam[i], u01(U[i]), sm);
+                    kp[i] = sm ? ks : 0.f;
+                }
+            }
+            if (wave_big || (queue_small && tot_small > 0)) {              // (a dark crop skips the queues altogether)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float l = lam[i];
+                const bool pos = live && l > 0.f;                           // (NaN: count 0, as the oracle's !(lam > 0))
+                const bool small0 = pos && l < 10.f, bigp = pos && !small0;
+                const bool small = small0 && queue_small;
+                bool q_big = false;
+                if (wave_big) {
+                    float kq;
+                    const bool acc = ptrs_quick(l, U[i], V[i], kq);
+                    kp[i] = (bigp && acc) ? kq : kp[i];
+                    q_big = bigp && !acc;
+                }
+                const uint64_t mb = __builtin_amdgcn_ballot_w64(q_big), ms = __builtin_amdgcn_ballot_w64(small);
+                const uint4 ent = make_uint4(__float_as_uint(l), U[i], V[i], e0 + i);
+                const uint32_t tag = (uint32_t)(i * 64 + lane) | ((uint32_t)b << 8);
+                if (q_big) {
+                    const int p = n_big + __builtin_amdgcn_mbcnt_hi((uint32_t)(mb >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mb, 0u));
+                    q_ent[p] = ent; q_tag[p] = tag;
+                }
+                if (small) {
+                    const int p = 255 - (n_small + __builtin_amdgcn_mbcnt_hi((uint32_t)(ms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ms, 0u)));
+                    q_ent[p] = ent; q_tag[p] = tag;
+                }
+                n_big += __popcll(mb); n_small += __popcll(ms);
+                queued |= (unsigned)(q_big || small) << i;
+            }
+            if (n_big | n_small) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (int j0 = 0; j0 < n_big; j0 += 64) {
+                    const int j = j0 + lane;
+                    if (j < n_big) {
+                        const uint4 e = q_ent[j];
+                        const uint32_t tg = q_tag[j];
+                        const Ctx cj{k0, k1, crop_base + (tg >> 8), off};
+                        q_res[tg & 255u] = poisson_ptrs(__uint_as_float(e.x), e.w, cj, e.y, e.z);
+                    }
+                }
+                for (int j0 = 0; j0 < n_small; j0 += 64) {
+                    const int j = j0 + lane;
+                    const bool take = j < n_small;
+                    const uint4 e = q_ent[255 - (take ? j : 0)];
+                    const uint32_t tg = q_tag[255 - (take ? j : 0)];
+                    const float k = poisson_small(__uint_as_float(e.x), u01(e.y), take);
+                    if (take) q_res[tg & 255u] = k;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((queued >> i) & 1u) kp[i] = q_res[i * 64 + lane];
+                __builtin_amdgcn_wave_barrier();                            // (the next iteration's pushes come after these reads)
+            }
+            }
+        }
         if (!use_b) {
             const uint4 b1 = philox4x32_10(e0, ctx.crop, 1u, off, k0, k1);
             if (use_g) {
@@ -266,13 +386,16 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
             const uint4 b3 = philox4x32_10(e0, ctx.crop, 3u, off, k0, k1);
             Q[0] = b3.x; Q[1] = b3.y; Q[2] = b3.z; Q[3] = b3.w;
         }
+        if (use_r && extras) {
+            __syncthreads();
+            row_noise = __fdiv_rn(__fmul_rn(row_n[row - row_first], P[PNNP_P_SIGR]), mfm);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint32_t elem = e0 + i;
             const float yy = yv[i];
             float shot;
             if (use_p) {
-                shot = fast_div(__fmul_rn(poisson_f32(lam[i], elem, ctx, U[i], V[i]), K), mfm);
+                shot = fast_div(__fmul_rn(kp[i], K), mfm);
             } else {
                 const float s = fast_sqrt(fmaxf(fast_div(yy, K), 1e-10f));
                 shot = __fadd_rn(yy, fast_div(__fmul_rn(__fmul_rn(shn[i], s), K), mfm));
@@ -292,6 +415,7 @@ noise_sample_kernel(const float* __restrict__ y, float* __restrict__ out, int B,
             if (flags & PNNP_NOISE_POST_MAX1) z = fminf(z, 1.f);
             o[i] = z;
         }
+        if (!live) continue;
         if (nx == 4 && ((((uintptr_t)(out + base)) & 15) == 0)) {
             *reinterpret_cast<float4*>(out + base) = make_float4(o[0], o[1], o[2], o[3]);
         } else {
@@ -394,16 +518,31 @@ extern "C" int pnnp_noise_sample_f32(const float* y, float* out, int B, int C, i
     if (!y || !out || !params || B < 0 || C < 0 || H < 0 || W < 0 || !(mfm > 0.f)) return PNNP_E_INVALID;
     if ((flags & PNNP_NOISE_MODE_TORCH) && (flags & PNNP_NOISE_G) && !(flags & PNNP_NOISE_TORCH_TUKEY)) return PNNP_E_UNSUPPORTED;   // process.py:654
     if ((flags & PNNP_NOISE_MODE_TORCH) && !(flags & PNNP_NOISE_P)) return PNNP_E_UNSUPPORTED;  // process.py:651
-    if ((int64_t)C * H * W >= (1ll << 32)) return PNNP_E_INVALID;
-    const int64_t total = (int64_t)B * C * H * ((W + 3) / 4);
-    if (total == 0) return PNNP_OK;
-    int64_t blocks = (total + 255) / 256;
+    if ((int64_t)C * H * W >= (1ll << 32) || B >= (1 << 24)) return PNNP_E_INVALID;     // (element counter 32 bits; crop index 24 bits in the queue tag)
+    const int64_t per_crop = (int64_t)C * H * ((W + 3) / 4);
+    if ((int64_t)B * per_crop == 0) return PNNP_OK;
+    if (per_crop >= (1ll << 31)) return PNNP_E_INVALID;
+    auto fastdiv = [](uint32_t d) {
+        uint32_t l = 0;
+        while ((1ull << l) < d) ++l;
+        const uint64_t m = (((unsigned __int128)1 << (32 + l)) + d - 1) / d - (1ull << 32);
+        return FastDiv{(uint32_t)m, l, d};
+    };
+    const FastDiv dwq = fastdiv((uint32_t)((W + 3) / 4)), dH = fastdiv((uint32_t)H), dC = fastdiv((uint32_t)C);
 #ifndef NS_BLOCKS_PER_CU
 #define NS_BLOCKS_PER_CU 64      // short blocks, scheduled dynamically: a wave's time varies with its pixels' Poisson paths (measured 5 .. 64: 358 -> 196 us)
 #endif
-    if (blocks > pnnp_device_cus() * NS_BLOCKS_PER_CU) blocks = pnnp_device_cus() * NS_BLOCKS_PER_CU;
     const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
-    hipLaunchKernelGGL(noise_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
-                       y, out, B, C, H, W, params, flags, mfm, k0, k1, (uint32_t)offset, crop_base);
+    const int Bmax = (int)(((1ll << 31) - 1) / per_crop);                          // crops per launch: the kernel's index is 31 bits
+    for (int b0 = 0; b0 < B; b0 += Bmax) {
+        const int Bl = B - b0 < Bmax ? B - b0 : Bmax;
+        const int64_t total = (int64_t)Bl * per_crop;
+        int64_t blocks = (total + 255) / 256;
+        if (blocks > pnnp_device_cus() * NS_BLOCKS_PER_CU) blocks = pnnp_device_cus() * NS_BLOCKS_PER_CU;
+        const int64_t eoff = (int64_t)b0 * C * H * W;
+        hipLaunchKernelGGL(noise_sample_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream),
+                           y + eoff, out + eoff, Bl, C, H, W, params + (int64_t)b0 * PNNP_NPARAM, flags, mfm, k0, k1, (uint32_t)offset,
+                           crop_base + (uint32_t)b0, dwq, dH, dC);
+    }
     return pnnp_launch_status();
 }
