@@ -75,6 +75,36 @@ def test_determinism_and_counter_semantics():
     assert np.array_equal(np.concatenate([lo, hi]), a)
 
 
+def test_grid_stride_second_trip_and_ragged_geometry():
+    """The kernel's index arithmetic is 32-bit multiply-shift division (csrc/noise.hip FastDiv) and its row-noise normals are drawn per
+    BLOCK and re-drawn in every trip of the grid-stride loop.  (a) 20 crops of 4x512x512 are more quads than the capped grid holds (second
+    trip): the whole batch must equal its two halves sampled separately with crop_base -- which run one trip each.  (b) odd sizes (W % 4 != 0,
+    C = 3, rows shorter than a wave, a single row) against the C oracle at tier A's bar."""
+    from oracle import cbind
+    from pnnp_amd import process as P
+    g = torch.Generator(device='cuda').manual_seed(3)
+    y = torch.rand(20, 4, 512, 512, device='cuda', generator=g) * 0.3
+    rows = P.pack_params([SONY] * 20, y.device)
+    f = P.noise_flags('prq', torch_mode=True)
+    whole = P.noise_sample(y, rows, f, seed=5, offset=11)
+    lo = P.noise_sample(y[:10], rows[:10], f, seed=5, offset=11, crop_base=0)
+    hi = P.noise_sample(y[10:], rows[10:], f, seed=5, offset=11, crop_base=10)
+    assert torch.equal(whole, torch.cat([lo, hi]))
+    rng = np.random.default_rng(9)
+    for B, C, H, W in ((7, 3, 5, 37), (2, 4, 1, 1030), (1, 1, 300, 6), (3, 4, 33, 4)):
+        yy = (rng.random((B, C, H, W), dtype=np.float32) ** 2).astype(np.float32)
+        plist = [dict(SONY, ratio=100.0 + 50 * b) for b in range(B)]
+        for code in ('pr', 'prq'):
+            fl = P.noise_flags(code, torch_mode=True)
+            ref = cbind.noise_sample(yy, cbind.param_rows(plist), fl, mfm=1.0, seed=1997, offset=3, crop_base=2)
+            got = _hip(yy, plist, fl, crop_base=2)
+            for b, pp in enumerate(plist):
+                scale = pp['ratio'] / (pp['wp'] - pp['bl'])
+                d = np.abs(got[b] - ref[b])
+                frac = float((d <= 1e-5 * np.maximum(np.abs(ref[b]), scale)).mean())
+                assert frac >= 0.995, ((B, C, H, W), code, b, frac)       # (small maps: one flipped pixel of 555 is already 0.2 %)
+
+
 def test_row_noise_structure():
     """'r': one draw per (packed channel, row), constant along W, independent across
     channels, rows and crops (process.py:615,660)."""
