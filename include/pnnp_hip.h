@@ -241,6 +241,25 @@ int pnnp_conv3x3_h2_bwd_weight_f32(const float* g, int g_cs, int Cout, const uns
 int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
                                      float* dx, int C1, const float* addsrc, const float* mask, int mode, unsigned* amax_dx,
                                      int B, int H, int W, void* stream);
+/* The same pointwise layers on the fp16 matrix cores (csrc/gemm_h2s.hip; round 5): the fp16x2 scheme of the 3x3 kernels (csrc/h2.h) -- per-tensor
+ * power-of-two scale from 4-byte amax slots, two fp16 pieces per operand, three products per multiply instead of bf16x3's six.  Contracts of the
+ * _x3_ entries below + the slots: amax_x / amax_g of the tensor that is split on the fly, amax_w of the weight tensor (the kind-6 packs of
+ * pnnp_pack_jobs_add_h2_convt / _1x1 were scaled with it; pnnp_h2mat_bytes(K, N) bytes), amax_y / amax_dx (or null) raised to max |stored|.
+ * K (channels per segment) % 32 == 0, N (GEMM columns: 4 Cout for ConvTranspose2d forward) % 64 == 0: pnnp_gemm_h2_supported. */
+int pnnp_gemm_h2_supported(int K, int N);
+int64_t pnnp_h2mat_bytes(int K, int N);
+int pnnp_pack_jobs_add_h2_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cin, int Cout, const unsigned* amax);
+int pnnp_pack_jobs_add_h2_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cout, int Cin, const unsigned* amax);
+int pnnp_convt2x2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, const void* w_h2, const unsigned* amax_w, const float* bias /*or null*/, float* y,
+                             unsigned* amax_y /*or null*/, int B, int H, int W, int Cout, void* stream);
+int pnnp_convt2x2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                  const float* mask /*or null*/, int mode, unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
+int pnnp_conv1x1_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2, const void* w_h2,
+                            const unsigned* amax_w, const float* bias /*or null*/, const float* residual /*or null*/, float* y, unsigned* amax_y /*or null*/,
+                            int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv1x1_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                 float* dx1, int C1, const float* mask1, int mode1, int accum1, unsigned* amax_dx1 /*or null*/,
+                                 float* dx2 /*or null*/, int C2, const float* mask2, int mode2, int accum2, int B, int H, int W, void* stream);
 /* pointwise layers on the bf16 matrix cores (csrc/gemm_x3.hip): ConvTranspose2d k2 s2 (archs/Unet.py:35-47), Conv2d 1x1 (ResidualBlock
  * shortcuts, archs/modules.py:176-197), Conv2d 3x3 stride 2 (archs/modules.py:130-138); same contracts as pnnp_convt2x2_* /
  * pnnp_conv_fwd_f32 + pnnp_conv_bwd_data_f32 with taps = 1 / pnnp_conv3x3s2_*; channel counts in multiples of 32; the weights are

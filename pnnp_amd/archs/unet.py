@@ -40,9 +40,10 @@ class ConvPolicy:
         # bf16x3 family passes at the same bars (tests/test_gpu_h2.py, tests/test_gpu_fullsize.py); ``set_policy(h2=False)`` = the bf16x3 family.
         self.h2 = bool(h2)
         self.h2_wgrad = bool(h2) and os.environ.get('PNNP_H2_WGRAD', '1') != '0'      # (host-side A/B switch: backward-weight stays on bf16x3 with 0)
+        self.h2_pointwise = bool(h2) and os.environ.get('PNNP_H2_POINTWISE', '1') != '0'      # (A/B switch: ConvTranspose2d stays on bf16x3 with 0)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -272,6 +273,7 @@ class UNetEngine(_EngineBase):
         jobs = ops.PackJobs()
         self._x3, self._wn = {}, {}            # per layer: (forward, backward-data) on the bf16x3 / Winograd kernel
         self._h2, self._wslot = {}, {}         # per layer: (forward, backward-data) fp16x2 packs; the weight tensor's amax slot
+        self._h2m = {}                         # ConvTranspose2d layers on the fp16x2 GEMM kernel: (forward, backward-data) kind-6 packs
         def buf(key, n, dt=torch.float32):
             if key not in self.packed:
                 self.packed[key] = torch.empty(n, dtype=dt, device=dev)
@@ -310,6 +312,13 @@ class UNetEngine(_EngineBase):
         for name in ('upv6', 'upv7', 'upv8', 'upv9'):
             w = P[name + '.weight']
             ci, co = w.shape[0], w.shape[1]
+            if (self._pol.h2 and self._pol.h2_pointwise and self._pol.use_x3_pointwise(ci, 4 * co) and self._pol.use_x3_pointwise(co, ci)
+                    and ops.gemm_h2_supported(ci, 4 * co) and ops.gemm_h2_supported(co, ci)):
+                self._x3[name] = (False, False)                    # ConvTranspose2d on the pointwise fp16x2 GEMM kernel (csrc/gemm_h2s.hip)
+                self._h2m[name] = (buf((name, dev, 'h2mf'), ops.h2mat_bytes(ci, 4 * co), torch.uint8),
+                                   buf((name, dev, 'h2md'), ops.h2mat_bytes(4 * co, ci), torch.uint8) if need_dgrad else None)
+                self._wslot[name] = jobs.add_h2_convt(w, self._h2m[name][0], self._h2m[name][1])
+                continue
             if self._pol.use_x3_pointwise(ci, 4 * co) and self._pol.use_x3_pointwise(co, ci):
                 self._x3[name] = (True, True)                      # ConvTranspose2d on the pointwise bf16x3 GEMM kernel
                 jobs.add_x3_convt(w, buf((name, dev, 'x3f'), ops.x3mat_bytes(ci, 4 * co), torch.uint8),
@@ -468,7 +477,11 @@ class UNetEngine(_EngineBase):
         cur = a['c5']
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
             lvl = 9 - i
-            if self._x3.get(f'upv{i}', (False, False))[0]:
+            if f'upv{i}' in self._h2m:
+                u = ops.convt_h2_fwd(cur, sl(src_name[id(cur)]), self._h2m[f'upv{i}'][0], self._wslot[f'upv{i}'], P[f'upv{i}.bias'],
+                                     g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl], amax_y=sl(f'upv{i}'))
+                a[f'u{i}'] = produced(u, f'upv{i}', fused=True)
+            elif self._x3.get(f'upv{i}', (False, False))[0]:
                 u = ops.convt_x3_fwd(cur, self._wx(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl],
                                      amax_y=sl(f'upv{i}') if h2_on else None)
                 a[f'u{i}'] = produced(u, f'upv{i}', fused=True)
@@ -603,7 +616,11 @@ class UNetEngine(_EngineBase):
             ct_wgrad(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc, dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
-            if self._x3.get(f'upv{i}', (False, False))[1]:
+            if f'upv{i}' in self._h2m and id(g_u) in gname:
+                ops.convt_h2_bwd_data(g_u, gslot(g_u), self._h2m[f'upv{i}'][1], self._wslot[f'upv{i}'], g_cur, mask=below, mode=LRELU,
+                                      amax_dx=bufs.slot('b', f'upv{i}', dev))
+                gproduced(g_cur, f'upv{i}', fused=True)
+            elif self._x3.get(f'upv{i}', (False, False))[1]:
                 ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU, amax_dx=bufs.slot('b', f'upv{i}', dev) if h2_on else None)
                 gproduced(g_cur, f'upv{i}', fused=True)
             else:

@@ -6,6 +6,8 @@
 int pnnp_igemm_launch(const IgemmArgs& a, int taps, int chan_per_seg, hipStream_t s);
 int pnnp_igemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);       // csrc/conv_x3.hip (3x3, bf16x3 split)
 int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);        // csrc/gemm_x3.hip (one tap per K segment, bf16x3 split)
+int pnnp_gemm_x3_check(const IgemmArgs& a, int chan_per_seg);                        // its argument validation alone
+int pnnp_gemm_h2s_launch(const H2Args& a, hipStream_t s);                             // csrc/gemm_h2s.hip (the same GEMMs on the fp16x2 scheme)
 
 namespace {
 
@@ -373,6 +375,60 @@ int pnnp_conv3x3s2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_
         slice += ns;
     }
     return PNNP_OK;
+}
+
+// ---------------------------------------------------------------- pointwise layers on the fp16 matrix cores (csrc/gemm_h2s.hip, csrc/h2.h)
+// Contracts of the _x3_ entries above + the amax slots of the fp16x2 family; weights: the kind-6 packs of pnnp_pack_jobs_add_h2_convt / _1x1.
+// K (channels of a segment) in multiples of 32, N (GEMM columns: 4 Cout for ConvTranspose2d forward) in multiples of 64.
+int pnnp_gemm_h2_supported(int K, int N) { return (K > 0 && N > 0 && K % 32 == 0 && N % 64 == 0) ? 1 : 0; }
+namespace {
+int gemm_h2_go(H2Args& h, int chan_per_seg, hipStream_t st) {
+    const int rc = pnnp_gemm_x3_check(h.g, chan_per_seg);
+    if (rc != PNNP_OK) return rc;
+    if (!pnnp_gemm_h2_supported(chan_per_seg, h.g.Ntot)) return PNNP_E_UNSUPPORTED;
+    h.g.seg_channels = chan_per_seg;
+    h.g.chunks_per_seg = chan_per_seg / 32;                         // csrc/gemm_h2s.hip walks K in 32-channel items
+    if ((int64_t)(h.g.Ntot / 32) * h.g.nseg * h.g.chunks_per_seg * 4096 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    return pnnp_gemm_h2s_launch(h, st);
+}
+}  // namespace
+int pnnp_convt2x2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, const void* w_h2, const unsigned* amax_w, const float* bias, float* y,
+                             unsigned* amax_y, int B, int H, int W, int Cout, void* stream) {
+    if (!x || !w_h2 || !y || !amax_x || !amax_w || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    convt_fwd_args(h.g, x, Cin, w_h2, bias, y, B, H, W, Cout);
+    h.g.amax_out[0] = amax_y; h.amax_in[0] = amax_x; h.amax_w = amax_w;
+    return gemm_h2_go(h, Cin, as_stream(stream));
+}
+int pnnp_convt2x2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                  const float* mask, int mode, unsigned* amax_dx, int B, int H, int W, void* stream) {
+    if (!g || !w_h2_dgrad || !dx || !amax_g || !amax_w || B < 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    convt_bwd_args(h.g, g, Cout, w_h2_dgrad, dx, Cin, mask, mode, B, H, W);
+    h.g.amax_out[0] = amax_dx; h.amax_in[0] = amax_g; h.amax_w = amax_w;
+    return gemm_h2_go(h, Cout, as_stream(stream));
+}
+int pnnp_conv1x1_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2, const void* w_h2,
+                            const unsigned* amax_w, const float* bias, const float* residual, float* y, unsigned* amax_y,
+                            int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_h2 || !y || !amax_x1 || !amax_w || (x2 && !amax_x2) || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    fwd_args(h.g, x1, C1, x2, C2, w_h2, bias, residual, y, B, H, W, Cout, act);
+    h.g.amax_out[0] = amax_y; h.amax_in[0] = amax_x1; h.amax_in[1] = x2 ? amax_x2 : nullptr; h.amax_w = amax_w;
+    return gemm_h2_go(h, C1, as_stream(stream));
+}
+int pnnp_conv1x1_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w,
+                                 float* dx1, int C1, const float* mask1, int mode1, int accum1, unsigned* amax_dx1,
+                                 float* dx2, int C2, const float* mask2, int mode2, int accum2, int B, int H, int W, void* stream) {
+    if (!g || !w_h2_dgrad || !dx1 || !amax_g || !amax_w || B < 0 || H <= 0 || W <= 0 || Cout <= 0 || C1 <= 0) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    bwd_args(h.g, g, Cout, w_h2_dgrad, dx1, C1, mask1, mode1, accum1, dx2, C2, mask2, mode2, accum2, B, H, W);
+    h.g.amax_out[0] = amax_dx1; h.amax_in[0] = amax_g; h.amax_w = amax_w;
+    return gemm_h2_go(h, Cout, as_stream(stream));
 }
 
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47

@@ -445,12 +445,18 @@ igemm_h2s_kernel(const H2Args ha) {
             const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             return f32x4{__builtin_fmaf(v.x, dsc, bias.x), __builtin_fmaf(v.y, dsc, bias.y), __builtin_fmaf(v.z, dsc, bias.z), __builtin_fmaf(v.w, dsc, bias.w)};
         };
-        // max |.| of a stored block into the lane's running maximum of destination du (uniform); lanes whose store is dropped do not count
-        auto track = [&](f32x4 o, bool valid, int du) {
-            const float cur_ = du ? amx1 : amx0;
-            const float m = fmaxf(fmaxf(fmaxf(cur_, fabsf(o.x)), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
-            const float mv = valid ? m : cur_;
-            if (du) amx1 = mv; else amx0 = mv;
+        // max |.| of the blocks of one destination: a running maximum per 32-column block (two v_max3_f32 per float4), merged into the lane's
+        // maximum of that destination once per block.  Lanes whose store is dropped (pixels / columns outside the tensor) count too: what
+        // they hold are finite sums over zero padding, and an amax slot may over-estimate (csrc/h2.h) -- masking them was a compare and
+        // two selects per float4.
+        float amk = 0.f;
+        auto track = [&](f32x4 o) {
+            amk = fmaxf(fmaxf(amk, fabsf(o.x)), fabsf(o.y));
+            amk = fmaxf(fmaxf(amk, fabsf(o.z)), fabsf(o.w));
+        };
+        auto track_done = [&](int du) {
+            if (du) amx1 = fmaxf(amx1, amk); else amx0 = fmaxf(amx0, amk);
+            amk = 0.f;
         };
         // Sign bits: element n = ((i 2 + h) 2 + jj) 4 + c of a 32-column block sits at bit 31 - n of the lane's word -- the order in which the
         // forward epilogue produces the values, so that it can SHIFT them in (sb = 2 sb + (o > 0): a compare and an add-with-carry per element) and
@@ -536,7 +542,7 @@ igemm_h2s_kernel(const H2Args ha) {
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
                             wn[jj][i] = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj]);
-                            track(wn[jj][i], blk_[k] && okp[i][h], 0);
+                            track(wn[jj][i]);
                             sb |= signs4(wn[jj][i], ((i * 2 + h) * 2 + jj) * 4);
                         }
 #pragma unroll
@@ -581,6 +587,7 @@ igemm_h2s_kernel(const H2Args ha) {
                     }
                 }
                 __builtin_amdgcn_raw_buffer_store_b32(sb, rb, (ea.bits_out && blk_[k]) ? bits_off(k, ea.nblk0) : OOB, 0, 0);
+                track_done(0);
             }
             return;
         }
@@ -647,7 +654,7 @@ igemm_h2s_kernel(const H2Args ha) {
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { float e = o1[c]; mask_bit(e, mbits[k], msl); o1[c] = e; }
                             }
-                            track(o0, blk_[k] && okp[i][h], du_[k]); track(o1, blk_[k] && okp[i][h], du_[k]);
+                            track(o0); track(o1);
                             trade(o0, o1);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rd, wo[k][i][h], 0, H2S_STORE_AUX);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
@@ -656,6 +663,7 @@ igemm_h2s_kernel(const H2Args ha) {
                         const __amdgpu_buffer_rsrc_t rb = bits_rsrc(ea.bits_out, ea.nblk0);
                         __builtin_amdgcn_raw_buffer_store_b32(sb, rb, (ea.bits_out && blk_[k] && !du_[k]) ? bits_off(k, ea.nblk0) : OOB, 0, 0);
                     }
+                    track_done(du_[k]);
                 }
             };
             // one wave-uniform branch per tile: with / without an activation (backward-data never has one: the launcher sends a masked layer
@@ -694,10 +702,11 @@ igemm_h2s_kernel(const H2Args ha) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c) o[c] = m2[i][h][c] > 0.f ? o[c] : t[c];
                         o += pr2[i][h];
-                        track(o, vo[k][i][h] != OOB, du);
+                        track(o);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
                     }
             }
+            track_done(du);
         }
     };
 

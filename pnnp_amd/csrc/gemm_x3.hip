@@ -4,12 +4,13 @@
 #include "igemm.h"
 
 int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s);
+int pnnp_gemm_x3_check(const IgemmArgs& a, int chan_per_seg);        // the validation alone (csrc/conv_api.hip: the fp16x2 entries share it)
 int pnnp_gemm_x3s_launch(const IgemmArgs& a, hipStream_t s);        // csrc/gemm_x3s.hip
 
 namespace { constexpr int WBLK = 2 * 3 * 32 * 16; }                 // one 16-channel k-step of one 32-column block: [octet 2][piece 3][32][16 B] = 3072
 
 // a.w: x3 pack with ONE tap: [N/32][K/16][octet 2][piece 3][32][8 bf16].  chan_per_seg: channels per K segment, a multiple of 32.
-int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
+int pnnp_gemm_x3_check(const IgemmArgs& a, int chan_per_seg) {
     if (a.nseg < 1 || a.nseg > 9 || chan_per_seg <= 0 || (chan_per_seg & 31) || a.Ntot <= 0) return PNNP_E_INVALID;
     if ((a.Ntot & 31) || a.in_mul < 1 || a.in_mul > 2 || (a.n_sub & 31) || (a.dst[1] && (a.n_split & 31))) return PNNP_E_UNSUPPORTED;
     if (a.addsrc && a.accum[0]) return PNNP_E_UNSUPPORTED;
@@ -22,6 +23,11 @@ int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
     }
     for (int d = 0; d < 2; ++d)
         if (a.dst[d] && (int64_t)a.OH * a.OW * a.dst_cs[d] * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+    return PNNP_OK;
+}
+int pnnp_gemm_x3_launch(const IgemmArgs& a, int chan_per_seg, hipStream_t s) {
+    const int rc = pnnp_gemm_x3_check(a, chan_per_seg);
+    if (rc != PNNP_OK) return rc;
     IgemmArgs b = a;
     b.seg_channels = chan_per_seg;
     const int64_t wbytes = (int64_t)(a.Ntot / 32) * b.nseg * (chan_per_seg / 16) * WBLK;

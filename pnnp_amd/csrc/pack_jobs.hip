@@ -135,6 +135,29 @@ __device__ __forceinline__ void x3mat_job(const PnnpPackJob& j, int64_t blk, int
     }
 }
 
+// fp16x2 pack of a K x N weight matrix for csrc/gemm_h2s.hip:  dst (fp16) [Ntot/32][K32tot][piece 2: hi', lo'][octet 4][32][8]  (4096 bytes per
+//   32-channel item and 32-column block); sub-matrix addressing exactly as x3mat_job (K32tot = field T); W s with s = 2^pnnp_h2_scale_exp(*amax)
+//   of the WHOLE weight tensor (a kind-5 job), hi' = f16(W s), lo' = f16(W s - hi').  Rows / columns no job covers: zero-filled by the caller.
+__device__ __forceinline__ void h2mat_job(const PnnpPackJob& j, int64_t blk, int nblk) {
+    const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
+    const int K = j.K, N = j.N, K32 = j.T, k_off = (int)j.st;
+    const float s = __uint_as_float((unsigned)(pnnp_h2_scale_exp(j.amax[0]) + 127) << 23);
+    const int64_t total = (int64_t)K * N;
+    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
+        const int kr = (int)(t & 7);                               // 8 consecutive k of one column: one 16-byte word per piece
+        int64_t r = t >> 3;
+        const int n = (int)(r % N);
+        const int k = (int)(r / N) * 8 + kr;
+        if (k >= K) continue;
+        const float vs = w[j.off + (int64_t)k * j.sk + (int64_t)n * j.sn] * s;
+        const _Float16 h = (_Float16)vs;
+        const _Float16 l = (_Float16)(vs - (float)h);
+        const int kk = k_off + k, nn = j.n_off + n;
+        unsigned short* o = u + ((int64_t)(nn >> 5) * K32 + (kk >> 5)) * 2048 + ((kk >> 3) & 3) * 256 + (nn & 31) * 8 + (kk & 7);
+        o[0] = __builtin_bit_cast(unsigned short, h); o[1024] = __builtin_bit_cast(unsigned short, l);
+    }
+}
+
 // fp16x2 pack of a 3x3 Conv2d weight for csrc/conv_h2s.hip:  dst (fp16) [N/32][K16] x { hi' [tap 9][octet 2][32][8], lo' [tap 10][octet 2][32][8] }
 //   (the tenth lo' tap is ZERO: the partner of the unpaired ninth tap; 19456 bytes per 32-column block and chunk)
 //   element (k, n, tap) as in x3_job;  W s with s = 2^pnnp_h2_scale_exp(*amax) (amax >= max |w|: a kind-5 job), hi' = f16(W s), lo' = f16(W s - hi')
@@ -193,12 +216,13 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
     else if (job.kind == 3) x3mat_job(job, (int64_t)blockIdx.x - b0, nblk);
     else if (job.kind == 4) h2_job(job, (int64_t)blockIdx.x - b0, nblk);
     else if (job.kind == 5) amax_job(job, (int64_t)blockIdx.x - b0, nblk);
+    else if (job.kind == 6) h2mat_job(job, (int64_t)blockIdx.x - b0, nblk);
     else gather_job(job, (int64_t)blockIdx.x - b0, nblk);
 }
 
 int job_blocks(const PnnpPackJob& j) {
     if (j.kind == 5) { const int64_t b5 = (j.sk + 256 * 16 - 1) / (256 * 16); return (int)(b5 > 1024 ? 1024 : (b5 < 1 ? 1 : b5)); }
-    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : ((j.kind == 2 || j.kind == 4) ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (j.kind == 3 || j.kind == 6) ? (int64_t)((j.K + 7) / 8 * 8) * j.N : ((j.kind == 2 || j.kind == 4) ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
@@ -232,7 +256,7 @@ int pnnp_pack_jobs_f32(const PnnpPackJob* jobs, int n, void* stream) {
         for (int i = 0; i < tb.n; ++i) {
             const PnnpPackJob& j = jobs[i0 + i];
             if (j.kind == 5) { if (!j.src || !j.dst || j.sk < 0) return PNNP_E_INVALID; }
-            else if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 4 && (!j.amax || j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 3 && (j.T <= 0 || j.Ndst <= 0 || (j.K & 7)))       /* kind 3 enumerates whole 8-row groups */) return PNNP_E_INVALID;
+            else if (!j.src || !j.dst || j.K <= 0 || j.N <= 0 || (j.kind == 4 && (!j.amax || j.Kvalid <= 0 || (j.Kvalid & 15))) || (j.kind == 0 && (j.T <= 0 || (j.K & 3))) || (j.kind == 2 && (j.Kvalid <= 0 || (j.Kvalid & 15))) || ((j.kind == 3 || j.kind == 6) && (j.T <= 0 || j.Ndst <= 0 || (j.K & 7))) || (j.kind == 6 && !j.amax)       /* kind 3 enumerates whole 8-row groups */) return PNNP_E_INVALID;
             tb.job[i] = j;
             blocks += job_blocks(j);
             tb.blk_end[i] = blocks;
@@ -376,6 +400,24 @@ int pnnp_pack_jobs_add_x3_s2(PnnpPackJob* jobs, int* n, int cap, const float* w,
     return ok ? PNNP_OK : PNNP_E_WORKSPACE;
 }
 int64_t pnnp_x3mat_bytes(int K, int N) { return (int64_t)K * N * 6; }
+// fp16x2 packs for csrc/gemm_h2s.hip: the same sub-matrix jobs as the x3 builders above in the kind-6 layout (32-channel items: 4 bytes per
+// weight), scaled with the weight tensor's amax slot.  Sizes: pnnp_h2mat_bytes(K, N).  Channel counts in multiples of 32.
+int pnnp_pack_jobs_add_h2_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cin, int Cout, const unsigned* amax) {
+    if (!jobs || !n || !w || !amax || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    const int n0 = *n;
+    const int rc = pnnp_pack_jobs_add_x3_convt(jobs, n, cap, w, fwd, dgrad, Cin, Cout);
+    for (int i = n0; i < *n; ++i) { jobs[i].kind = 6; jobs[i].T /= 2; jobs[i].amax = amax; }       // (T: 16-channel -> 32-channel items)
+    return rc;
+}
+int pnnp_pack_jobs_add_h2_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin, const unsigned* amax) {
+    if (!jobs || !n || !w || !amax || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    const int n0 = *n;
+    const int rc = pnnp_pack_jobs_add_x3_1x1(jobs, n, cap, w, fwd, dgrad, Cout, Cin);
+    for (int i = n0; i < *n; ++i) { jobs[i].kind = 6; jobs[i].T /= 2; jobs[i].amax = amax; }
+    return rc;
+}
+int64_t pnnp_h2mat_bytes(int K, int N) { return (int64_t)K * N * 4; }
+
 
 // bytes of one x3 pack: K (reduction channels, rounded up to 16) x N (channels written, rounded up to 32) x 9 taps x 3 pieces x 2 B
 int64_t pnnp_x3_weight_bytes(int K, int N) { return (int64_t)((K + 15) / 16 * 16) * ((N + 31) / 32 * 32) * 9 * 6; }

@@ -43,6 +43,7 @@ def _prep():
         L.pnnp_x3mat_bytes.restype = C.c_int64
         L.pnnp_h2_weight_bytes.restype = C.c_int64
         L.pnnp_h2_bits_words.restype = C.c_int64
+        L.pnnp_h2mat_bytes.restype = C.c_int64
         L.pnnp_head_bwd_workspace_floats.restype = C.c_int64
         L.pnnp_first_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
@@ -122,6 +123,22 @@ class PackJobs:
         slot = self.weight_slot(w)
         check(_prep().pnnp_pack_jobs_add_h2(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci,
                                             cin_pad or (ci + 15) // 16 * 16, ptr(slot)), 'pack_jobs_add_h2')
+        self.keep += [w, fwd, dgrad]
+        return slot
+
+    def add_h2_convt(self, w, fwd, dgrad):
+        """fp16x2 packs (csrc/gemm_h2s.hip) of a ConvTranspose2d(2, 2) weight; fwd / dgrad: uint8 buffers of h2mat_bytes (zero-filled), or None.
+        Returns the weight tensor's amax slot."""
+        ci, co = w.shape[0], w.shape[1]
+        slot = self.weight_slot(w)
+        check(_prep().pnnp_pack_jobs_add_h2_convt(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), ci, co, ptr(slot)), 'pack_jobs_add_h2_convt')
+        self.keep += [w, fwd, dgrad]
+        return slot
+
+    def add_h2_1x1(self, w, fwd, dgrad):
+        co, ci = w.shape[0], w.shape[1]
+        slot = self.weight_slot(w)
+        check(_prep().pnnp_pack_jobs_add_h2_1x1(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci, ptr(slot)), 'pack_jobs_add_h2_1x1')
         self.keep += [w, fwd, dgrad]
         return slot
 
@@ -321,6 +338,31 @@ def convt_x3_bwd_data(g, w_x3_dgrad, dx, mask=None, mode=0, amax_dx=None):
     with _Timed('convt_dgrad_x3', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
         check(_prep().pnnp_convt2x2_x3_bwd_data_amax_f32(ptr(g), g.shape[3], ptr(w_x3_dgrad), ptr(dx), Cin, ptr(mask), mode, ptr(amax_dx), B, H, W, stream()),
               'convt_x3_bwd_data')
+
+
+def gemm_h2_supported(K, N):
+    return bool(_prep().pnnp_gemm_h2_supported(int(K), int(N)))
+
+
+def h2mat_bytes(K, N):
+    return int(_prep().pnnp_h2mat_bytes(int(K), int(N)))
+
+
+def convt_h2_fwd(x, amax_x, w_h2, amax_w, bias, y, cout, amax_y=None):
+    """ConvTranspose2d(2, 2) forward on the fp16 matrix cores (csrc/gemm_h2s.hip): contract of convt_x3_fwd + the amax slots."""
+    require_cuda(x, w_h2, y, amax_x, amax_w)
+    B, H, W, Cin = x.shape
+    with _Timed('convt_fwd_h2', 8.0 * B * H * W * Cin * cout, 4.0 * B * H * W * (Cin + 4 * cout)):
+        check(_prep().pnnp_convt2x2_h2_fwd_f32(ptr(x), Cin, ptr(amax_x), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y), ptr(amax_y), B, H, W, cout, stream()), 'convt_h2_fwd')
+    return y
+
+
+def convt_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx, mask=None, mode=0, amax_dx=None):
+    require_cuda(g, w_h2_dgrad, dx, amax_g, amax_w)
+    B, H, W, Cin = dx.shape
+    with _Timed('convt_dgrad_h2', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_h2_bwd_data_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), Cin, ptr(mask), mode, ptr(amax_dx),
+                                                    B, H, W, stream()), 'convt_h2_bwd_data')
 
 
 def conv1x1_x3_fwd(x1, x2, w_x3, bias, y, cout, act, residual=None):
