@@ -244,12 +244,17 @@ int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* a
 /* The same pointwise layers on the fp16 matrix cores (csrc/gemm_h2s.hip; round 5): the fp16x2 scheme of the 3x3 kernels (csrc/h2.h) -- per-tensor
  * power-of-two scale from 4-byte amax slots, two fp16 pieces per operand, three products per multiply instead of bf16x3's six.  Contracts of the
  * _x3_ entries below + the slots: amax_x / amax_g of the tensor that is split on the fly, amax_w of the weight tensor (the kind-6 packs of
- * pnnp_pack_jobs_add_h2_convt / _1x1 were scaled with it; pnnp_h2mat_bytes(K, N) bytes), amax_y / amax_dx (or null) raised to max |stored|.
+ * pnnp_pack_jobs_add_h2_convt / _1x1 / _s2 were scaled with it; pnnp_h2mat_bytes(K, N) bytes), amax_y / amax_dx (or null) raised to max |stored|.
  * K (channels per segment) % 32 == 0, N (GEMM columns: 4 Cout for ConvTranspose2d forward) % 64 == 0: pnnp_gemm_h2_supported. */
 int pnnp_gemm_h2_supported(int K, int N);
 int64_t pnnp_h2mat_bytes(int K, int N);
 int pnnp_pack_jobs_add_h2_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cin, int Cout, const unsigned* amax);
 int pnnp_pack_jobs_add_h2_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cout, int Cin, const unsigned* amax);
+int pnnp_pack_jobs_add_h2_s2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null: 9 x pnnp_h2mat_bytes(Cout, Cin)*/, int Cout, int Cin, const unsigned* amax);
+int pnnp_conv3x3s2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, const void* w_h2, const unsigned* amax_w, const float* bias /*or null*/, float* y,
+                              unsigned* amax_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
+int pnnp_conv3x3s2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_s2dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                   const float* mask /*or null*/, int mode, int accum, unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
 int pnnp_convt2x2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, const void* w_h2, const unsigned* amax_w, const float* bias /*or null*/, float* y,
                              unsigned* amax_y /*or null*/, int B, int H, int W, int Cout, void* stream);
 int pnnp_convt2x2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,

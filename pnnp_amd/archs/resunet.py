@@ -77,6 +77,8 @@ class ResUnetEngine(_EngineBase):
         W = {}
         self.WU, self.WX = {}, {}
         self.WH, self.WS = {}, {}              # fp16x2 packs (forward, backward-data) per layer; the weight tensor's amax slot (csrc/h2.h)
+        self.WM = {}                           # pointwise / stride-2 / ConvTranspose2d layers on the fp16x2 GEMM kernel (csrc/gemm_h2s.hip): kind-6 packs
+        h2pw = self._pol.h2 and self._pol.h2_pointwise
         def conv(name, pname, cin_pad=None, cout_pad=None, dgrad=True, c1=None):
             w = P[pname]
             co, ci, kh, kw = w.shape
@@ -93,6 +95,12 @@ class ResUnetEngine(_EngineBase):
                 self.WS[name] = jobs.add_h2(w, self.WH[name][0], self.WH[name][1], cin_pad=(cip + 15) // 16 * 16)
                 xf, xd = xf and not hf, xd and not hd
             p1 = t == 1 and self._pol.use_x3_pointwise(ci, co) and self._pol.use_x3_pointwise(co, ci) and (c1 is None or c1 % 32 == 0)
+            if p1 and h2pw and ops.gemm_h2_supported(c1 if c1 else ci, co) and ops.gemm_h2_supported(co, ci):
+                mf = self._buf(name + ':h2mf', ops.h2mat_bytes(ci, co), dev, torch.uint8)
+                md = self._buf(name + ':h2md', ops.h2mat_bytes(co, ci), dev, torch.uint8) if bwd else None
+                self.WS[name] = jobs.add_h2_1x1(w, mf, md)
+                W[name] = (None, None); self.WU[name] = (None, None); self.WM[name] = (mf, md if bwd else mf)
+                return
             if p1:                                                     # 1x1 (ResidualBlock shortcut) on the pointwise bf16x3 kernel
                 x3f = self._buf(name + ':x3f', ops.x3mat_bytes(ci, co), dev, torch.uint8)
                 x3d = self._buf(name + ':x3d', ops.x3mat_bytes(co, ci), dev, torch.uint8) if bwd else None
@@ -126,6 +134,12 @@ class ResUnetEngine(_EngineBase):
         for l in range(1, 5):
             w = P[f'pool{l}.conv.weight']
             co, ci = w.shape[0], w.shape[1]
+            if h2pw and self._pol.use_x3_pointwise(ci, co) and ops.gemm_h2_supported(ci, co) and ops.gemm_h2_supported(co, ci):
+                f = self._buf(f'pool{l}:h2mf', ops.h2mat_bytes(9 * ci, co), dev, torch.uint8)
+                d = self._buf(f'pool{l}:h2md', 9 * ops.h2mat_bytes(co, ci), dev, torch.uint8) if train else None
+                self.WS[f'pool{l}'] = jobs.add_h2_s2(w, f, d)
+                self.WM[f'pool{l}'] = (f, d if train else f)
+                continue
             if self._pol.use_x3_pointwise(ci, co) and self._pol.use_x3_pointwise(co, ci):      # stride-2 conv on the pointwise bf16x3 kernel
                 f = self._buf(f'pool{l}:x3f', ops.x3mat_bytes(9 * ci, co), dev, torch.uint8)
                 d = self._buf(f'pool{l}:x3d', 9 * ops.x3mat_bytes(co, ci), dev, torch.uint8) if train else None
@@ -142,6 +156,12 @@ class ResUnetEngine(_EngineBase):
         for i in range(6, 10):
             w = P[f'upv{i}.weight']
             ci, co = w.shape[0], w.shape[1]
+            if h2pw and self._pol.use_x3_pointwise(ci, 4 * co) and ops.gemm_h2_supported(ci, 4 * co) and ops.gemm_h2_supported(co, ci):
+                f = self._buf(f'upv{i}:h2mf', ops.h2mat_bytes(ci, 4 * co), dev, torch.uint8)
+                d = self._buf(f'upv{i}:h2md', ops.h2mat_bytes(4 * co, ci), dev, torch.uint8) if train else None
+                self.WS[f'upv{i}'] = jobs.add_h2_convt(w, f, d)
+                self.WM[f'upv{i}'] = (f, d if train else f)
+                continue
             if self._pol.use_x3_pointwise(ci, 4 * co) and self._pol.use_x3_pointwise(co, ci):
                 f = self._buf(f'upv{i}:x3f', ops.x3mat_bytes(ci, 4 * co), dev, torch.uint8)
                 d = self._buf(f'upv{i}:x3d', ops.x3mat_bytes(4 * co, ci), dev, torch.uint8) if train else None
@@ -226,6 +246,11 @@ class ResUnetEngine(_EngineBase):
                 ops.amax(t, sl(name))
             return t
 
+        def fslot(t, name):                        # the amax slot of an activation an fp16x2 kernel is about to split (filled here if nobody did)
+            if id(t) not in src_name:
+                produced(t, name, fused=False)
+            return sl(src_name[id(t)])
+
         def cf(name, src, src2, bias, out, cout, act, residual=None):
             hp = self.WH.get(name, (None, None))[0]
             if hp is None:
@@ -251,7 +276,10 @@ class ResUnetEngine(_EngineBase):
             a[f't{l}'] = cf(f'b{l}_0', xin, None, None, g(f't{l}', shp), ch[lv], RELU)
             a[f'c{l}'] = cf(f'b{l}_1', a[f't{l}'], None, None, g(f'c{l}', shp), ch[lv], 0, residual=xin)
             if l < 5:
-                if f'pool{l}' in self.WX:
+                if f'pool{l}' in self.WM:
+                    a[f'd{l}'] = produced(ops.conv_s2_h2_fwd(a[f'c{l}'], fslot(a[f'c{l}'], f'c{l}'), self.WM[f'pool{l}'][0], self.WS[f'pool{l}'], P[f'pool{l}.conv.bias'],
+                                                             g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l], 0, amax_y=sl(f'pool{l}')), f'pool{l}', fused=True)
+                elif f'pool{l}' in self.WX:
                     a[f'd{l}'] = produced(ops.conv_s2_x3_fwd(a[f'c{l}'], self.WX[f'pool{l}'][0], P[f'pool{l}.conv.bias'],
                                                              g(f'd{l}', (B, hs[l], ws[l], ch[l])), ch[l], amax_y=sl(f'pool{l}') if h2_on else None), f'pool{l}', fused=True)
                 else:
@@ -262,7 +290,10 @@ class ResUnetEngine(_EngineBase):
         for i in range(6, 10):
             lv = 9 - i
             shp = (B, hs[lv], ws[lv], ch[lv])
-            if f'upv{i}' in self.WX:
+            if f'upv{i}' in self.WM:
+                u = produced(ops.convt_h2_fwd(cur, fslot(cur, f'in_upv{i}'), self.WM[f'upv{i}'][0], self.WS[f'upv{i}'], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv],
+                                              amax_y=sl(f'upv{i}')), f'upv{i}', fused=True)
+            elif f'upv{i}' in self.WX:
                 u = produced(ops.convt_x3_fwd(cur, self.WX[f'upv{i}'][0], P[f'upv{i}.bias'], g(f'u{i}', shp), ch[lv],
                                               amax_y=sl(f'upv{i}') if h2_on else None), f'upv{i}', fused=True)
             else:
@@ -270,7 +301,9 @@ class ResUnetEngine(_EngineBase):
             skip = a[f'c{lv + 1}']
             a[f'u{i}'] = u
             a[f't{i}'] = cf(f'b{i}_0', u, skip, None, g(f't{i}', shp), ch[lv], RELU)
-            if self.WX.get(f'sc{i}', (None, None))[0] is not None:
+            if f'sc{i}' in self.WM:
+                sc = ops.conv1x1_h2_fwd(u, fslot(u, f'upv{i}'), skip, fslot(skip, f'c{lv + 1}'), self.WM[f'sc{i}'][0], self.WS[f'sc{i}'], None, g(f'sc{i}', shp), ch[lv], 0)
+            elif self.WX.get(f'sc{i}', (None, None))[0] is not None:
                 sc = ops.conv1x1_x3_fwd(u, skip, self.WX[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 0)
             else:
                 sc = ops.conv_fwd(u, skip, W[f'sc{i}'][0], None, g(f'sc{i}', shp), ch[lv], 1, 0)
@@ -319,6 +352,11 @@ class ResUnetEngine(_EngineBase):
             if h2_on and not fused:
                 ops.amax(t, bufs.slot('b', name, dev))
             return t
+
+        def bneed(t, name):                        # the amax slot of a gradient an fp16x2 kernel is about to split (filled here if it is stale / missing)
+            if id(t) not in gname:
+                gproduced(t, name, fused=False)
+            return gslot(t)
 
         def dg(name, gsrc, dx1, **kw):
             hp = self.WH.get(name, (None, None))[1]
@@ -382,7 +420,11 @@ class ResUnetEngine(_EngineBase):
             # (the shortcut's gradient is ACCUMULATED into g_u and g_skip next: their slots are stale from here on -- no fp16x2 kernel reads
             #  them before ConvTranspose2d's backward / the stride-2 backward rewrite or finish them)
             gname.pop(id(g_u), None); gname.pop(id(g_skip), None)
-            if self.WX.get(f'sc{i}', (None, None))[0] is not None:
+            if f'sc{i}' in self.WM:
+                # (g_u now holds block gradient + shortcut gradient: the kernel reports max |sum| -- its slot is valid again; g_skip's stays stale)
+                ops.conv1x1_h2_bwd_data(g, bneed(g, f'gc{i}'), self.WM[f'sc{i}'][1], self.WS[f'sc{i}'], g_u, accum1=1, amax_dx1=bslot(f'gu{i}'), dx2=g_skip, accum2=1)
+                gname[id(g_u)] = f'gu{i}'
+            elif self.WX.get(f'sc{i}', (None, None))[0] is not None:
                 ops.conv1x1_x3_bwd_data(g, self.WX[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1)
             else:
                 ops.conv_bwd_data(g, W[f'sc{i}'][1], g_u, accum1=1, dx2=g_skip, accum2=1, taps=1)
@@ -392,7 +434,10 @@ class ResUnetEngine(_EngineBase):
             ct_wgrad(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
-            if f'upv{i}' in self.WX:
+            if f'upv{i}' in self.WM:
+                ops.convt_h2_bwd_data(g_u, bneed(g_u, f'gu{i}'), self.WM[f'upv{i}'][1], self.WS[f'upv{i}'], g, amax_dx=bslot(f'upv{i}'))
+                gproduced(g, f'upv{i}', fused=True)
+            elif f'upv{i}' in self.WX:
                 ops.convt_x3_bwd_data(g_u, self.WX[f'upv{i}'][1], g, amax_dx=bslot(f'upv{i}'))
                 gproduced(g, f'upv{i}', fused=True)
             else:
@@ -427,7 +472,10 @@ class ResUnetEngine(_EngineBase):
                 s2_wgrad(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
                 done(f'pool{l - 1}.conv.weight')
                 g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
-                if f'pool{l - 1}' in self.WX:
+                if f'pool{l - 1}' in self.WM:
+                    ops.conv_s2_h2_bwd_data(g_x, bneed(g_x, f'gx{l}'), self.WM[f'pool{l - 1}'][1], self.WS[f'pool{l - 1}'], g, accum=1, amax_dx=bslot(f'pool{l - 1}'))
+                    gproduced(g, f'pool{l - 1}', fused=True)
+                elif f'pool{l - 1}' in self.WX:
                     ops.conv_s2_x3_bwd_data(g_x, self.WX[f'pool{l - 1}'][1], g, accum=1, amax_dx=bslot(f'pool{l - 1}'))
                     gproduced(g, f'pool{l - 1}', fused=True)           # (the sums it stored: skip gradient + this layer's)
                 else:

@@ -478,6 +478,8 @@ class UNetEngine(_EngineBase):
         for i in range(6, 10):             # decoder: upv{i}, conv{i}_1 on [up, skip], conv{i}_2
             lvl = 9 - i
             if f'upv{i}' in self._h2m:
+                if id(cur) not in src_name:
+                    produced(cur, f'in_upv{i}', fused=False)
                 u = ops.convt_h2_fwd(cur, sl(src_name[id(cur)]), self._h2m[f'upv{i}'][0], self._wslot[f'upv{i}'], P[f'upv{i}.bias'],
                                      g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl], amax_y=sl(f'upv{i}'))
                 a[f'u{i}'] = produced(u, f'upv{i}', fused=True)
@@ -616,7 +618,9 @@ class UNetEngine(_EngineBase):
             ct_wgrad(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc, dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
-            if f'upv{i}' in self._h2m and id(g_u) in gname:
+            if f'upv{i}' in self._h2m:
+                if id(g_u) not in gname:
+                    gproduced(g_u, f'gu{i}', fused=False)
                 ops.convt_h2_bwd_data(g_u, gslot(g_u), self._h2m[f'upv{i}'][1], self._wslot[f'upv{i}'], g_cur, mask=below, mode=LRELU,
                                       amax_dx=bufs.slot('b', f'upv{i}', dev))
                 gproduced(g_cur, f'upv{i}', fused=True)

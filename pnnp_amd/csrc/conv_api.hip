@@ -431,6 +431,32 @@ int pnnp_conv1x1_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_
     return gemm_h2_go(h, Cout, as_stream(stream));
 }
 
+int pnnp_conv3x3s2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, const void* w_h2, const unsigned* amax_w, const float* bias, float* y,
+                              unsigned* amax_y, int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x || !w_h2 || !y || !amax_x || !amax_w || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    s2_fwd_args(h.g, x, Cin, w_h2, bias, y, B, H, W, Cout, act);
+    h.g.amax_out[0] = amax_y; h.amax_in[0] = amax_x; h.amax_w = amax_w;
+    return gemm_h2_go(h, Cin, as_stream(stream));
+}
+int pnnp_conv3x3s2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_s2dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                   const float* mask, int mode, int accum, unsigned* amax_dx, int B, int H, int W, void* stream) {
+    if (!g || !w_h2_s2dgrad || !dx || !amax_g || !amax_w || B < 0 || H <= 0 || W <= 0 || (H & 1) || (W & 1)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    int slice = 0;
+    for (int cls = 0; cls < 4; ++cls) {                              // one launch per input-pixel parity class (pnnp_conv3x3s2_x3_bwd_data_amax_f32)
+        H2Args h{};
+        const int ns = s2_bwd_args(h.g, cls, g, Cout, dx, Cin, mask, mode, accum, B, H, W);
+        h.g.amax_out[0] = amax_dx; h.amax_in[0] = amax_g; h.amax_w = amax_w;
+        h.g.w = reinterpret_cast<const float*>(reinterpret_cast<const char*>(w_h2_s2dgrad) + (int64_t)slice * Cout * Cin * 4);
+        const int rc = gemm_h2_go(h, Cout, as_stream(stream));
+        if (rc != PNNP_OK) return rc;
+        slice += ns;
+    }
+    return PNNP_OK;
+}
+
 // ConvTranspose2d(Cin, Cout, 2, stride=2) forward   archs/Unet.py:35-47
 //   x [B][H][W][Cin] -> y [B][2H][2W][Cout];  one GEMM with N = 4*Cout (the 4 output sub-pixels).
 int pnnp_convt2x2_fwd_f32(const float* x, int Cin, const float* w_packed, const float* bias, float* y,

@@ -416,6 +416,22 @@ int pnnp_pack_jobs_add_h2_1x1(PnnpPackJob* jobs, int* n, int cap, const float* w
     for (int i = n0; i < *n; ++i) { jobs[i].kind = 6; jobs[i].T /= 2; jobs[i].amax = amax; }
     return rc;
 }
+// Conv2d 3x3 stride 2 (layouts of pnnp_pack_jobs_add_x3_s2: fwd = [K = 9 Cin][N = Cout]; dgrad = 9 slices [K = Cout][N = Cin] in parity-class order,
+// the taps of a class stacked along K, class c at the byte offset of its first slice: slices of pnnp_h2mat_bytes(Cout, Cin))
+int pnnp_pack_jobs_add_h2_s2(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd, void* dgrad, int Cout, int Cin, const unsigned* amax) {
+    if (!jobs || !n || !w || !amax || (Cin & 31) || (Cout & 31)) return PNNP_E_INVALID;
+    static const int order[9] = {4, 3, 5, 1, 7, 0, 2, 6, 8};          // S2_TAP_ORDER of csrc/conv_api.hip: classes of 1, 2, 2, 4 taps
+    static const int first[9] = {0, 1, 1, 3, 3, 5, 5, 5, 5}, count[9] = {1, 2, 2, 2, 2, 4, 4, 4, 4};
+    bool ok = true;
+    const int n0 = *n;
+    for (int t = 0; t < 9; ++t) {
+        if (fwd) ok = ok && push(jobs, n, cap, x3mat(w, fwd, Cin, Cout, 9, (int64_t)Cin * 9, t, 9 * Cin, t * Cin, Cout, 0));
+        if (dgrad) ok = ok && push(jobs, n, cap, x3mat(w, reinterpret_cast<char*>(dgrad) + (int64_t)first[t] * Cout * Cin * 4, Cout, Cin, (int64_t)Cin * 9, 9,
+                                                       order[t], count[t] * Cout, (t - first[t]) * Cout, Cin, 0));
+    }
+    for (int i = n0; i < *n; ++i) { jobs[i].kind = 6; jobs[i].T /= 2; jobs[i].amax = amax; }
+    return ok ? PNNP_OK : PNNP_E_WORKSPACE;
+}
 int64_t pnnp_h2mat_bytes(int K, int N) { return (int64_t)K * N * 4; }
 
 

@@ -142,6 +142,13 @@ class PackJobs:
         self.keep += [w, fwd, dgrad]
         return slot
 
+    def add_h2_s2(self, w, fwd, dgrad):
+        co, ci = w.shape[0], w.shape[1]
+        slot = self.weight_slot(w)
+        check(_prep().pnnp_pack_jobs_add_h2_s2(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), co, ci, ptr(slot)), 'pack_jobs_add_h2_s2')
+        self.keep += [w, fwd, dgrad]
+        return slot
+
     def add_x3_convt(self, w, fwd, dgrad):
         ci, co = w.shape[0], w.shape[1]
         check(_prep().pnnp_pack_jobs_add_x3_convt(self.jobs, C.byref(self.n), self.cap, ptr(w), ptr(fwd), ptr(dgrad), ci, co), 'pack_jobs_add_x3_convt')
@@ -363,6 +370,41 @@ def convt_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx, mask=None, mode=0, amax
     with _Timed('convt_dgrad_h2', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
         check(_prep().pnnp_convt2x2_h2_bwd_data_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), Cin, ptr(mask), mode, ptr(amax_dx),
                                                     B, H, W, stream()), 'convt_h2_bwd_data')
+
+
+def conv1x1_h2_fwd(x1, amax_x1, x2, amax_x2, w_h2, amax_w, bias, y, cout, act, residual=None, amax_y=None):
+    require_cuda(x1, x2, w_h2, y, amax_x1, amax_w)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv1_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2), 4.0 * B * H * W * (C1 + C2 + cout)):
+        check(_prep().pnnp_conv1x1_h2_fwd_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(residual), ptr(y), ptr(amax_y),
+                                              B, H, W, cout, act, stream()), 'conv1x1_h2_fwd')
+    return y
+
+
+def conv1x1_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx1, mask1=None, mode1=0, accum1=0, amax_dx1=None, dx2=None, mask2=None, mode2=0, accum2=0):
+    require_cuda(g, w_h2_dgrad, dx1, dx2, amax_g, amax_w)
+    B, H, W, Cout = g.shape
+    C1 = dx1.shape[3]; C2 = dx2.shape[3] if dx2 is not None else 0
+    with _Timed('conv1_dgrad_h2', 2.0 * B * H * W * Cout * (C1 + C2), 4.0 * B * H * W * (C1 + C2 + Cout)):
+        check(_prep().pnnp_conv1x1_h2_bwd_data_f32(ptr(g), Cout, ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx1), C1, ptr(mask1), mode1, int(accum1), ptr(amax_dx1),
+                                                   ptr(dx2), C2, ptr(mask2), mode2, int(accum2), B, H, W, stream()), 'conv1x1_h2_bwd_data')
+
+
+def conv_s2_h2_fwd(x, amax_x, w_h2, amax_w, bias, y, cout, act, amax_y=None):
+    require_cuda(x, w_h2, y, amax_x, amax_w)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_fwd_h2', 2.0 * B * (H // 2) * (W // 2) * cout * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_h2_fwd_f32(ptr(x), Cin, ptr(amax_x), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y), ptr(amax_y), B, H, W, cout, act, stream()), 'conv_s2_h2_fwd')
+    return y
+
+
+def conv_s2_h2_bwd_data(g, amax_g, w_h2_s2dgrad, amax_w, dx, mask=None, mode=0, accum=0, amax_dx=None):
+    require_cuda(g, w_h2_s2dgrad, dx, amax_g, amax_w)
+    B, H, W, Cin = dx.shape
+    with _Timed('conv9s2_dgrad_h2', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_h2_bwd_data_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(w_h2_s2dgrad), ptr(amax_w), ptr(dx), Cin, ptr(mask), mode, int(accum), ptr(amax_dx),
+                                                     B, H, W, stream()), 'conv_s2_h2_bwd_data')
 
 
 def conv1x1_x3_fwd(x1, x2, w_x3, bias, y, cout, act, residual=None):

@@ -76,3 +76,63 @@ def test_convt_h2_scales_and_refusals():
         ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), w.double(), None, stride=2).permute(0, 2, 3, 1)
         assert _rel(y, ref) < 6e-7, (sx, sw_, _rel(y, ref))
     assert not ops.gemm_h2_supported(48, 128) and not ops.gemm_h2_supported(64, 32)
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 32, 64, 64, 128), (1, 24, 40, 128, 256)])
+def test_conv_s2_h2_forward_and_backward_data_vs_float64_and_bf16x3(B, H, W, Cin, Cout):
+    """Conv2d 3x3 stride 2 (ResUnet's pool layers): forward as 9 strided taps, backward-data as four parity-class GEMMs accumulating into dx."""
+    from pnnp_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(B * 77 + Cin)
+    x = torch.randn(B, H, W, Cin, device='cuda', generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device='cuda', generator=g) * 0.05
+    bias = torch.randn(Cout, device='cuda', generator=g)
+    jobs = ops.PackJobs()
+    wf = torch.zeros(ops.h2mat_bytes(9 * Cin, Cout), dtype=torch.uint8, device='cuda'); wd = torch.zeros(9 * ops.h2mat_bytes(Cout, Cin), dtype=torch.uint8, device='cuda')
+    sw = jobs.add_h2_s2(w, wf, wd)
+    xf = torch.zeros(ops.x3mat_bytes(9 * Cin, Cout), dtype=torch.uint8, device='cuda'); xd = torch.zeros(9 * ops.x3mat_bytes(Cout, Cin), dtype=torch.uint8, device='cuda')
+    jobs.add_x3_s2(w, xf, xd); jobs.run()
+    y = torch.empty(B, H // 2, W // 2, Cout, device='cuda'); y3 = torch.empty_like(y)
+    ops.conv_s2_h2_fwd(x, _slot(x), wf, sw, bias, y, Cout, 0)
+    ops.conv_s2_x3_fwd(x, xf, bias, y3, Cout)
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), bias.double(), stride=2, padding=1).permute(0, 2, 3, 1)
+    e_h2, e_x3 = _rel(y, ref), _rel(y3, ref)
+    print(f's2 fwd {Cin}->{Cout}: rel L2 vs float64 h2 {e_h2:.2e}, bf16x3 {e_x3:.2e}')
+    assert e_h2 < 6e-7 and e_h2 < 3 * e_x3 + 1e-7
+    gy = torch.randn(B, H // 2, W // 2, Cout, device='cuda', generator=g)
+    base = torch.randn(B, H, W, Cin, device='cuda', generator=g)
+    dx = base.clone(); dx3 = base.clone()
+    sd = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.conv_s2_h2_bwd_data(gy, _slot(gy), wd, sw, dx, accum=1, amax_dx=sd)
+    ops.conv_s2_x3_bwd_data(gy, xd, dx3, accum=1)
+    refd = base.double() + F.conv_transpose2d(gy.permute(0, 3, 1, 2).double(), w.double(), stride=2, padding=1, output_padding=1).permute(0, 2, 3, 1)
+    e_h2, e_x3 = _rel(dx, refd), _rel(dx3, refd)
+    print(f's2 dgrad {Cout}->{Cin}: rel L2 vs float64 h2 {e_h2:.2e}, bf16x3 {e_x3:.2e}')
+    assert e_h2 < 8e-7 and e_h2 < 3 * e_x3 + 1e-7
+    amax = torch.tensor(sd.item(), dtype=torch.int32).view(torch.float32).item()
+    assert float(dx.abs().max()) <= amax <= 1.0001 * float(dx.abs().max())
+
+
+def test_conv1x1_h2_two_inputs_and_two_accumulating_outputs():
+    """ResidualBlock's 1x1 shortcut on cat([up, skip]): forward over two K segments with their own amax slots, backward-data ACCUMULATING into the
+    two gradients (the general epilogue), the first one's slot raised to max |sum|."""
+    from pnnp_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(11)
+    B, H, W, C = 2, 24, 40, 64
+    u = torch.randn(B, H, W, C, device='cuda', generator=g); skip = torch.randn(B, H, W, C, device='cuda', generator=g) * 3
+    w = torch.randn(C, 2 * C, 1, 1, device='cuda', generator=g) * 0.1
+    jobs = ops.PackJobs()
+    wf = torch.zeros(ops.h2mat_bytes(2 * C, C), dtype=torch.uint8, device='cuda'); wd = torch.zeros(ops.h2mat_bytes(C, 2 * C), dtype=torch.uint8, device='cuda')
+    sw = jobs.add_h2_1x1(w, wf, wd); jobs.run()
+    y = torch.empty(B, H, W, C, device='cuda')
+    ops.conv1x1_h2_fwd(u, _slot(u), skip, _slot(skip), wf, sw, None, y, C, 0)
+    ref = F.conv2d(torch.cat([u, skip], 3).permute(0, 3, 1, 2).double(), w.double()).permute(0, 2, 3, 1)
+    assert _rel(y, ref) < 6e-7, _rel(y, ref)
+    gy = torch.randn(B, H, W, C, device='cuda', generator=g)
+    b1 = torch.randn(B, H, W, C, device='cuda', generator=g); b2 = torch.randn(B, H, W, C, device='cuda', generator=g)
+    d1, d2 = b1.clone(), b2.clone()
+    s1 = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.conv1x1_h2_bwd_data(gy, _slot(gy), wd, sw, d1, accum1=1, amax_dx1=s1, dx2=d2, accum2=1)
+    full = torch.einsum('bhwo,oi->bhwi', gy.double(), w[:, :, 0, 0].double())
+    assert _rel(d1, b1.double() + full[..., :C]) < 8e-7 and _rel(d2, b2.double() + full[..., C:]) < 8e-7
+    amax = torch.tensor(s1.item(), dtype=torch.int32).view(torch.float32).item()
+    assert float(d1.abs().max()) <= amax <= 1.0001 * float(d1.abs().max())
