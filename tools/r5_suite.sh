@@ -42,7 +42,8 @@ cp gpurun_out/aux_kernels.json gpurun_out/aux_kernel_stats.csv $OUT/ 2>/dev/null
 timeout 300 python tools/eval_bench.py > $OUT/eval_bench.txt 2>&1
 timeout 300 python tools/layer_bench.py --h2 > $OUT/layer_bench.txt 2>&1
 timeout 300 python tools/layer_bench.py --x3 > $OUT/layer_bench_x3.txt 2>&1
-timeout 300 python tools/pointwise_bench.py > $OUT/pointwise_bench.txt 2>&1
+timeout 300 python tools/pointwise_bench.py --h2 > $OUT/pointwise_bench.txt 2>&1
+timeout 300 python tools/pointwise_bench.py > $OUT/pointwise_bench_x3.txt 2>&1
 timeout 300 python tools/convt_wgrad_bench.py > $OUT/convt_wgrad_bench.txt 2>&1
 timeout 200 python tools/squat_test.py 32 > $OUT/squat_test.txt 2>&1
 ./tools/ubench/h2_probe > $OUT/h2_probe.txt 2>&1
