@@ -156,7 +156,8 @@ class ResUnetEngine(_EngineBase):
         for i in range(6, 10):
             w = P[f'upv{i}.weight']
             ci, co = w.shape[0], w.shape[1]
-            if h2pw and self._pol.use_x3_pointwise(ci, 4 * co) and ops.gemm_h2_supported(ci, 4 * co) and ops.gemm_h2_supported(co, ci):
+            # (only beside an fp16x2 shortcut: its backward-data leaves the amax slot of the summed gradient this layer's backward splits)
+            if h2pw and f'sc{i}' in self.WM and self._pol.use_x3_pointwise(ci, 4 * co) and ops.gemm_h2_supported(ci, 4 * co) and ops.gemm_h2_supported(co, ci):
                 f = self._buf(f'upv{i}:h2mf', ops.h2mat_bytes(ci, 4 * co), dev, torch.uint8)
                 d = self._buf(f'upv{i}:h2md', ops.h2mat_bytes(4 * co, ci), dev, torch.uint8) if train else None
                 self.WS[f'upv{i}'] = jobs.add_h2_convt(w, f, d)
@@ -392,7 +393,11 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             elif taps == 1 and self._pol.use_x3g_wgrad(ops.X3G_PW, cout, c1 + c2, gpre.shape[0], gpre.shape[1], gpre.shape[2], gpre.shape[1], gpre.shape[2],
                                                        max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
-                ops.conv1x1_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+                if h2_on and self._pol.h2_pointwise and id(gpre) in gname and id(x1) in src_name and (x2 is None or id(x2) in src_name):
+                    ops.conv1x1_h2_bwd_weight(gpre, gslot(gpre), cout, x1, slf(x1), c1, x2, slf(x2) if x2 is not None else None, G(pname), G(bias) if bias else None,
+                                              wsf, accumulate=acc)
+                else:
+                    ops.conv1x1_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             else:
                 ops.conv_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, taps, wsf, accumulate=acc)
 
@@ -431,7 +436,10 @@ class ResUnetEngine(_EngineBase):
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
             ct_wgrad = ops.convt_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_CT, below.shape[3], g_u.shape[3], B, below.shape[1], below.shape[2],
                                                                            g_u.shape[1], g_u.shape[2], max(below.shape[3], g_u.shape[3])) else ops.convt_bwd_weight
-            ct_wgrad(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
+            if ct_wgrad is ops.convt_x3_bwd_weight and h2_on and self._pol.h2_pointwise and id(below) in src_name and id(g_u) in gname:
+                ops.convt_h2_bwd_weight(below, slf(below), g_u, gslot(g_u), G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
+            else:
+                ct_wgrad(below, g_u, G(f'upv{i}.weight'), wsf, accumulate=acc, dbias=G(f'upv{i}.bias'))
             done(f'upv{i}.weight')
             g = gb('c5' if i == 6 else f'c{i - 1}', below)
             if f'upv{i}' in self.WM:
@@ -458,7 +466,8 @@ class ResUnetEngine(_EngineBase):
             x3d = self.WX.get(f'b{l}_0', (None, None))[1]
             h2d = self.WH.get(f'b{l}_0', (None, None))[1]
             if h2d is not None:
-                ops.conv_h2_bwd_data_res(g_t, gslot(g_t), h2d, self.WS[f'b{l}_0'], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
+                ops.conv_h2_bwd_data_res(g_t, gslot(g_t), h2d, self.WS[f'b{l}_0'], g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU, amax_dx=bslot(f'gx{l}'))
+                gname[id(g_x)] = f'gx{l}'                          # (the stride-2 layer's fp16x2 backward kernels split it next)
             elif x3d is not None:
                 ops.conv_x3_bwd_data_res(g_t, x3d, g_x, addsrc=g, mask=xin if l == 1 else None, mode=RELU)
             elif ud is not None:
@@ -469,7 +478,10 @@ class ResUnetEngine(_EngineBase):
                 c_prev = a[f'c{l - 1}']
                 s2_wgrad = ops.conv_s2_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_S2, g_x.shape[3], c_prev.shape[3], B, g_x.shape[1], g_x.shape[2],
                                                                                 c_prev.shape[1], c_prev.shape[2], max(g_x.shape[3], c_prev.shape[3])) else ops.conv_s2_bwd_weight
-                s2_wgrad(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
+                if s2_wgrad is ops.conv_s2_x3_bwd_weight and h2_on and self._pol.h2_pointwise and id(c_prev) in src_name:
+                    ops.conv_s2_h2_bwd_weight(g_x, bneed(g_x, f'gx{l}'), c_prev, slf(c_prev), G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
+                else:
+                    s2_wgrad(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
                 done(f'pool{l - 1}.conv.weight')
                 g = gb(f'c{l - 1}', c_prev)                          # already holds the skip gradient
                 if f'pool{l - 1}' in self.WM:

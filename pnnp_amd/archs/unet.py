@@ -615,7 +615,11 @@ class UNetEngine(_EngineBase):
             below = a['c5'] if i == 6 else a[f'c{i - 1}']
             ct_wgrad = ops.convt_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_CT, below.shape[3], ch[lvl], B, below.shape[1], below.shape[2],
                                                                            g_u.shape[1], g_u.shape[2], max(below.shape[3], g_u.shape[3])) else ops.convt_bwd_weight
-            ct_wgrad(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc, dbias=G(f'upv{i}.bias', (ch[lvl],)))
+            if ct_wgrad is ops.convt_x3_bwd_weight and h2_on and self._pol.h2_pointwise and id(below) in src_name and id(g_u) in gname:
+                ops.convt_h2_bwd_weight(below, slf(below), g_u, gslot(g_u), G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc,
+                                        dbias=G(f'upv{i}.bias', (ch[lvl],)))
+            else:
+                ct_wgrad(below, g_u, G(f'upv{i}.weight', P[f'upv{i}.weight'].shape), wsf, accumulate=acc, dbias=G(f'upv{i}.bias', (ch[lvl],)))
             done(f'upv{i}')
             g_cur = gb('c5' if i == 6 else f'c{i - 1}', below.shape)
             if f'upv{i}' in self._h2m:

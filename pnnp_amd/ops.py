@@ -625,6 +625,32 @@ def conv1x1_x3_bwd_weight(g, cout, x1, c1, x2, dW, dbias, ws, accumulate=0):
                                                      B, H, W, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv1x1_x3_bwd_weight')
 
 
+def convt_h2_bwd_weight(x, amax_x, g, amax_g, dW, ws, accumulate=0, dbias=None):
+    """convt_x3_bwd_weight on the fp16x2 scheme (csrc/wgrad_h2g.hip): same shapes and workspace, + the operands' amax slots."""
+    require_cuda(x, g, dW, ws, dbias, amax_x, amax_g)
+    B, H, W, Cin = x.shape
+    with _Timed('convt_wgrad_h2', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        check(_prep().pnnp_convt2x2_h2_bwd_weight_f32(ptr(x), Cin, ptr(amax_x), ptr(g), g.shape[3], ptr(amax_g), ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                      ptr(ws), _i64(ws.numel()), stream()), 'convt_h2_bwd_weight')
+
+
+def conv_s2_h2_bwd_weight(g, amax_g, x, amax_x, dW, dbias, ws, accumulate=0):
+    require_cuda(g, x, dW, ws, amax_g, amax_x)
+    B, H, W, Cin = x.shape
+    with _Timed('conv9s2_wgrad_h2', 2.0 * B * (H // 2) * (W // 2) * g.shape[3] * Cin * 9):
+        check(_prep().pnnp_conv3x3s2_h2_bwd_weight_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(x), Cin, ptr(amax_x), ptr(dW), ptr(dbias), B, H, W, accumulate,
+                                                       ptr(ws), _i64(ws.numel()), stream()), 'conv3x3s2_h2_bwd_weight')
+
+
+def conv1x1_h2_bwd_weight(g, amax_g, cout, x1, amax_x1, c1, x2, amax_x2, dW, dbias, ws, accumulate=0):
+    require_cuda(g, x1, dW, ws, amax_g, amax_x1)
+    B, H, W, gcs = g.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv1_wgrad_h2', 2.0 * B * H * W * cout * (c1 + C2), 4.0 * B * H * W * (c1 + C2 + cout)):
+        check(_prep().pnnp_conv1x1_h2_bwd_weight_f32(ptr(g), gcs, cout, ptr(amax_g), ptr(x1), x1.shape[3], c1, ptr(amax_x1), ptr(x2), C2, C2, ptr(amax_x2), ptr(dW), ptr(dbias),
+                                                     B, H, W, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv1x1_h2_bwd_weight')
+
+
 def convt_bwd_weight(x, g, dW, ws, accumulate=0, dbias=None):
     """dW (and dbias = the channel sums of g, gathered by the same kernel while g is staged) of ConvTranspose2d(k2, s2)."""
     require_cuda(x, g, dW, ws, dbias)

@@ -136,3 +136,49 @@ def test_conv1x1_h2_two_inputs_and_two_accumulating_outputs():
     assert _rel(d1, b1.double() + full[..., :C]) < 8e-7 and _rel(d2, b2.double() + full[..., C:]) < 8e-7
     amax = torch.tensor(s1.item(), dtype=torch.int32).view(torch.float32).item()
     assert float(d1.abs().max()) <= amax <= 1.0001 * float(d1.abs().max())
+
+
+def _wgrad_check(name, got, ref, e_cap=1.2e-6):
+    e = _rel(got, ref)
+    print(f'{name}: rel L2 vs float64 {e:.2e}')
+    assert e < e_cap, (name, e)
+
+
+def test_pointwise_weight_gradients_h2_vs_float64():
+    """Backward-weights of the three pointwise geometries on csrc/wgrad_h2g.hip (two fp16 pieces per operand, three MFMAs per block and tap):
+    dW and dbias against float64, at the bar of the bf16x3 kernels' test (K = 10^4 .. 10^5 pixels per weight)."""
+    from pnnp_amd import ops
+    g = torch.Generator(device='cuda').manual_seed(21)
+    # ConvTranspose2d(128 -> 64): x [B,H,W,128], gy [B,2H,2W,64]
+    B, H, W, Ci, Co = 2, 32, 64, 128, 64
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=g); gy = torch.randn(B, 2 * H, 2 * W, Co, device='cuda', generator=g) * 1e-3
+    assert ops.x3g_wgrad_supported(ops.X3G_CT, Ci, Co)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, H, W, Ci, Co), device='cuda')
+    dW = torch.empty(Ci, Co, 2, 2, device='cuda'); db = torch.empty(Co, device='cuda')
+    ops.convt_h2_bwd_weight(x, _slot(x), gy, _slot(gy), dW, ws, dbias=db)
+    ref = torch.einsum('bhwi,bhawco->ioac', x.double(), gy.double().reshape(B, H, 2, W, 2, Co))
+    _wgrad_check('convT dW', dW, ref); _wgrad_check('convT dbias', db, gy.double().sum((0, 1, 2)))
+    dW3 = torch.empty_like(dW); ops.convt_x3_bwd_weight(x, gy, dW3, ws)
+    assert _rel(dW, ref) < 3 * _rel(dW3, ref) + 1e-7
+    # Conv2d 3x3 stride 2 (64 -> 128)
+    B, H, W, Ci, Co = 2, 32, 64, 64, 128
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=g); gy = torch.randn(B, H // 2, W // 2, Co, device='cuda', generator=g)
+    assert ops.x3g_wgrad_supported(ops.X3G_S2, Co, Ci)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_S2, B, H // 2, W // 2, Co, Ci), device='cuda')
+    dW = torch.empty(Co, Ci, 3, 3, device='cuda'); db = torch.empty(Co, device='cuda')
+    ops.conv_s2_h2_bwd_weight(gy, _slot(gy), x, _slot(x), dW, db, ws)
+    xd = x.permute(0, 3, 1, 2).double().requires_grad_(False)
+    wref = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device='cuda', requires_grad=True)
+    F.conv2d(xd, wref, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    _wgrad_check('s2 dW', dW, wref.grad); _wgrad_check('s2 dbias', db, gy.double().sum((0, 1, 2)))
+    # Conv2d 1x1 on cat([x1, x2]) (2 x 64 -> 64), accumulating into an existing gradient
+    B, H, W, C = 2, 32, 64, 64
+    x1 = torch.randn(B, H, W, C, device='cuda', generator=g); x2 = torch.randn(B, H, W, C, device='cuda', generator=g) * 5
+    gy = torch.randn(B, H, W, C, device='cuda', generator=g)
+    assert ops.x3g_wgrad_supported(ops.X3G_PW, C, 2 * C)
+    ws = torch.empty(ops.x3g_wgrad_workspace_floats(ops.X3G_PW, B, H, W, C, 2 * C), device='cuda')
+    base = torch.randn(C, 2 * C, device='cuda', generator=g)
+    dW = base.clone()
+    ops.conv1x1_h2_bwd_weight(gy, _slot(gy), C, x1, _slot(x1), C, x2, _slot(x2), dW, None, ws, accumulate=1)
+    ref = base.double() + torch.einsum('bhwo,bhwi->oi', gy.double(), torch.cat([x1, x2], 3).double())
+    _wgrad_check('1x1 dW (accumulated)', dW, ref)

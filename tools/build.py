@@ -13,7 +13,7 @@ HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
           '-I', os.path.join(REPO, 'include')] + os.environ.get('PNNP_HIPCC_EXTRA', '').split()     # A/B experiments (-DWINO_FENCED=0 ...)
 # per-file extra flags: the sampler keeps every float32 rounding explicit (matches oracle/pnnp_oracle.c)
-EXTRA = {'wino.hip': ['-fno-slp-vectorize'], 'conv_igemm.hip': ['-fno-slp-vectorize'], 'conv_x3.hip': ['-fno-slp-vectorize'], 'conv_x3s.hip': ['-fno-slp-vectorize'], 'conv_h2s.hip': ['-fno-slp-vectorize'], 'wgrad_x3.hip': ['-fno-slp-vectorize'], 'wgrad_x3s.hip': ['-fno-slp-vectorize'], 'wgrad_x3g.hip': ['-fno-slp-vectorize'], 'gemm_x3.hip': ['-fno-slp-vectorize'], 'gemm_x3s.hip': ['-fno-slp-vectorize'],      # measured: +0.5 % / +0.7 % on the step each
+EXTRA = {'wino.hip': ['-fno-slp-vectorize'], 'conv_igemm.hip': ['-fno-slp-vectorize'], 'conv_x3.hip': ['-fno-slp-vectorize'], 'conv_x3s.hip': ['-fno-slp-vectorize'], 'conv_h2s.hip': ['-fno-slp-vectorize'], 'wgrad_x3.hip': ['-fno-slp-vectorize'], 'wgrad_x3s.hip': ['-fno-slp-vectorize'], 'wgrad_x3g.hip': ['-fno-slp-vectorize'], 'gemm_x3.hip': ['-fno-slp-vectorize'], 'gemm_x3s.hip': ['-fno-slp-vectorize'], 'gemm_h2s.hip': ['-fno-slp-vectorize'], 'wgrad_h2g.hip': ['-fno-slp-vectorize'],      # measured: +0.5 % / +0.7 % on the step each
          'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off'], 'cropaug.hip': ['-ffp-contract=off'],
          # the Winograd backward-weight kernel's source order is its schedule (slots fenced with sched_barrier)
          # (-fno-slp-vectorize: its stride-2 transforms vectorise into packed ops fed by 84 register moves per chunk; scalar is 44 fewer)

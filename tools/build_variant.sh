@@ -11,7 +11,7 @@ OBJS=$(ls pnnp_amd/csrc/_build/*.o)
 while [ $# -gt 0 ]; do
   F="$1"; FL="$2"; shift 2
   EXTRA=""
-  case "$F" in conv_x3.hip|conv_x3s.hip|conv_h2s.hip|wgrad_h2s.hip|wgrad_x3.hip|wgrad_x3s.hip|wgrad_x3g.hip|gemm_x3.hip|gemm_x3s.hip|conv_igemm.hip|wino.hip) EXTRA="-fno-slp-vectorize";; esac
+  case "$F" in conv_x3.hip|conv_x3s.hip|conv_h2s.hip|wgrad_h2s.hip|gemm_h2s.hip|wgrad_h2g.hip|wgrad_x3.hip|wgrad_x3s.hip|wgrad_x3g.hip|gemm_x3.hip|gemm_x3s.hip|conv_igemm.hip|wino.hip) EXTRA="-fno-slp-vectorize";; esac
   O=$V/obj_$TAG/${F%.hip}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I include $EXTRA $FL -c pnnp_amd/csrc/$F -o $O
   OBJS=$(echo "$OBJS" | grep -v "/${F%.hip}.o"); OBJS="$OBJS $O"
