@@ -142,19 +142,23 @@ __device__ __forceinline__ void h2mat_job(const PnnpPackJob& j, int64_t blk, int
     const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
     const int K = j.K, N = j.N, K32 = j.T, k_off = (int)j.st;
     const float s = __uint_as_float((unsigned)(pnnp_h2_scale_exp(j.amax[0]) + 127) << 23);
-    const int64_t total = (int64_t)K * N;
-    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
-        const int kr = (int)(t & 7);                               // 8 consecutive k of one column: one 16-byte word per piece
-        int64_t r = t >> 3;
-        const int n = (int)(r % N);
-        const int k = (int)(r / N) * 8 + kr;
-        if (k >= K) continue;
-        const float vs = w[j.off + (int64_t)k * j.sk + (int64_t)n * j.sn] * s;
-        const _Float16 h = (_Float16)vs;
-        const _Float16 l = (_Float16)(vs - (float)h);
-        const int kk = k_off + k, nn = j.n_off + n;
-        unsigned short* o = u + ((int64_t)(nn >> 5) * K32 + (kk >> 5)) * 2048 + ((kk >> 3) & 3) * 256 + (nn & 31) * 8 + (kk & 7);
-        o[0] = __builtin_bit_cast(unsigned short, h); o[1024] = __builtin_bit_cast(unsigned short, l);
+    const unsigned total = (unsigned)(K / 8) * (unsigned)N;          // one thread = 8 consecutive k of one column: a 16-byte word per piece (K % 8 == 0)
+    for (unsigned t = (unsigned)blk * 256 + threadIdx.x; t < total; t += (unsigned)nblk * 256) {
+        const unsigned n = t % (unsigned)N, k0 = (t / (unsigned)N) * 8;
+        const float* src = w + j.off + (int64_t)k0 * j.sk + (int64_t)n * j.sn;
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            const float v0 = src[(int64_t)e * j.sk] * s, v1 = src[(int64_t)(e + 1) * j.sk] * s;
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+            hw[e >> 1] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[e >> 1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        const int kk = k_off + (int)k0, nn = j.n_off + (int)n;
+        unsigned short* o = u + ((int64_t)(nn >> 5) * K32 + (kk >> 5)) * 2048 + ((kk >> 3) & 3) * 256 + (nn & 31) * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *reinterpret_cast<uint4*>(o + 1024) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
 }
 
@@ -166,27 +170,38 @@ __device__ __forceinline__ void h2_job(const PnnpPackJob& j, int64_t blk, int nb
     const float* __restrict__ w = j.src; unsigned short* __restrict__ u = reinterpret_cast<unsigned short*>(j.dst);
     const int Cout = j.K, Cin = j.N, dgrad = j.T;
     const int K = dgrad ? Cout : Cin, N = dgrad ? Cin : Cout;
-    const int Kp = j.Kvalid, K16 = Kp / 16;
+    const int Kp = j.Kvalid, K16 = Kp / 16, NB = (N + 31) / 32;
     const float s = __uint_as_float((unsigned)(pnnp_h2_scale_exp(j.amax[0]) + 127) << 23);
-    const int64_t total = (int64_t)Kp * ((N + 31) / 32 * 32) * 9;
-    for (int64_t t = blk * 256 + threadIdx.x; t < (int64_t)((N + 31) / 32) * K16 * 512; t += (int64_t)nblk * 256)       // the zero taps
-        u[(t >> 9) * 9728 + 18 * 512 + (t & 511)] = 0;
-    for (int64_t t = blk * 256 + threadIdx.x; t < total; t += (int64_t)nblk * 256) {
-        const int e = (int)(t & 7);                                // destination order: coalesced 2-byte stores of one piece plane
-        int64_t r = t >> 3;
-        const int nn = (int)(r & 31); r >>= 5;
-        const int oct = (int)(r & 1); r >>= 1;
-        const int tap = (int)(r % 9); r /= 9;
-        const int c = (int)(r % K16);
-        const int nb = (int)(r / K16);
-        const int k = c * 16 + oct * 8 + e, n = nb * 32 + nn;
-        float v = 0.f;
-        if (k < K && n < N) v = dgrad ? w[((int64_t)k * Cin + n) * 9 + (8 - tap)] : w[((int64_t)n * Cin + k) * 9 + tap];
-        const float vs = v * s;
-        const _Float16 h = (_Float16)vs;
-        const _Float16 l = (_Float16)(vs - (float)h);
-        unsigned short* o = u + ((int64_t)nb * K16 + c) * 9728 + tap * 512 + oct * 256 + nn * 8 + e;
-        o[0] = __builtin_bit_cast(unsigned short, h); o[9 * 512] = __builtin_bit_cast(unsigned short, l);
+    // one thread = one 16-byte word of each piece plane: 8 consecutive k of (32-column block nb, chunk c, tap, octet, column nn) -- 32-bit index
+    // arithmetic, two 16-byte stores (was: one element, two 2-byte stores and three 64-bit divisions per thread: 45 us per launch)
+    const unsigned words = (unsigned)NB * K16 * 9 * 2 * 32;        // (< 2^31 / 8: the launcher's job_blocks bound)
+    for (unsigned t = (unsigned)blk * 256 + threadIdx.x; t < (unsigned)NB * K16 * 64; t += (unsigned)nblk * 256)        // the zero taps: 64 words per block
+        reinterpret_cast<uint4*>(u)[(size_t)(t >> 6) * (9728 / 8) + 18 * 64 + (t & 63)] = make_uint4(0, 0, 0, 0);
+    for (unsigned t = (unsigned)blk * 256 + threadIdx.x; t < words; t += (unsigned)nblk * 256) {
+        const unsigned nn = t & 31, oct = (t >> 5) & 1;
+        unsigned r = t >> 6;
+        const unsigned tap = r % 9; r /= 9;
+        const unsigned c = r % (unsigned)K16, nb = r / (unsigned)K16;
+        const int k0 = (int)(c * 16 + oct * 8), n = (int)(nb * 32 + nn);
+        unsigned hw[4], lw[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float v[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int k = k0 + e + q;
+                v[q] = 0.f;
+                if (k < K && n < N) v[q] = dgrad ? w[((int64_t)k * Cin + n) * 9 + (8 - tap)] : w[((int64_t)n * Cin + k) * 9 + tap];
+            }
+            const float v0 = v[0] * s, v1 = v[1] * s;
+            const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+            const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
+            hw[e >> 1] = (unsigned)__builtin_bit_cast(unsigned short, h0) | ((unsigned)__builtin_bit_cast(unsigned short, h1) << 16);
+            lw[e >> 1] = (unsigned)__builtin_bit_cast(unsigned short, l0) | ((unsigned)__builtin_bit_cast(unsigned short, l1) << 16);
+        }
+        unsigned short* o = u + ((size_t)nb * K16 + c) * 9728 + tap * 512 + oct * 256 + nn * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+        *reinterpret_cast<uint4*>(o + 9 * 512) = make_uint4(lw[0], lw[1], lw[2], lw[3]);
     }
 }
 
@@ -222,7 +237,7 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
 
 int job_blocks(const PnnpPackJob& j) {
     if (j.kind == 5) { const int64_t b5 = (j.sk + 256 * 16 - 1) / (256 * 16); return (int)(b5 > 1024 ? 1024 : (b5 < 1 ? 1 : b5)); }
-    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : (j.kind == 3 || j.kind == 6) ? (int64_t)((j.K + 7) / 8 * 8) * j.N : ((j.kind == 2 || j.kind == 4) ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N);
+    const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : j.kind == 6 ? (int64_t)(j.K / 8) * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (j.kind == 4 ? (int64_t)j.Kvalid / 8 * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N));
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
