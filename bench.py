@@ -348,7 +348,7 @@ def main():
         out = {
             "metric": "512x512x4 raw crops/sec (train step)", "value": value, "unit": "crops/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
-            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": ("f32 (operands, accumulation and results; 3x3 forward / backward-data / backward-weight multiply on the fp16 matrix cores through a per-tensor-scaled 2-way split, 22 significand bits per operand: csrc/h2.h; ConvTranspose2d on the bf16 matrix cores through the exact 3-way split)" if getattr(pol, 'h2', False) else "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)") if pol.x3 else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": ("f32 (operands, accumulation and results; 3x3 and ConvTranspose2d / 1x1 / stride-2 forward / backward-data / backward-weight multiply on the fp16 matrix cores through a per-tensor-scaled 2-way split, 22 significand bits per operand: csrc/h2.h)" if getattr(pol, 'h2', False) else "f32 (operands, accumulation and results; 3x3 forward / backward-data multiply on the bf16 matrix cores through an exact 3-way split)") if pol.x3 else "f32", "data": "synthetic",
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else f"NoiseFlow.sample proxy (iso 6400, ratio in {{1,2,4,8,16}}, BatchNorm in {args.proxy_mode} mode)") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
