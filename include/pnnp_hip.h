@@ -255,8 +255,10 @@ int pnnp_conv3x3s2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, c
                               unsigned* amax_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
 int pnnp_conv3x3s2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_s2dgrad, const unsigned* amax_w, float* dx, int Cin,
                                    const float* mask /*or null*/, int mode, int accum, unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
-/* ... and their backward-weights (csrc/wgrad_h2g.hip): shapes, workspace and contracts of the _x3_ entries (pnnp_x3g_wgrad_supported,
- * pnnp_x3g_wgrad_workspace_floats) + the amax slots of the two tensors that are split */
+/* ... and their backward-weights (csrc/wgrad_h2g.hip): contracts of the _x3_ entries + the amax slots of the two tensors that are split; shapes and
+ * workspace: pnnp_h2g_wgrad_supported / _workspace_floats (kind as pnnp_x3g_wgrad_supported: everything it takes, and stride-2 with Cout % 64 == 0) */
+int pnnp_h2g_wgrad_supported(int kind, int M, int N);
+int64_t pnnp_h2g_wgrad_workspace_floats(int kind, int B, int UH, int UW, int M, int N);
 int pnnp_convt2x2_h2_bwd_weight_f32(const float* x, int Cin, const unsigned* amax_x, const float* g, int Cout, const unsigned* amax_g, float* dW, float* dbias /*or null*/,
                                     int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream);
 int pnnp_conv3x3s2_h2_bwd_weight_f32(const float* g, int Cout, const unsigned* amax_g, const float* x, int Cin, const unsigned* amax_x, float* dW, float* dbias /*or null*/,

@@ -478,7 +478,9 @@ class ResUnetEngine(_EngineBase):
                 c_prev = a[f'c{l - 1}']
                 s2_wgrad = ops.conv_s2_x3_bwd_weight if self._pol.use_x3g_wgrad(ops.X3G_S2, g_x.shape[3], c_prev.shape[3], B, g_x.shape[1], g_x.shape[2],
                                                                                 c_prev.shape[1], c_prev.shape[2], max(g_x.shape[3], c_prev.shape[3])) else ops.conv_s2_bwd_weight
-                if s2_wgrad is ops.conv_s2_x3_bwd_weight and h2_on and self._pol.h2_pointwise and id(c_prev) in src_name:
+                h2g_ok = (h2_on and self._pol.h2_pointwise and self._pol.x3 and id(c_prev) in src_name and ops.h2g_wgrad_supported(ops.X3G_S2, g_x.shape[3], c_prev.shape[3])
+                          and ops.x3_wgrad_fits(B, g_x.shape[1], g_x.shape[2], max(g_x.shape[3], c_prev.shape[3])) and ops.x3_wgrad_fits(B, c_prev.shape[1], c_prev.shape[2], max(g_x.shape[3], c_prev.shape[3])))
+                if h2g_ok:                                           # (the fp16x2 kernel also has a tile for Cout = 64: pool1, which bf16x3 left to the fp32-MFMA kernel)
                     ops.conv_s2_h2_bwd_weight(g_x, bneed(g_x, f'gx{l}'), c_prev, slf(c_prev), G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
                 else:
                     s2_wgrad(g_x, c_prev, G(f'pool{l - 1}.conv.weight'), G(f'pool{l - 1}.conv.bias'), wsf, accumulate=acc)
@@ -517,7 +519,8 @@ class ResUnetEngine(_EngineBase):
                 need = max(need, ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 4),
                            ops.wgrad_workspace_floats(B, h >> 1, w >> 1, ch[lv + 1], c, 18),
                            ops.x3g_wgrad_workspace_floats(ops.X3G_CT, B, h >> 1, w >> 1, ch[lv + 1], c),
-                           ops.x3g_wgrad_workspace_floats(ops.X3G_S2, B, h >> 1, w >> 1, ch[lv + 1], c))
+                           ops.x3g_wgrad_workspace_floats(ops.X3G_S2, B, h >> 1, w >> 1, ch[lv + 1], c),
+                           ops.h2g_wgrad_workspace_floats(ops.X3G_S2, B, h >> 1, w >> 1, ch[lv + 1], c))
         need = max(need, ops.head_bwd_workspace_floats(ch[0]), ops.first_wgrad_workspace_floats(ch[0]))
         return max(need, ops.wgrad_workspace_floats(B, H, W, self.cout, ch[0], 1))
 

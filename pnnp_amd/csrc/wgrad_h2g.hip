@@ -384,6 +384,7 @@ using CtA = WhgLaunch<GEO_CT, 2, 1, 4, 2, 1, 16, 1>;
 using CtB = WhgLaunch<GEO_CT, 1, 1, 4, 2, 1, 16, 1>;
 using CtC = WhgLaunch<GEO_CT, 1, 1, 2, 1, 4, 32, 2>;
 using S2A = WhgLaunch<GEO_S2, 1, 1, 4, 1, 2, 32, 1>;
+using S2B = WhgLaunch<GEO_S2, 1, 1, 2, 1, 4, 32, 2>;          // 64 x 32 (64 px; M = Cout = 64: pool1 of the ResUnet -- no bf16x3 twin, it ran on fp32 MFMA)
 using PwA = WhgLaunch<GEO_PW, 2, 2, 2, 2, 2, 32, 1>;
 using PwB = WhgLaunch<GEO_PW, 1, 2, 2, 2, 2, 32, 1>;
 
@@ -391,7 +392,7 @@ using PwB = WhgLaunch<GEO_PW, 1, 2, 2, 2, 2, 32, 1>;
 int wxg_config(int geo, int M, int N) {
     if (M <= 0 || N <= 0 || (M & 31) || (N & 31)) return 0;
     if (geo == GEO_CT) return (M % 256 == 0 && N % 64 == 0) ? 1 : ((M % 128 == 0 && N % 64 == 0) ? 2 : ((M % 64 == 0) ? 3 : 0));
-    if (geo == GEO_S2) return (M % 128 == 0) ? 4 : 0;
+    if (geo == GEO_S2) return (M % 128 == 0) ? 4 : ((M % 64 == 0) ? 7 : 0);
     if (geo == GEO_PW) return (N % 128 == 0) ? ((M % 128 == 0) ? 5 : ((M % 64 == 0) ? 6 : 0)) : 0;
     return 0;
 }
@@ -402,6 +403,7 @@ template <class F> auto wxg_dispatch(int cfg, F&& f) {
         case 3: return f(CtC{});
         case 4: return f(S2A{});
         case 5: return f(PwA{});
+        case 7: return f(S2B{});
         default: return f(PwB{});
     }
 }
@@ -452,8 +454,17 @@ int wxg_run(int geo, const float* U, int Ucs, int M, const unsigned* amax_u, con
 
 extern "C" {
 
-// Same shapes (pnnp_x3g_wgrad_supported), workspace (pnnp_x3g_wgrad_workspace_floats) and contracts as the _x3_ entries of csrc/wgrad_x3g.hip,
-// plus the amax slots of the two tensors that are split on the fly (csrc/h2.h).
+// Contracts of the _x3_ entries of csrc/wgrad_x3g.hip, plus the amax slots of the two tensors that are split on the fly (csrc/h2.h).  Shapes and
+// workspace: pnnp_h2g_wgrad_supported / pnnp_h2g_wgrad_workspace_floats -- everything pnnp_x3g_wgrad_* takes and, in addition, the stride-2
+// layer with Cout % 64 == 0 (a 64 x 32 tile: two pieces per operand leave the LDS room).
+/* kind: 0 = Conv2d 1x1 (M = Cout, N = Cin), 1 = ConvTranspose2d 2x2 s2 (M = Cin, N = Cout), 2 = Conv2d 3x3 s2 (M = Cout, N = Cin) */
+int pnnp_h2g_wgrad_supported(int kind, int M, int N) { return wxg_config(kind, M, N) ? 1 : 0; }
+int64_t pnnp_h2g_wgrad_workspace_floats(int kind, int B, int UH, int UW, int M, int N) {
+    const int cfg = wxg_config(kind, M, N);
+    if (!cfg) return 0;
+    const int taps = kind == GEO_PW ? 1 : (kind == GEO_CT ? 4 : 9);
+    return (int64_t)wxg_splits(cfg, B, UH, UW, M, N) * ((int64_t)taps * M * N + (M > N ? M : N));
+}
 int pnnp_convt2x2_h2_bwd_weight_f32(const float* x, int Cin, const unsigned* amax_x, const float* g, int Cout, const unsigned* amax_g, float* dW, float* dbias,
                                     int B, int H, int W, int accumulate, float* workspace, int64_t workspace_floats, void* stream) {
     if (!x || !g || !dW || !workspace || B <= 0 || H <= 0 || W <= 0) return PNNP_E_INVALID;

@@ -44,6 +44,7 @@ def _prep():
         L.pnnp_h2_weight_bytes.restype = C.c_int64
         L.pnnp_h2_bits_words.restype = C.c_int64
         L.pnnp_h2mat_bytes.restype = C.c_int64
+        L.pnnp_h2g_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_head_bwd_workspace_floats.restype = C.c_int64
         L.pnnp_first_wgrad_workspace_floats.restype = C.c_int64
         L._pnnp_sigs = True
@@ -623,6 +624,14 @@ def conv1x1_x3_bwd_weight(g, cout, x1, c1, x2, dW, dbias, ws, accumulate=0):
     with _Timed('conv1_wgrad_x3', 2.0 * B * H * W * cout * (c1 + C2), 4.0 * B * H * W * (c1 + C2 + cout)):
         check(_prep().pnnp_conv1x1_x3_bwd_weight_f32(ptr(g), gcs, cout, ptr(x1), x1.shape[3], c1, ptr(x2), C2, C2, ptr(dW), ptr(dbias),
                                                      B, H, W, accumulate, ptr(ws), _i64(ws.numel()), stream()), 'conv1x1_x3_bwd_weight')
+
+
+def h2g_wgrad_supported(kind, M, N):
+    return bool(_prep().pnnp_h2g_wgrad_supported(int(kind), int(M), int(N)))
+
+
+def h2g_wgrad_workspace_floats(kind, B, UH, UW, M, N):
+    return int(_prep().pnnp_h2g_wgrad_workspace_floats(int(kind), int(B), int(UH), int(UW), int(M), int(N)))
 
 
 def convt_h2_bwd_weight(x, amax_x, g, amax_g, dW, ws, accumulate=0, dbias=None):

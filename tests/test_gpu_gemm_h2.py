@@ -171,6 +171,16 @@ def test_pointwise_weight_gradients_h2_vs_float64():
     wref = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device='cuda', requires_grad=True)
     F.conv2d(xd, wref, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).double())
     _wgrad_check('s2 dW', dW, wref.grad); _wgrad_check('s2 dbias', db, gy.double().sum((0, 1, 2)))
+    # ... and the 64 x 32 tile only the fp16x2 kernel has (ResUnet's pool1: 32 -> 64 at 512^2)
+    B, H, W, Ci, Co = 2, 64, 96, 32, 64
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=g); gy = torch.randn(B, H // 2, W // 2, Co, device='cuda', generator=g)
+    assert ops.h2g_wgrad_supported(ops.X3G_S2, Co, Ci) and not ops.x3g_wgrad_supported(ops.X3G_S2, Co, Ci)
+    ws = torch.empty(ops.h2g_wgrad_workspace_floats(ops.X3G_S2, B, H // 2, W // 2, Co, Ci), device='cuda')
+    dW = torch.empty(Co, Ci, 3, 3, device='cuda'); db = torch.empty(Co, device='cuda')
+    ops.conv_s2_h2_bwd_weight(gy, _slot(gy), x, _slot(x), dW, db, ws)
+    wref = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, device='cuda', requires_grad=True)
+    F.conv2d(x.permute(0, 3, 1, 2).double(), wref, stride=2, padding=1).backward(gy.permute(0, 3, 1, 2).double())
+    _wgrad_check('s2 dW (64 x 32 tile)', dW, wref.grad); _wgrad_check('s2 dbias (64 x 32 tile)', db, gy.double().sum((0, 1, 2)))
     # Conv2d 1x1 on cat([x1, x2]) (2 x 64 -> 64), accumulating into an existing gradient
     B, H, W, C = 2, 32, 64, 64
     x1 = torch.randn(B, H, W, C, device='cuda', generator=g); x2 = torch.randn(B, H, W, C, device='cuda', generator=g) * 5
