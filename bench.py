@@ -177,6 +177,38 @@ def cpu_baseline(H, W, budget_s=240.0):
             "generate_noisy_obs_1crop_1core_s": obs}
 
 
+PEAK_HBM_TBS = 8.0                 # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+
+
+def probe_rates():
+    """What a bare register-only loop of v_mfma_f32_16x16x32_f16 sustains on this chip (tools/ubench/h2_probe.hip part (1), random operands,
+    2 waves per SIMD: the power-limited clock), read from the newest committed suite output -- the GPU box has no compiler-independent way to
+    re-measure it inside this run's time budget.  Returns (dict, source path) or (None, None)."""
+    import glob
+    import re
+    cands = sorted(glob.glob(os.path.join(REPO, 'profiles', 'r*', 'final_h2_probe.txt')) + glob.glob(os.path.join(REPO, 'profiles', 'r*', 'h2_probe.txt')),
+                   key=lambda f: (int(re.search(r'profiles/r(\d+)/', f).group(1)), os.path.basename(f).startswith('final_')))
+    for f in reversed(cands):
+        rates = {}
+        for line in open(f):
+            m = re.match(r'rate\s+(bf16|f16)\s+16x16x32, (\d) per pair\s+[\d.]+ ms\s+([\d.]+) TFLOP/s', line)
+            if m:
+                rates.setdefault(f'{m.group(1)}_{m.group(2)}_per_pair', []).append(float(m.group(3)))
+        if rates:
+            return {k: max(v) for k, v in rates.items()}, os.path.relpath(f, REPO)
+    return None, None
+
+
+def lib_sha():
+    """Content hash of the library binary this process loaded (an A/B whose two arms print the same hash is not an A/B)."""
+    import hashlib
+    from pnnp_amd import _lib
+    try:
+        return hashlib.sha256(open(_lib.LIB_PATH, 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def csrc_sha():
     """Content hash of the kernel sources: PMC-derived numbers stored under profiles/ are attached to a bench line only when
     they were measured on exactly these kernels (the GPU box has no .git to ask for HEAD)."""
@@ -352,7 +384,7 @@ def main():
             "config": {"workload": ("PNNP noise-proxy ('pr' physics sampler, SonyA7S2 params)" if proxy is None else f"NoiseFlow.sample proxy (iso 6400, ratio in {{1,2,4,8,16}}, BatchNorm in {args.proxy_mode} mode)") +
                                    (" + UNetSeeInDark" if args.arch == "unet" else " + ResUnet") + " nf=32 train step (fwd + L1 + bwd + Adam)", "crops_per_gpu": B, "global_batch": global_batch,
                        "crop": f"4x{S}x{S}", "parallelism": f"dp{world}", "optimizer": "Adam lr 1e-4"},
-            "final_loss": loss_val,
+            "final_loss": loss_val, "lib_sha": lib_sha(), "csrc_sha": csrc_sha(),
         }
         if spread is not None:
             out["replica_checksum_spread"] = spread
@@ -369,9 +401,14 @@ def main():
         step_tflops = GFLOP_PER_CROP_TRAIN[args.arch] * (S * S / (512 * 512)) * B * 1e-3 / (dt / args.steps)
         classes = {}
         if prof:
-            for kind, fl, by, e0, e1 in prof:
+            inst = {}                               # (kind, instantiation) of the dominant kernel: its own line against the roof that bounds it
+            for kind, fl, by, e0, e1, sub in prof:
+                ms_ = e0.elapsed_time(e1) * 1e-3
                 c = classes.setdefault(kind, [0, 0.0, 0.0, 0.0])
-                c[0] += 1; c[1] += fl; c[2] += by; c[3] += e0.elapsed_time(e1) * 1e-3
+                c[0] += 1; c[1] += fl; c[2] += by; c[3] += ms_
+                if sub:
+                    q = inst.setdefault((kind, sub), [0, 0.0, 0.0, 0.0])
+                    q[0] += 1; q[1] += fl; q[2] += by; q[3] += ms_
             # dominant kernel = the family of 3x3 forward / backward-data launches timed in the timed region
             fam = fam0
             dom = [k for k in classes if k in FAMILY[fam][2]]
@@ -391,15 +428,37 @@ def main():
                 else:
                     traffic_note = f"profiles/traffic.json was measured on other kernel sources ({tdoc.get('csrc_sha')} != {csrc_sha()}): not attached"
             by = sum(classes[k][2] for k in dom)
+            # `frac` = FLOPs the matrix pipe EXECUTES / its dense peak (MFMA utilisation: what the hardware does);
+            # `frac_algorithmic` = SURVEY 8(d)'s definition: algorithmic FLOPs (2 px Cout Cin 9 per layer) / launch time / the same peak --
+            # the fp16x2 scheme executes 28/9 piece products per float32 product, so the second is the first / 3.11.
             out["roofline"] = {"bound": "mfma", "achieved": alg_tflops * exec_factor, "peak": peak, "unit": "TFLOP/s",
-                               "frac": alg_tflops * exec_factor / peak, "traffic": traffic, "traffic_source": traffic_note,
+                               "frac": alg_tflops * exec_factor / peak, "frac_algorithmic": alg_tflops / peak,
+                               "traffic": traffic, "traffic_source": traffic_note,
                                "alg_bytes_per_launch": by / n, "kernel": kdesc,
                                "launches": n, "avg_launch_ms": 1e3 * sec / n,
                                "achieved_algorithmic": alg_tflops, "executed_over_algorithmic": exec_factor,
                                "alg_gflop_per_launch": fl / n / 1e9, "executed_gflop_per_launch": fl / n / 1e9 * exec_factor}
+            if inst:
+                # the dominant kernel by instantiation: the 64-column tiles against the matrix pipe, the 32-column tiles (the 32-channel layers
+                # of the 512 x 512 level) against HBM -- algorithmic bytes = the tensors a layer must read and write once, / launch time
+                tab = {}
+                for (kind, sub), (n_, fl_, by_, s_) in sorted(inst.items()):
+                    hbm = sub == 'bn32'
+                    row = {"launches": n_, "ms_per_step": 1e3 * s_ / args.steps, "share_of_kernel_time": s_ / sec,
+                           "algorithmic_tflops": fl_ / s_ / 1e12, "algorithmic_tbytes_per_s": by_ / s_ / 1e12}
+                    row.update({"bound": "hbm", "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": by_ / s_ / 1e12 / PEAK_HBM_TBS} if hbm else
+                               {"bound": "mfma", "peak": peak, "unit": "TFLOP/s", "frac": fl_ / s_ / 1e12 * exec_factor / peak,
+                                "frac_algorithmic": fl_ / s_ / 1e12 / peak})
+                    tab[f"{'igemm_h2s_kernel' if fam == 'h2' else kind}<{sub[2:]},{'forward' if 'fwd' in kind else 'backward-data'}>"] = row
+                out["roofline"]["instantiations"] = tab
+                hb = sum(v[3] for (k_, sub), v in inst.items() if sub == 'bn32')
+                out["roofline"]["hbm_bound_share_of_kernel_time"] = hb / sec
             if fam == 'h2':
                 # informational: a bare register-only loop of v_mfma_f32_16x16x32_f16 on random operands (the power-limited clock), 2 waves per SIMD
-                out["roofline"]["sustained_bare_mfma_loop"] = {"random_operands": 1803.0, "unit": "TFLOP/s", "source": "tools/ubench/h2_probe.hip (profiles/r5/h2_probe.txt)"}
+                pr, psrc = probe_rates()
+                if pr:
+                    out["roofline"]["sustained_bare_mfma_loop"] = {"f16_6_products_per_operand_pair": pr.get('f16_6_per_pair'), "f16_3_products_per_operand_pair": pr.get('f16_3_per_pair'),
+                                                                   "unit": "TFLOP/s", "source": f"tools/ubench/h2_probe.hip part (1), {psrc}"}
             if fam == 'x3':
                 # informational: what a bare loop of the 32x32x16 MFMA sustains on this chip (the 16x16x32 shape the kernel uses: ~1950; tools/ubench/mfma_shape.hip, 8 waves per CU, operands
                 # re-read from LDS): 1790 TFLOP/s on random operands (power-limited clock), 2250 on zero operands; `peak` stays the 2.4 GHz figure
@@ -407,7 +466,7 @@ def main():
                                                                "source": "tools/ubench/mfma_shape.hip (DESIGN 5)"}
             # per-class table: from the un-timed pass with events around every launch (extra_steps steps)
             call = {}
-            for kind, fl2, by2, e0, e1 in (prof_all or []):
+            for kind, fl2, by2, e0, e1, _sub in (prof_all or []):
                 c = call.setdefault(kind, [0, 0.0, 0.0, 0.0])
                 c[0] += 1; c[1] += fl2; c[2] += by2; c[3] += e0.elapsed_time(e1) * 1e-3
             if call:

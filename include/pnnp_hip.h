@@ -33,6 +33,14 @@ extern "C" {
 
 int pnnp_version(void);
 const char* pnnp_error_string(int code);
+/* ABI version: bumped whenever a struct of this header changes its layout or an entry point its meaning (history: INTEGRATION.md, "Upgrade
+ * notes").  A binding written against this header compares pnnp_abi_version() with the PNNP_ABI_VERSION it was compiled / written with and
+ * pnnp_pack_job_bytes() with its own sizeof(PnnpPackJob) before it passes a job table (pnnp_amd/ops.py does, on first use).
+ *   6 (round 6): PnnpPackJob carries a trailing `amax` pointer since round 5 (an older caller's job ARRAY would be read with the wrong stride);
+ *                pnnp_x3_supported refuses more than 1024 output channels (PNNP_E_UNSUPPORTED from the pnnp_conv3x3_x3_* entries beyond it). */
+#define PNNP_ABI_VERSION 6
+int pnnp_abi_version(void);
+int pnnp_pack_job_bytes(void);
 /* Number of compute units etc. of the current device (0 on failure). */
 int pnnp_device_cus(void);
 /* Workgroups per CU of the persistent forward / backward-data convolution kernels (default 1: one per CU with an equal static share of
@@ -217,6 +225,10 @@ int pnnp_conv3x3_x3_bwd_data_res_f32(const float* g, int Cout, const void* w_x3_
  * float32 activation's traffic (archs/Unet.py:52,57-69).  Weights: kind-4 packs of pnnp_h2_weight_bytes(K, N) bytes, scaled with the
  * weight tensor's own slot (pnnp_pack_jobs_add_amax in an earlier launch of the pack table, then pnnp_pack_jobs_add_h2). */
 int pnnp_h2_supported(int K, int N);
+/* GEMM columns (output channels) per workgroup tile that pnnp_conv3x3_h2_* picks for a [B][H][W] map with N channels written: 64, or 32 when N < 64
+ * or 64-column tiles would leave CUs idle (the rule the launcher itself uses).  The 32-column tiles are the HBM-bound instantiations of the
+ * 512 x 512 level (bench.py reports them against the HBM roofline).  pool != 0: the forward + MaxPool2d(2) entry. */
+int pnnp_h2_tile_columns(int B, int H, int W, int N, int pool);
 int64_t pnnp_h2_weight_bytes(int K, int N);
 int64_t pnnp_h2_bits_words(int B, int H, int W, int C);
 int pnnp_amax_f32(const float* x, int64_t count, unsigned* slot, void* stream);

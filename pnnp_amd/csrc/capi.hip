@@ -5,6 +5,9 @@ extern "C" {
 
 int pnnp_version(void) { return 100; }   // 0.1.0
 
+int pnnp_abi_version(void) { return PNNP_ABI_VERSION; }
+int pnnp_pack_job_bytes(void) { return (int)sizeof(PnnpPackJob); }
+
 const char* pnnp_error_string(int code) {
     switch (code) {
         case PNNP_OK: return "ok";

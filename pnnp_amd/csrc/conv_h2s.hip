@@ -74,6 +74,9 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #ifndef H2S_TURNS
 #define H2S_TURNS 0                  // 1: the two consumer waves of a SIMD take turns with a tile's epilogue (see the consumers' loop): measured 1-3 % SLOWER, off
 #endif
+#ifndef H2S_NSETS
+#define H2S_NSETS 2                  // producer register sets for the halo tile: 1 = a chunk's halo is requested at the END of the period before the one that splits it (round 5),
+#endif                               // 2 / 3 = at the START of that period / a period earlier still (profiles/r6/ab_producer_sets.txt)
 #ifdef H2S_STAMPS                 // debug build: cycle sums per wave, dumped into dst[0] (tools/x3s_stamps.py)
 #define H2S_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
 #else
@@ -137,23 +140,41 @@ igemm_h2s_kernel(const H2Args ha) {
     };
     int t = xcd_remap(blockIdx.x, G);
     if (t >= total) return;
-    Tile cur = decode(t), nxt = pick(t + G < total, advance(cur), cur);
-    Tile nxt2 = pick(t + 2 * G < total, advance(nxt), nxt);
+    // lookahead of LA tiles: the producers request halo chunks up to max(2, H2S_NSETS) chunks ahead, which is that many TILES ahead for a one-chunk layer
+    constexpr int NS = H2S_NSETS, LA = NS > 2 ? NS : 2;
+    static_assert(NS >= 1 && NS <= 3, "producer register sets");
+    Tile cur = decode(t), ahead[LA];
+    ahead[0] = pick(t + G < total, advance(cur), cur);
+#pragma unroll
+    for (int i = 1; i < LA; ++i) ahead[i] = pick(t + (i + 1) * G < total, advance(ahead[i - 1]), ahead[i - 1]);
     int g = 0;                                                       // chunk of the current tile
-    // the k-th chunk after the current one, k = 1, 2: (tile, chunk, exists); past the end of this workgroup's work it falls back to the
+    // the k-th chunk after the current one, k = 1 .. LA: (tile, chunk, exists); past the end of this workgroup's work it falls back to the
     // current chunk (requests stay branch-free; weights are then requested with valid = false)
     struct Ck { Tile tile; int g; bool ok; };
-    auto chunk_at = [&](int k) {
+    auto chunk_at = [&](auto ktag) {
+        constexpr int k = decltype(ktag)::value;
+        static_assert(k >= 1 && k <= LA, "lookahead");
         int gk = g + k, hop = 0;
-        if (gk >= nchunks) { gk -= nchunks; hop = 1; }
-        if (gk >= nchunks) { gk -= nchunks; hop = 2; }
+#pragma unroll
+        for (int i = 0; i < k; ++i)
+            if (gk >= nchunks) { gk -= nchunks; ++hop; }
         Ck c;
         c.ok = t + hop * G < total;
         c.g = c.ok ? gk : g;
-        c.tile = pick(!c.ok || hop == 0, cur, pick(hop == 1, nxt, nxt2));
+        Tile far = ahead[0];
+#pragma unroll
+        for (int i = 1; i < k; ++i) far = pick(hop > i, ahead[i], far);
+        c.tile = pick(!c.ok || hop == 0, cur, far);
         return c;
     };
-    auto next_tile = [&]() { t += G; cur = nxt; nxt = nxt2; nxt2 = pick(t + 2 * G < total, advance(nxt), nxt); g = 0; };
+    auto next_tile = [&]() {
+        t += G; cur = ahead[0];
+#pragma unroll
+        for (int i = 0; i + 1 < LA; ++i) ahead[i] = ahead[i + 1];
+        ahead[LA - 1] = pick(t + LA * G < total, advance(ahead[LA - 2]), ahead[LA - 2]);
+        g = 0;
+    };
+    using K1 = std::integral_constant<int, 1>;
 
     if (wave >= NCW) {
         // =============================================== PRODUCER ===============================================
@@ -173,9 +194,10 @@ igemm_h2s_kernel(const H2Args ha) {
             xdst[k] = XS_PLANE(0, oct) + pix;                       // + 2 NPIXP for the lo plane (+ image * XS_F4)
         }
         const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, 0x7fffffff, 0x00020000);
-        f32x4 ra[NSLOT][2];                                         // the halo of the NEXT chunk, 8 channels per slot
-        // global loads of the halo tile of (tile, chunk gq) -> ra: hardware zero for pixels outside the image and channels past the segment
-        auto load_halo = [&](const Tile& tl, int gq) {
+        f32x4 ra[NS][NSLOT][2];                                     // halo chunks in flight / waiting to be split, 8 channels per slot
+        // global loads of the halo tile of (tile, chunk gq) -> register set S: hardware zero for pixels outside the image and channels past the segment
+        auto load_halo = [&](auto stag, const Tile& tl, int gq) {
+            constexpr int S = decltype(stag)::value;
             const int si = gq / a.chunks_per_seg, cc = gq - si * a.chunks_per_seg;
             const IgemmSeg sg = a.seg[si];
             const int c0 = sg.coff + cc * 16;
@@ -189,22 +211,26 @@ igemm_h2s_kernel(const H2Args ha) {
             for (int k = 0; k < NSLOT; ++k) {
                 const int bad = (rk[k] - rlo) | (rhi - 1 - rk[k]) | (qk[k] - qlo) | (qhi - 1 - qk[k]) | (cvalid - 1);     // sign bit set <=> outside
                 const unsigned vo = bad < 0 ? OOB : __umul24(pixk[k], cs4) + oct * 32;
-                ra[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
-                ra[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16, 0));
+                ra[S][k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff, 0));
+                ra[S][k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, soff + 16, 0));
             }
         };
-        // slot k of ra -> its two 16-byte words (8 channels of hi, of lo) in halo image img
-        auto stage_slot = [&](int k, int img) {
-            u32x4 sh, sl;
+        // register set S -> the two 16-byte words (8 channels of hi, of lo) per slot in halo image img
+        auto stage = [&](auto stag, int img) {
+            constexpr int S = decltype(stag)::value;
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const f32x4 v = ra[k][p >> 1];
-                unsigned h, l;
-                split_h2(v[(p & 1) * 2], v[(p & 1) * 2 + 1], sx, h, l);
-                sh[p] = h; sl[p] = l;
+            for (int k = 0; k < NSLOT; ++k) {
+                u32x4 sh, sl;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const f32x4 v = ra[S][k][p >> 1];
+                    unsigned h, l;
+                    split_h2(v[(p & 1) * 2], v[(p & 1) * 2 + 1], sx, h, l);
+                    sh[p] = h; sl[p] = l;
+                }
+                u32x4* d = xs + img * XS_F4 + xdst[k];
+                d[0] = sh; d[2 * NPIXP] = sl;
             }
-            u32x4* d = xs + img * XS_F4 + xdst[k];
-            d[0] = sh; d[2 * NPIXP] = sl;
         };
         // LDS-DMA of the weights of (tile n0, chunk gq) into stage st: per 32-channel block 18432 contiguous bytes of the pack, as 1 KB pieces
         // dealt over the 4 producer waves; past the end a wave repeats the last piece (same bytes, same place)
@@ -222,43 +248,57 @@ igemm_h2s_kernel(const H2Args ha) {
             }
         };
         // ---- prologue: the bias vector, the padding words of the hi planes (the unpaired ninth tap's second half reads one pixel past tap 8: word 612
-        // for the last lane of the last row -- multiplied by the pack's zero tap, so it must be FINITE, not whatever bit pattern the LDS held), the weights of chunk 0, chunk 0's halo straight into image 0, chunk 1's halo into the registers
+        // for the last lane of the last row -- multiplied by the pack's zero tap, so it must be FINITE, not whatever bit pattern the LDS held), the weights
+        // of chunk 0, chunk 0's halo straight into image 0, the halos of chunks 1 .. max(1, NS - 1) into the register sets
         for (int i = ptid; i < Cfg::BIAS_MAX + 64; i += PTHR) bias_lds[i] = (a.bias && i < a.Ntot) ? a.bias[i] : 0.f;
         if (ptid < 48) xs[(ptid / 24) * XS_F4 + XS_PLANE(0, (ptid / 12) & 1) + NPIX + ptid % 12] = u32x4{0u, 0u, 0u, 0u};
         dma_weights(cur, 0, 0, true);
-        load_halo(cur, 0);
-#pragma unroll
-        for (int k = 0; k < NSLOT; ++k) stage_slot(k, 0);
-        {
-            const Ck n1 = chunk_at(1);
-            load_halo(n1.tile, n1.g);                               // (past the end: the current chunk again, harmless)
-        }
-        __builtin_amdgcn_s_waitcnt(H2S_VMCNT(2 * NSLOT));           // the weights; chunk 1's halo stays in flight
+        load_halo(std::integral_constant<int, 0>{}, cur, 0);
+        stage(std::integral_constant<int, 0>{}, 0);
+        static_for<1, (NS > 1 ? NS : 2)>([&](auto jt) {             // (past the end: the current chunk again, harmless)
+            constexpr int j = decltype(jt)::value;
+            const Ck nj = chunk_at(jt);
+            load_halo(std::integral_constant<int, j % NS>{}, nj.tile, nj.g);
+        });
+        __builtin_amdgcn_s_waitcnt(H2S_VMCNT(2 * NSLOT * (NS > 1 ? NS - 1 : 1)));      // the weights; the halos stay in flight
         H2S_BARRIER();                                            // barrier 0: chunk 0 may start
         int img = 0, st = 0;                                        // image / weight stage of the current chunk
 #ifdef H2S_STAMPS
         long long t_work = 0, t_wait = 0, t_bar = 0, tlast_ = clock64(), tall = tlast_; int nch = 0;
 #endif
-        for (;;) {
-            const Ck n1 = chunk_at(1), n2 = chunk_at(2);
+        // One period = the consumers run chunk c: the weights of chunk c + 1 into the other stage (the consumers left it at the last barrier);
+        //   NS = 1: the halo of chunk c + 1 (requested at the end of period c - 1) is split into the other image, then chunk c + 2's is requested;
+        //   NS > 1: chunk c + NS's halo is requested FIRST, into the register set chunk c was split out of a period ago, then chunk c + 1's
+        //           (set (c + 1) % NS, in flight for NS - 1 whole periods) is split.
+        // In front of the barrier the weights must have landed: vmcnt(what was issued behind them).  The loop is unrolled NS times (P = c % NS).
+        auto period = [&](auto ptag) {
+            constexpr int P = decltype(ptag)::value;
+            const Ck n1 = chunk_at(K1{}), nl = chunk_at(std::integral_constant<int, (NS > 1 ? NS : 2)>{});
 #ifdef H2S_STAMPS
             ++nch;
 #endif
-            // While the consumers run chunk c: the weights of chunk c + 1 into the other stage (the consumers left it at the last barrier), the
-            // halo of chunk c + 1 (in flight for a whole chunk) split into the other image, then chunk c + 2's halo is requested.  In front of
-            // the barrier the weights must have landed: vmcnt(what was issued behind them).
             dma_weights(n1.tile, n1.g, st ^ 1, n1.ok);
-#pragma unroll
-            for (int k = 0; k < NSLOT; ++k) stage_slot(k, img ^ 1);
-            load_halo(n2.tile, n2.g);
+            if constexpr (NS == 1) {
+                stage(std::integral_constant<int, 0>{}, img ^ 1);
+                load_halo(std::integral_constant<int, 0>{}, nl.tile, nl.g);
+            } else {
+                load_halo(ptag, nl.tile, nl.g);
+                stage(std::integral_constant<int, (P + 1) % NS>{}, img ^ 1);
+            }
             H2S_T(t_work)
             __builtin_amdgcn_s_waitcnt(H2S_VMCNT(2 * NSLOT));
             H2S_T(t_wait)
-            if (!n1.ok) break;                                      // (the consumers' epilogue and exit need no barrier)
+            if (!n1.ok) return false;                               // (the consumers' epilogue and exit need no barrier)
             H2S_BARRIER();
             H2S_T(t_bar)
             if (g == nchunks - 1) next_tile(); else ++g;
             img ^= 1; st ^= 1;
+            return true;
+        };
+        for (;;) {
+            if (!period(std::integral_constant<int, 0>{})) break;
+            if constexpr (NS > 1) { if (!period(std::integral_constant<int, 1>{})) break; }
+            if constexpr (NS > 2) { if (!period(std::integral_constant<int, 2>{})) break; }
         }
 #ifdef H2S_STAMPS
         if (lane == 0) {
@@ -719,7 +759,7 @@ igemm_h2s_kernel(const H2Args ha) {
     H2S_BARRIER();                                                // barrier 0
     H2S_T(t_bar)
     for (;;) {
-        const Ck n1 = chunk_at(1);
+        const Ck n1 = chunk_at(K1{});
 #ifdef H2S_STAMPS
         ++nch;
 #endif
@@ -780,6 +820,16 @@ extern "C" int64_t pnnp_h2_bits_words(int B, int H, int W, int C) {
     return (int64_t)B * ((H + TH - 1) / TH) * ((W + 31) / 32) * ((C + 31) / 32) * NCW * 64;
 }
 
+// 64-column tiles unless the layer has fewer channels or they would leave CUs idle (csrc/conv_x3.hip); the pooled forward keeps 64 whenever it can
+extern "C" int pnnp_h2_tile_columns(int B, int H, int W, int N, int pool) {
+    if (N < 64) return 32;
+    if (pool) return 64;
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int64_t tiles64 = (int64_t)((W + 31) / 32) * ((H + TH - 1) / TH) * B * ((N + 63) / 64);
+    return tiles64 * 4 >= (int64_t)cus * 3 ? 64 : 32;
+}
+
 // Validates like pnnp_igemm_x3_launch (csrc/conv_x3.hip); a.g.w: the h2 pack of csrc/pack_jobs.hip (kind 4).
 int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
     const IgemmArgs& a = ha.g;
@@ -813,13 +863,9 @@ int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
             a.OW != a.DW || (a.pool_cs & 3) || a.pool_cs < a.Ntot || ((uintptr_t)a.pool_dst & 15) || ((uintptr_t)a.pool_codes & 3) || ha.bits_in[0] || ha.bits_in[1])
             return PNNP_E_UNSUPPORTED;
         if ((int64_t)(a.OH / 2) * (a.OW / 2) * a.pool_cs * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
-        return a.Ntot >= 64 ? launch_h2s<64, EK_POOL>(b, s) : launch_h2s<32, EK_POOL>(b, s);
+        return pnnp_h2_tile_columns(a.B, a.DH, a.DW, a.Ntot, 1) == 64 ? launch_h2s<64, EK_POOL>(b, s) : launch_h2s<32, EK_POOL>(b, s);
     }
-    // 64-column tiles unless they leave CUs idle (csrc/conv_x3.hip)
-    int cus = pnnp_device_cus();
-    if (cus < 1) cus = 256;
-    const int64_t tiles64 = (int64_t)((a.DW + 31) / 32) * ((a.DH + TH - 1) / TH) * a.B * ((a.Ntot + 63) / 64);
-    const bool wide = a.Ntot >= 64 && tiles64 * 4 >= (int64_t)cus * 3;
+    const bool wide = pnnp_h2_tile_columns(a.B, a.DH, a.DW, a.Ntot, 0) == 64;
     const bool plain = !a.addsrc && !a.accum[0] && !(two && a.accum[1]);
     const bool m0 = a.mask_mode[0] != 0, m1 = two && a.mask_mode[1] != 0;
     const bool f0 = m0 && !ha.bits_in[0], f1 = m1 && !ha.bits_in[1];           // float32 masks

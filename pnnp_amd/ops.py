@@ -10,16 +10,18 @@ from ._lib import check, lib, ptr, require_cuda, stream
 _i64 = C.c_int64
 
 # Optional per-launch timing with HIP events on the launching stream (bench.py turns it on):
-# PROFILE = [] collects (kind, algorithmic_flops, algorithmic_bytes, start_event, end_event).
+# PROFILE = [] collects (kind, algorithmic_flops, algorithmic_bytes, start_event, end_event, sub); `sub` names the kernel instantiation
+# a launch class resolves to where that matters for its roofline ('bn32' / 'bn64': pnnp_h2_tile_columns), else ''.
 PROFILE = None
 PROFILE_KINDS = None        # None: every launch class; a set: only those (bench.py times just the dominant kernel in its timed region)
 
 
 class _Timed:
-    def __init__(self, kind, flops=0.0, nbytes=0.0):
+    def __init__(self, kind, flops=0.0, nbytes=0.0, sub=None):
         self.rec = None
         if PROFILE is not None and (PROFILE_KINDS is None or kind in PROFILE_KINDS):
-            self.rec = (kind, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.rec = (kind, float(flops), float(nbytes), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                        sub() if callable(sub) else (sub or ''))
 
     def __enter__(self):
         if self.rec is not None:
@@ -31,9 +33,16 @@ class _Timed:
             PROFILE.append(self.rec)
 
 
+ABI_VERSION = 6                 # the PNNP_ABI_VERSION of include/pnnp_hip.h these wrappers (and the PackJob mirror below) were written against
+
+
 def _prep():
     L = lib()
     if not getattr(L, '_pnnp_sigs', False):
+        got = L.pnnp_abi_version() if hasattr(L, 'pnnp_abi_version') else None
+        if got != ABI_VERSION or L.pnnp_pack_job_bytes() != C.sizeof(PackJob):
+            raise _lib.PnnpError(f'{_lib.LIB_PATH}: ABI version {got} / PnnpPackJob of {L.pnnp_pack_job_bytes() if got else "?"} bytes, these bindings '
+                                 f'were written for version {ABI_VERSION} / {C.sizeof(PackJob)} bytes: rebuild the library (tools/build.py)')
         L.pnnp_wgrad_workspace_floats.restype = C.c_int64
         L.pnnp_wino_weight_floats.restype = C.c_int64
         L.pnnp_wino_wgrad_workspace_floats.restype = C.c_int64
@@ -282,12 +291,17 @@ def amax(x, slot):
     return slot
 
 
+def h2_tile_columns(B, H, W, N, pool=False):
+    """GEMM columns per workgroup tile the fp16x2 3x3 kernel picks for this map (32: the HBM-bound instantiations; pnnp_h2_tile_columns)."""
+    return int(_prep().pnnp_h2_tile_columns(int(B), int(H), int(W), int(N), int(bool(pool))))
+
+
 def conv_h2_fwd(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, amax_x2=None, amax_y=None, bits_y=None, residual=None):
     """3x3 / stride 1 / pad 1 forward on the fp16 matrix cores, fp32 operands split in two scaled pieces (contract of conv_fwd, taps=9)."""
     require_cuda(x1, x2, w_h2, y, amax_w, amax_x1)
     B, H, W, C1 = x1.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout), sub=lambda: 'bn%d' % h2_tile_columns(B, H, W, cout)):
         check(_prep().pnnp_conv3x3_h2_fwd_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(residual),
                                               ptr(y), ptr(amax_y), ptr(bits_y), B, H, W, cout, act, stream()), 'conv_h2_fwd')
     return y
@@ -297,7 +311,8 @@ def conv_h2_fwd_pool(x1, x2, w_h2, amax_w, bias, y, pooled, codes, cout, act, am
     require_cuda(x1, x2, w_h2, y, pooled, codes, amax_w, amax_x1)
     B, H, W, C1 = x1.shape
     C2 = x2.shape[3] if x2 is not None else 0
-    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout)):
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + 1.25 * cout) + B * H * W * cout / 4,
+                sub=lambda: 'bn%d' % h2_tile_columns(B, H, W, cout, True)):      # (+ the pooled map and its one-byte codes)
         check(_prep().pnnp_conv3x3_h2_fwd_pool_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y),
                                                    ptr(pooled), ptr(codes), ptr(amax_y), ptr(bits_y), B, H, W, cout, act, stream()), 'conv_h2_fwd_pool')
     return y
@@ -309,7 +324,7 @@ def conv_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx1, mask1=None, bits1=None,
     B, H, W, Cout = g.shape
     C1 = dx1.shape[3]
     C2 = dx2.shape[3] if dx2 is not None else 0
-    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout)):
+    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + Cout), sub=lambda: 'bn%d' % h2_tile_columns(B, H, W, C1 + C2)):
         check(_prep().pnnp_conv3x3_h2_bwd_data_f32(ptr(g), Cout, ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w),
                                                    ptr(dx1), C1, ptr(mask1), ptr(bits1), mode1, accum1, ptr(amax_dx1),
                                                    ptr(dx2), C2, ptr(mask2), ptr(bits2), mode2, accum2, ptr(amax_dx2), B, H, W, stream()), 'conv_h2_bwd_data')
@@ -319,7 +334,7 @@ def conv_h2_bwd_data_res(g, amax_g, w_h2_dgrad, amax_w, dx, addsrc, mask=None, m
     require_cuda(g, w_h2_dgrad, dx, addsrc, amax_g, amax_w)
     B, H, W, Cout = g.shape
     C1 = dx.shape[3]
-    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout)):
+    with _Timed('conv9_dgrad_h2', 2.0 * B * H * W * Cout * C1 * 9, 4.0 * B * H * W * (2 * C1 + Cout), sub=lambda: 'bn%d' % h2_tile_columns(B, H, W, C1)):
         check(_prep().pnnp_conv3x3_h2_bwd_data_res_f32(ptr(g), Cout, ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), C1, ptr(addsrc), ptr(mask), mode,
                                                        ptr(amax_dx), B, H, W, stream()), 'conv_h2_bwd_data_res')
 
