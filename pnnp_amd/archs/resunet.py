@@ -235,7 +235,7 @@ class ResUnetEngine(_EngineBase):
         a['x8'] = ops.nchw_to_nhwc(x, g('x8', (B, H, Wd, self.cin_pad)), self.cin_pad, reflect_pad=reflect_pad)
         # fp16x2 family (csrc/h2.h): amax slots of the activations, keyed by the layer that wrote the tensor; sign bits of the ReLU outputs
         # that backward-data will need as masks
-        h2_on = bool(self.WH)
+        h2_on = bool(self.WH) or bool(self.WM)       # amax-slot upkeep whenever ANY layer runs on an fp16x2 kernel
         if h2_on:
             bufs.slots('f', dev).zero_()
         sl = lambda n: bufs.slot('f', n, dev)
@@ -339,7 +339,7 @@ class ResUnetEngine(_EngineBase):
                 on_ready(self.params.slices[pname][0])
 
         # fp16x2 family: amax slots of the gradients (zeroed per backward), the activations' slots are the forward's
-        h2_on = bool(self.WH)
+        h2_on = bool(self.WH) or bool(self.WM)       # amax-slot upkeep whenever ANY layer runs on an fp16x2 kernel
         if h2_on:
             bufs.slots('b', dev).zero_()
         src_name = a.get('_src_name', {})

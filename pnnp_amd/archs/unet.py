@@ -104,6 +104,7 @@ class _EngineBase:
 
     def _init_base(self):
         self.policy = ConvPolicy(*DEFAULT_POLICY.key()[:7])
+        self._h2_sub = {}            # explicit set_policy(h2_wgrad= / h2_pointwise=) overrides: they survive later set_policy calls
         self._pol = self.policy      # the effective policy of the current forward (effective_policy)
         self.saved = None
         self.gen = 0                 # bumped by every forward that (re)writes an activation buffer set
@@ -116,11 +117,13 @@ class _EngineBase:
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
+            for k in ('h2_wgrad', 'h2_pointwise'):                 # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
+                if k in kw:
+                    self._h2_sub[k] = bool(kw.pop(k))
             cur.update(kw)
-            h2w = cur.pop('h2_wgrad', None)
-            policy = ConvPolicy(**cur)
-            if h2w is not None:
-                policy.h2_wgrad = bool(h2w) and policy.h2
+            policy = ConvPolicy(**cur)                             # (defaults of the sub-switches: environment, as at construction)
+            for k, v in self._h2_sub.items():
+                setattr(policy, k, v and policy.h2)
         self.policy = self._pol = policy
         self._pack_key = None        # re-pack for the other kernel family
         self._jobs_key = None
@@ -136,6 +139,42 @@ class _EngineBase:
             raise PnnpError(f'frame {H} x {W} is too large for the HIP convolution kernels: one image of a {cs_max}-channel map must stay '
                             f'below 2 GB ((H + 4) * W * {cs_max} * 4 bytes); run the frame in tiles')
         return self.policy
+
+    def h2_range_report(self, sample=1 << 22):
+        """Debug aid for the fp16x2 family's ONE precision caveat (csrc/h2.h): the scale is per TENSOR, so elements below
+        2^-18 of a tensor's largest magnitude keep only absolute accuracy (2^-40 of that maximum).  After a training forward + backward this walks the
+        tensors the kernels split on the fly -- the saved activations and the gradient buffers of that step -- and returns, per tensor,
+        ``dict(name, kind, amax, median, log2_ratio = log2(amax / median |x|), frac_small, l2_small)``: ``median`` over the non-zero elements
+        of a strided sample, ``frac_small`` the share of non-zero elements below 2^-18 amax, ``l2_small`` the share of the tensor's sum of squares they
+        carry (what an output that depends on them alone would lose).  Plain torch ops: for tools and tests (tools/soak.py), never on the hot path."""
+        if self.saved is None:
+            raise PnnpError('h2_range_report: no saved training forward')
+        a, key, _ = self.saved
+        rows = []
+
+        def add(name, kind, t):
+            if not torch.is_tensor(t) or t.dtype != torch.float32 or t.dim() != 4:
+                return
+            v = t.reshape(-1)
+            amax = float(v.abs().max())
+            step = max(1, v.numel() // sample)
+            sv = v[::step].abs()
+            nz = sv[sv > 0]
+            if amax == 0.0 or nz.numel() == 0 or not torch.isfinite(sv).all():
+                rows.append(dict(name=name, kind=kind, amax=amax, median=0.0, log2_ratio=float('nan'), frac_small=0.0, l2_small=0.0))
+                return
+            med = float(nz.median())
+            small = nz < amax * 2.0 ** -18
+            rows.append(dict(name=name, kind=kind, amax=amax, median=med, log2_ratio=float(torch.log2(torch.tensor(amax / med))),
+                             frac_small=float(small.float().mean()), l2_small=float((nz[small] ** 2).sum() / (nz ** 2).sum())))
+
+        for k, t in a.items():
+            if isinstance(k, str) and not k.startswith(('bits:', 'pc', '_')):
+                add(k, 'act', t)
+        for k, t in self.bufs[key].t.items():
+            if isinstance(k, str) and k.startswith('g_') and k != 'g_out8':
+                add(k, 'grad', t)
+        return rows
 
     def mark_dirty(self):
         """Parameters were modified behind torch's back (fused Adam on the flat buffer)."""
@@ -389,7 +428,7 @@ class UNetEngine(_EngineBase):
         a = {}
         # fp16x2 family: amax slots of the activations (keyed by the name of the layer that wrote the tensor; a pooled map shares its
         # full-resolution map's slot) and, in a training forward, the sign bits of every LeakyReLU output that backward-data will need
-        h2_on = bool(self._h2)
+        h2_on = bool(self._h2) or bool(self._h2m)     # amax-slot upkeep whenever ANY layer runs on an fp16x2 kernel (3x3 or pointwise)
         if h2_on:
             bufs.slots('f', dev).zero_()
         sl = lambda n: bufs.slot('f', n, dev)
@@ -524,7 +563,7 @@ class UNetEngine(_EngineBase):
         wsf = bufs.get('wgrad_ws', (self._ws_floats(B, H, W),), dev)
 
         # fp16x2 family: amax slots of the gradients (keyed by the buffer name), zeroed per backward; the activations' slots are the forward's
-        h2_on = bool(self._h2)
+        h2_on = bool(self._h2) or bool(self._h2m)
         if h2_on:
             bufs.slots('b', dev).zero_()
         src_name = a.get('_src_name', {})

@@ -74,6 +74,9 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #ifndef H2S_TURNS
 #define H2S_TURNS 0                  // 1: the two consumer waves of a SIMD take turns with a tile's epilogue (see the consumers' loop): measured 1-3 % SLOWER, off
 #endif
+#ifndef H2S_ABL
+#define H2S_ABL 0                    // timing ablations of the FWD / BWDB epilogue (results are WRONG with any bit set; tools/scratch builds only):
+#endif                               // 1 no line trade, 2 no sign bits, 4 no amax tracking, 8 accumulators not zeroed, 16 no stores, 32 no activation / mask
 #ifndef H2S_NSETS
 #define H2S_NSETS 2                  // producer register sets for the halo tile: 1 = a chunk's halo is requested at the END of the period before the one that splits it (round 5),
 #endif                               // 2 / 3 = at the START of that period / a period earlier still (profiles/r6/ab_producer_sets.txt)
@@ -478,11 +481,13 @@ igemm_h2s_kernel(const H2Args ha) {
                     for (int c = 0; c < 4; ++c) acc[mb][j][c] = __builtin_ldexpf(acc[mb][j][c], ea.dexp - dexp_c);
         }
         auto take = [&](int mb, int j) {                             // the block, un-scaled, and the accumulator zeroed for the next tile
-            const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = acc[mb][j];
+            if constexpr (!(H2S_ABL & 8)) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             return v * dsc;
         };
         auto take_bias = [&](int mb, int j, f32x4 bias) {            // ... with the bias: one fma per element
-            const f32x4 v = acc[mb][j]; acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 v = acc[mb][j];
+            if constexpr (!(H2S_ABL & 8)) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             return f32x4{__builtin_fmaf(v.x, dsc, bias.x), __builtin_fmaf(v.y, dsc, bias.y), __builtin_fmaf(v.z, dsc, bias.z), __builtin_fmaf(v.w, dsc, bias.w)};
         };
         // max |.| of the blocks of one destination: a running maximum per 32-column block (two v_max3_f32 per float4), merged into the lane's
@@ -491,6 +496,7 @@ igemm_h2s_kernel(const H2Args ha) {
         // two selects per float4.
         float amk = 0.f;
         auto track = [&](f32x4 o) {
+            if constexpr (H2S_ABL & 4) return;
             amk = fmaxf(fmaxf(amk, fabsf(o.x)), fabsf(o.y));
             amk = fmaxf(fmaxf(amk, fabsf(o.z)), fabsf(o.w));
         };
@@ -506,6 +512,8 @@ igemm_h2s_kernel(const H2Args ha) {
         };
         // one element of the forward epilogue: shift (o > 0) into sb; with an activation o = (o > 0) ? o : slope o on the same compare
         auto act_sign = [](float& o, unsigned& sb, float slope_, auto act_tag) __attribute__((always_inline)) {
+            if constexpr (H2S_ABL & 32) return;
+            if constexpr (H2S_ABL & 2) { if constexpr (decltype(act_tag)::value) o = fmaxf(o, o * slope_); return; }
             unsigned long long cout_;
             if constexpr (decltype(act_tag)::value) {
                 float t;
@@ -517,6 +525,7 @@ igemm_h2s_kernel(const H2Args ha) {
         };
         // one element of the bit-masked backward epilogue: the next bit of mb out (carry of mb + mb), o = bit ? o : msl o
         auto mask_bit = [](float& o, unsigned& mb_, float msl) __attribute__((always_inline)) {
+            if constexpr (H2S_ABL & 32) return;
             float t;
             asm("v_add_co_u32 %1, vcc, %1, %1\n\tv_mul_f32 %2, %3, %0\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(o), "+v"(mb_), "=&v"(t) : "v"(msl) : "vcc");
         };
@@ -695,7 +704,8 @@ igemm_h2s_kernel(const H2Args ha) {
                                 for (int c = 0; c < 4; ++c) { float e = o1[c]; mask_bit(e, mbits[k], msl); o1[c] = e; }
                             }
                             track(o0); track(o1);
-                            trade(o0, o1);
+                            if constexpr (!(H2S_ABL & 1)) trade(o0, o1);
+                            if constexpr (H2S_ABL & 16) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rd, wo[k][i][h], 0, H2S_STORE_AUX);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
                         }

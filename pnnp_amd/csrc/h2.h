@@ -7,6 +7,10 @@
 //   products (exact in the fp32 accumulator) where the bf16x3 family needs six; the dropped lo lo' is below 2^-22 |a b|.  Against float64
 //   the scheme is at the fp32-MFMA kernels' error or below for every reduction length the networks have (profiles/r5/h2_probe.txt).
 //
+// Both pieces are FLOATING-point numbers -- hi the element's top 11 significand bits, lo its next 11 -- so the scale only matters where lo leaves fp16's
+// normal range: for every element within 2^-18 of the maximum the split, the products and the result are the same numbers times a power of two
+// WHATEVER scale was used (a crop's results are bit-identical alone and beside batch-mates up to 2^18 = 2.6e5 x brighter: tests/test_gpu_dp2.py).
+//
 // The scale needs max|a| of the tensor BEFORE the kernel that splits it starts: every kernel that writes a tensor the h2 kernels read also
 // writes max|.| of what it stored into a 4-byte slot (atomicMax on the float's bit pattern: non-negative floats order like unsigned
 // integers).  Slots are zeroed by the caller once per pass.  A slot that is too LARGE only costs range at the small end; one that is

@@ -432,3 +432,82 @@ def test_h2_wgrad_is_as_accurate_as_the_fp32_mfma_kernel(shape):
     print(f'wgrad {shape} vs float64: rel L2 h2 {e2:.2e} fp32-MFMA {e32:.2e}; max-element (per (co,ci) scale) h2 {m2:.2e} fp32-MFMA {m32:.2e}')
     assert e2 < 2.0 * e32 + 1e-8, (e2, e32)
     assert m2 < 2.0 * m32 + 1e-7, (m2, m32)
+
+
+# ---------------------------------------------------------------- the family's one caveat, in all three directions
+def test_h2_wide_range_inside_one_tensor_backward_data():
+    """Backward-data with one GRADIENT channel at 1e+6 x the others: dx channels whose filters ignore that channel keep 1e-5 relative (the absolute
+    error 2^-40 x max of the small elements), the channels that see it are at float32 level -- the same contract as the forward test above."""
+    B, H, W, Ci, Co = 1, 8, 32, 32, 64
+    gen = torch.Generator().manual_seed(8)
+    g = torch.randn(B, Co, H, W, generator=gen); g[:, 0] *= 1e6
+    w = torch.randn(Co, Ci, 3, 3, generator=gen) * 0.1; w[0, :16] = 0.0
+    ref = F.conv_transpose2d(g.double(), w.double(), None, padding=1)
+    y2, y32 = _both(g, w, dgrad=True)
+    e_blind = float((y2[:, :16] - ref[:, :16]).norm() / ref[:, :16].norm())
+    e_see = float((y2[:, 16:] - ref[:, 16:]).norm() / ref[:, 16:].norm())
+    e32 = float((y32[:, :16] - ref[:, :16]).norm() / ref[:, :16].norm())
+    print(f'dgrad, one channel 1e6 x the others: rel L2 of dx channels that ignore it {e_blind:.2e} (fp32-MFMA {e32:.2e}), that see it {e_see:.2e}')
+    assert torch.isfinite(y2).all() and e_blind < 1e-5 and e_see < 5e-7
+
+
+def _wgrad_both(g, x):
+    """(h2, fp32-MFMA, float64) weight gradient of a 3x3 layer from NHWC CUDA tensors."""
+    from pnnp_amd import ops
+    from test_gpu_x3 import _f64_wgrad
+    B, H, W, Co = g.shape
+    Ci = x.shape[3]
+    ws = torch.empty(max(ops.x3_wgrad_workspace_floats(B, H, W, Co, Ci), ops.wgrad_workspace_floats(B, H, W, Co, Ci, 9)), device='cuda')
+    d2 = torch.empty(Co, Ci, 3, 3, device='cuda'); d32 = torch.empty_like(d2)
+    ops.conv_h2_bwd_weight(g, _slot(g), Co, x, _slot(x), Ci, None, None, d2, None, ws)
+    ops.conv_bwd_weight(g, Co, x, Ci, None, d32, None, 9, ws)
+    return d2.double(), d32.double(), _f64_wgrad(g, x)
+
+
+def test_h2_wide_range_inside_one_tensor_backward_weight():
+    """Backward-weight with one activation channel AND one gradient channel at 1e+6 x the others.  A weight's gradient is a sum of products g x: where
+    at least one factor is a SMALL element of its tensor (absolute accuracy 2^-40 x max = relative 1e-6 of itself) the product inherits that -- dW[1:, 1:],
+    dW[1:, 0] and dW[0, 1:] keep 1e-5 relative against float64 sums (measured 2-5e-6); only dW[0, 0], large x large, is at float32 level."""
+    B, H, W, Ci, Co = 2, 32, 64, 32, 32
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen); x[..., 0] *= 1e6
+    g = torch.randn(B, H, W, Co, device='cuda', generator=gen); g[..., 0] *= 1e6
+    d2, d32, ref = _wgrad_both(g, x)
+    rel = lambda d, sl: float((d[sl] - ref[sl]).norm() / ref[sl].norm())
+    blind, col, row, big = (slice(1, None), slice(1, None)), (slice(1, None), slice(0, 1)), (slice(0, 1), slice(1, None)), (slice(0, 1), slice(0, 1))
+    print(f'wgrad, channel 0 of x and of g 1e6 x the others: rel L2 vs float64 of dW[1:,1:] {rel(d2, blind):.2e} (fp32-MFMA {rel(d32, blind):.2e}), '
+          f'dW[1:,0] {rel(d2, col):.2e}, dW[0,1:] {rel(d2, row):.2e}, dW[0,0] {rel(d2, big):.2e}')
+    assert torch.isfinite(d2).all() and rel(d2, blind) < 1e-5 and rel(d2, col) < 1e-5 and rel(d2, row) < 1e-5 and rel(d2, big) < 5e-7
+
+
+@pytest.mark.parametrize('direction', ['fwd', 'dgrad', 'wgrad'])
+def test_h2_single_outlier_bounds_the_damage(direction):
+    """ONE element at 1e+8 x the rest of its tensor (a hot pixel times ratio, a gradient spike: ADVICE round 5).  The other elements sit 2^-26.6 below the
+    maximum: their split keeps an ABSOLUTE accuracy of 2^-40 x 1e8 = 9e-5 (csrc/h2.h), i.e. ~13 bits -- the documented price of ONE scale per tensor.  The test
+    pins that bound (outputs that do not touch the outlier: relative L2 below 2^-40 x 1e8 = 9.1e-5, finite, no saturation) and that the outputs that DO see it are at
+    float32 level relative to their own size; it also prints what the exact bf16x3 / fp32 kernels give, which is what `set_policy(h2=False)` buys."""
+    gen = torch.Generator().manual_seed(10)
+    bound = 2.0 ** -40 * 1e8
+    if direction in ('fwd', 'dgrad'):
+        B, H, W, Ca, Cb = 1, 16, 32, 64, 32
+        a = torch.randn(B, Ca, H, W, generator=gen); a[0, 3, 8, 16] = 1e8
+        w = torch.randn(Cb, Ca, 3, 3, generator=gen) * 0.1 if direction == 'fwd' else torch.randn(Ca, Cb, 3, 3, generator=gen) * 0.1
+        ref = F.conv2d(a.double(), w.double(), None, padding=1) if direction == 'fwd' else F.conv_transpose2d(a.double(), w.double(), None, padding=1)
+        y2, y32 = _both(a, w, dgrad=direction == 'dgrad')
+        near = torch.zeros(H, W, dtype=torch.bool); near[7:10, 15:18] = True          # the 3 x 3 pixels the outlier reaches
+        far = ~near
+        e_far, e32_far = float((y2[..., far] - ref[..., far]).norm() / ref[..., far].norm()), float((y32[..., far] - ref[..., far]).norm() / ref[..., far].norm())
+        e_near = float((y2[..., near] - ref[..., near]).norm() / ref[..., near].norm())
+        print(f'{direction}, one element 1e8: rel L2 away from it {e_far:.2e} (fp32-MFMA {e32_far:.2e}; bound {bound:.1e}), at the pixels it reaches {e_near:.2e}')
+        assert torch.isfinite(y2).all() and e_far < bound and e_near < 5e-7
+    else:
+        B, H, W, Ci, Co = 2, 32, 64, 32, 32
+        gc = torch.Generator(device='cuda').manual_seed(11)
+        x = torch.randn(B, H, W, Ci, device='cuda', generator=gc); x[1, 5, 9, 2] = 1e8
+        g = torch.randn(B, H, W, Co, device='cuda', generator=gc)
+        d2, d32, ref = _wgrad_both(g, x)
+        oth = [c for c in range(Ci) if c != 2]
+        e_oth, e32_oth = float((d2[:, oth] - ref[:, oth]).norm() / ref[:, oth].norm()), float((d32[:, oth] - ref[:, oth]).norm() / ref[:, oth].norm())
+        e_hit = float((d2[:, 2] - ref[:, 2]).norm() / ref[:, 2].norm())
+        print(f'wgrad, one element of x 1e8: rel L2 of the other input channels: weights {e_oth:.2e} (fp32-MFMA {e32_oth:.2e}; bound {bound:.1e}), of channel 2 {e_hit:.2e}')
+        assert torch.isfinite(d2).all() and e_oth < bound and e_hit < 5e-7

@@ -2,7 +2,6 @@
 overlapped with the backward pass, base_trainer.py:115-118).  The 1-GPU boxes cannot run RCCL with two ranks, so a kernel that
 occupies k CUs stands in for the collective (tools/ubench/squat.hip)."""
 import os
-import shutil
 import sys
 
 import pytest
@@ -13,21 +12,24 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 pytestmark = pytest.mark.gpu
 
 
-def test_persistent_split_is_bit_identical_and_reports_the_cost_of_occupied_cus(tmp_path):
+def test_persistent_split_is_bit_identical_and_reports_the_cost_of_occupied_cus():
     """With one workgroup per CU and static shares, the workgroups whose CUs are occupied start when the others have FINISHED and the
     layer takes about twice as long.  With pnnp_set_persistent_split(4) the hardware dispatcher hands the quarter shares to whichever
     CU frees up.  The HARD check is the contract: the split changes which workgroup runs a tile, never a result bit.  The wall-clock
     ratios depend on the dispatcher, clocks, the power state and box noise, so they are printed (and kept per round in
-    profiles/r*/squat_test.txt from `python tools/squat_test.py 32`: measured x 1.45 beside a kernel on 32 CUs with static shares,
-    x 1.04-1.05 with quarter shares, 6-14 % for the split alone on the chip) and only a gross failure of the mechanism -- quarter
-    shares beside the squatter SLOWER than 1.5 x the static ones -- fails the test."""
-    if not (shutil.which('hipcc') or os.path.exists('/opt/rocm/bin/hipcc')):
-        pytest.skip('hipcc not available to build the occupying kernel')
+    profiles/r*/squat_test.txt from `python tools/squat_test.py 32`: measured x 1.38-1.50 beside a kernel on 32 CUs with static shares,
+    x 0.99-1.08 with quarter shares, 6-14 % for the split alone on the chip).  The SOFT check that the mechanism still helps:
+    beside the squatter the quarter shares must be at least 5 % faster than the static ones (measured: 25-30 %; medians of 5 repetitions).
+    The occupying kernel (tools/ubench/libsquat.so) is built by tools/build.py with the library -- never from this process, which has
+    initialised the GPU by the time the suite gets here."""
     import squat_test
-    r = squat_test.measure(32, build_dir=str(tmp_path))
+    try:
+        r = squat_test.measure(32, may_build=False)
+    except FileNotFoundError as e:
+        pytest.skip(f'{e} not built (python tools/build.py)')
     print(r)
     assert r['same_result']
-    assert r['beside_4'] < 1.5 * r['beside_1'], r
+    assert r['beside_4'] <= 0.95 * r['beside_1'], r
 
 
 def test_persistent_split_covers_the_weight_gradient_too():

@@ -42,6 +42,11 @@ def build(verbose=True, force=False):
     objs = [os.path.join(OBJ, s[:-4] + '.o') for s in srcs]
     if force or jobs or newer(OUT, objs):
         run([HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', OUT] + objs)
+    # test / tool helper (not part of the product): the kernel that occupies k CUs beside a persistent grid (tools/squat_test.py,
+    # tests/test_gpu_overlap.py) -- built HERE so that no test has to spawn hipcc from a process that has initialised the GPU
+    sq_src, sq_so = os.path.join(REPO, 'tools', 'ubench', 'squat.hip'), os.path.join(REPO, 'tools', 'ubench', 'libsquat.so')
+    if os.path.exists(sq_src) and (force or newer(sq_so, [sq_src])):
+        run([HIPCC, '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', sq_so, sq_src])
     return OUT
 
 

@@ -22,19 +22,22 @@ from pnnp_amd import _lib, ops  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def squat_lib(build_dir=None):
-    """``build_dir``: where libsquat.so is built (tests pass a temporary directory: pytest writes nothing into the tree)."""
+def squat_lib(build_dir=None, may_build=True):
+    """tools/ubench/libsquat.so is built by tools/build.py together with the library (before any GPU call); ``may_build`` = False (the tests): never
+    spawn a compiler from this process, raise FileNotFoundError instead."""
     so = os.path.join(build_dir or os.path.join(HERE, 'ubench'), 'libsquat.so')
     src = os.path.join(HERE, 'ubench', 'squat.hip')
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        if not may_build:
+            raise FileNotFoundError(so)
         subprocess.check_call([os.environ.get('HIPCC', '/opt/rocm/bin/hipcc'), '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', so, src])
     L = C.CDLL(so)
     L.squat_launch.argtypes = [C.c_int, C.c_double, C.c_void_p]
     return L
 
 
-def measure(k=32, S=256, Ci=64, Co=64, B=16, reps=5, build_dir=None):
-    L = squat_lib(build_dir)
+def measure(k=32, S=256, Ci=64, Co=64, B=16, reps=5, build_dir=None, may_build=True):
+    L = squat_lib(build_dir, may_build)
     x = torch.randn(B, S, S, Ci, device='cuda'); w = torch.randn(Co, Ci, 3, 3, device='cuda') * 0.05; b = torch.randn(Co, device='cuda')
     wx = torch.empty(ops.x3_weight_bytes(Ci, Co), dtype=torch.uint8, device='cuda')
     jobs = ops.PackJobs(); jobs.add_x3(w, wx, None, cin_pad=Ci); jobs.run()
