@@ -238,6 +238,15 @@ int pnnp_pack_jobs_add_h2(PnnpPackJob* jobs, int* n, int cap, const float* w, vo
 int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
                             const void* w_h2, const unsigned* amax_w, const float* bias, const float* residual, float* y,
                             unsigned* amax_y /*or null*/, unsigned* bits_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
+/* The last 3x3 layer + LeakyReLU + the 1x1 head conv10_1 (archs/Unet.py:93-94; ResUnet: archs/ResUnet.py conv_out) in ONE kernel (round 6): Cout == 32
+ * (one workgroup tile holds every channel of a pixel), head_w [4][32] / head_b [4] are the parameters as they are, head_out NCHW [B][4][H][W] float32
+ * (+ head_res, NCHW like head_out: the `res` networks' input, or null).  y (the 32-channel map, with amax_y / bits_y as in pnnp_conv3x3_h2_fwd_f32) may be
+ * NULL: an eval forward neither writes nor re-reads it; a training forward passes it (backward needs it: pnnp_head_bwd_f32).  The head's sums run in
+ * float32 on the vector ALUs over the ACTIVATED float32 accumulators (the same arithmetic as pnnp_head_fwd_f32, another summation order). */
+int pnnp_conv3x3_h2_fwd_head_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
+                                 const void* w_h2, const unsigned* amax_w, const float* bias, float* y /*or null*/, unsigned* amax_y, unsigned* bits_y,
+                                 const float* head_w, const float* head_b /*or null*/, const float* head_res /*or null*/, float* head_out,
+                                 int B, int H, int W, int Cout, int act, void* stream);
 int pnnp_conv3x3_h2_fwd_pool_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
                                  const void* w_h2, const unsigned* amax_w, const float* bias, float* y, float* pooled, unsigned char* codes,
                                  unsigned* amax_y /*or null*/, unsigned* bits_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);

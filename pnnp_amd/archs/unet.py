@@ -41,9 +41,10 @@ class ConvPolicy:
         self.h2 = bool(h2)
         self.h2_wgrad = bool(h2) and os.environ.get('PNNP_H2_WGRAD', '1') != '0'      # (host-side A/B switch: backward-weight stays on bf16x3 with 0)
         self.h2_pointwise = bool(h2) and os.environ.get('PNNP_H2_POINTWISE', '1') != '0'      # (A/B switch: ConvTranspose2d stays on bf16x3 with 0)
+        self.head_fused = bool(h2) and os.environ.get('PNNP_HEAD_FUSED', '1') != '0'          # (A/B switch) conv10_1 inside conv9_2's epilogue (round 6)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise, self.head_fused)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -117,7 +118,7 @@ class _EngineBase:
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
-            for k in ('h2_wgrad', 'h2_pointwise'):                 # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
+            for k in ('h2_wgrad', 'h2_pointwise', 'head_fused'):   # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
                 if k in kw:
                     self._h2_sub[k] = bool(kw.pop(k))
             cur.update(kw)
@@ -372,6 +373,12 @@ class UNetEngine(_EngineBase):
             jobs.add_convt(w, f, d if need_dgrad else None)
         return jobs
 
+    def _head_fusable(self):
+        """conv10_1 inside conv9_2's epilogue (ops.conv_h2_fwd_head)?  nf = 32 (one 32-column tile holds a pixel's channels), 4 output planes, conv9_2 on
+        the fp16x2 kernel; reflect-padded eval frames included (the head writes the PADDED NCHW planes like head_fwd did)."""
+        return (self._pol.head_fused and self.ch[0] == 32 and self.cout == 4 and self._h2.get('conv9_2', (None, None))[0] is not None
+                and self.m.conv10_1.weight.shape[1] == 32)
+
     def _w(self, name):
         """(forward, backward-data) direct packs of a layer (ConvTranspose2d: the pair built by add_convt)."""
         dev = self.params.flat.device
@@ -530,10 +537,26 @@ class UNetEngine(_EngineBase):
                 u = ops.convt_fwd(cur, self._w(f'upv{i}')[0], P[f'upv{i}.bias'], g(f'u{i}', (B, hs[lvl], ws[lvl], ch[lvl])), ch[lvl])
                 a[f'u{i}'] = produced(u, f'upv{i}', fused=False)
             a[f'c{i}a'] = conv(f'conv{i}_1', u, a[f'c{lvl + 1}'], hs[lvl], ws[lvl], ch[lvl])
+            if i == 9 and self._head_fusable():
+                break
             a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
             cur = a[f'c{i}']
         out = torch.empty((B, self.cout, H, W), dtype=torch.float32, device=dev)
-        if self._pol.use_thin_head(ch[0], self.cout, B * H * W):
+        if 'c9' not in a:
+            # conv9_2 + LeakyReLU + conv10_1 in one kernel (csrc/conv_h2s.hip EK_HEAD): the 4 output planes come straight from the accumulators; the
+            # 32-channel map c9 is stored (with its sign bits and amax) only for a backward pass -- an eval forward neither writes nor re-reads it
+            name = 'conv9_2'
+            y = g(name, (B, H, W, ch[0])) if train else None
+            bits = bufs.bits(name, B, H, W, ch[0], dev) if train else None
+            if bits is not None:
+                a['bits:' + name] = bits
+            ops.conv_h2_fwd_head(a['c9a'], None, self._h2[name][0], self._wslot[name], P[name + '.bias'], y, ch[0], LRELU, sl(src_name[id(a['c9a'])]),
+                                 P['conv10_1.weight'], P['conv10_1.bias'], out, amax_y=sl(name) if train else None, bits_y=bits,
+                                 residual=x if (self.m.res and add_residual) else None)
+            if train:
+                a['c9'] = y
+                src_name[id(y)] = name
+        elif self._pol.use_thin_head(ch[0], self.cout, B * H * W):
             ops.head_fwd(a['c9'], P['conv10_1.weight'], P['conv10_1.bias'], out, residual=x if (self.m.res and add_residual) else None)
         else:
             o = conv('conv10_1', a['c9'], None, H, W, self.cout, act=0, taps=1, out=g('o', (B, H, W, self.cout)))

@@ -250,6 +250,22 @@ int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, co
     return pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
 }
 
+// conv3x3 + activation + the network's 1x1 head (archs/Unet.py:93-94: conv9_2, lrelu, conv10_1) in one kernel; y null: the 32-channel map is not stored
+int pnnp_conv3x3_h2_fwd_head_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
+                                 const void* w_h2, const unsigned* amax_w, const float* bias, float* y, unsigned* amax_y, unsigned* bits_y,
+                                 const float* head_w, const float* head_b, const float* head_res, float* head_out,
+                                 int B, int H, int W, int Cout, int act, void* stream) {
+    if (!x1 || !w_h2 || !head_w || !head_out || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1)) return PNNP_E_INVALID;
+    if (Cout != 32) return PNNP_E_UNSUPPORTED;
+    if (B == 0) return PNNP_OK;
+    H2Args a{};
+    fwd_args(a.g, x1, C1, x2, C2, w_h2, bias, nullptr, y, B, H, W, Cout, act);
+    a.amax_in[0] = amax_x1; a.amax_in[1] = x2 ? amax_x2 : nullptr; a.amax_w = amax_w; a.amax_out[0] = y ? amax_y : nullptr;
+    a.bits_out = y ? bits_y : nullptr; a.bits_nblk[0] = 1;
+    a.head_w = head_w; a.head_b = head_b; a.head_res = head_res; a.head_out = head_out;
+    return pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
+}
+
 int pnnp_conv3x3_h2_fwd_pool_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
                                  const void* w_h2, const unsigned* amax_w, const float* bias, float* y, float* pooled, unsigned char* codes,
                                  unsigned* amax_y, unsigned* bits_y, int B, int H, int W, int Cout, int act, void* stream) {

@@ -37,6 +37,7 @@ constexpr unsigned OOB = 0x80000000u;
 #define H2S_VMCNT(N) (0x0f70 | ((N) & 15) | (((N) >> 4) << 14))    // s_waitcnt vmcnt(N) alone
 #define H2S_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")      // (csrc/conv_x3s.hip: why not __syncthreads())
 
+constexpr int HEAD_LDS_FLOATS = 256;                               // (EK_HEAD) [4][32] head weights + [4] biases, padded
 template <int BN> struct SCfg {
     static constexpr int NT = BN / 32;
     static constexpr int WS_STAGE = NT * WBLK;                     // 19456 / 38912: one chunk's weights
@@ -44,7 +45,7 @@ template <int BN> struct SCfg {
     static constexpr int DPW = (NDMA + NPW - 1) / NPW;             // LDS-DMA instructions per producer wave and chunk: 5 / 10
     static constexpr int NSTAGE = 2;
     static constexpr int BIAS_MAX = 1024;                          // the layer's bias vector lives in LDS: at most this many output channels (the launcher checks)
-    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (BIAS_MAX + 64) * 4;      // 162048 / 123136
+    static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE + (BIAS_MAX + 64) * 4 + (BN == 32 ? HEAD_LDS_FLOATS * 4 : 0);      // 162048 / 124160
     static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
 };
 
@@ -87,7 +88,12 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #endif
 // the epilogue a kernel carries (one straight-line path each): forward (no mask, no accumulation, no residual; writes sign bits when asked),
 // masked backward-data with float32 masks / with bit masks, the general one, forward + MaxPool2d(2)
-enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3, EK_BWDB = 4 };
+enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3, EK_BWDB = 4, EK_HEAD = 5 };
+// EK_HEAD (32-column kernel only): the forward epilogue + the network's 1x1 head (archs/Unet.py:94: conv10_1, 32 -> 4 channels, no activation) computed from
+// the activated accumulators -- a lane holds 8 of a pixel's 32 channels, the 4 lanes of a pixel add their partial sums through two butterfly exchanges --
+// and written as the NCHW output planes (+ the `res` networks' input residual).  The 32-channel map itself is stored only when the caller asks for it
+// (a training forward: backward needs it); an eval forward never writes or re-reads it.
+
 
 // The 14 matrix instructions of a (chunk, 16 x 16 block): kind 0 = tap t0, pixels [hi | lo] x weights [hi' | hi'];  kind 1 / 2 = taps (t0, t0 + 1),
 // pixels [hi @ t0 | hi @ t0 + 1] x weights [lo' @ t0 | lo' @ t0 + 1] (the second tap's halo offset is + 1 pixel, or + 32 from tap 2 to tap 3);
@@ -107,6 +113,7 @@ igemm_h2s_kernel(const H2Args ha) {
     u32x4* xs = reinterpret_cast<u32x4*>(smem);                     // two halo images
     char* wsb = smem + 2 * XS_BYTES;                                // the weight ring: two chunk stages
     float* bias_lds = reinterpret_cast<float*>(smem + 2 * XS_BYTES + Cfg::NSTAGE * Cfg::WS_STAGE);      // bias[0 .. Ntot) (zeros without a bias)
+    float* head_lds = bias_lds + Cfg::BIAS_MAX + 64;                // (EK_HEAD) the head's weights [4][32] and biases [4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 0 .. 7 consumers, 8 .. 11 producers
@@ -254,6 +261,9 @@ igemm_h2s_kernel(const H2Args ha) {
         // for the last lane of the last row -- multiplied by the pack's zero tap, so it must be FINITE, not whatever bit pattern the LDS held), the weights
         // of chunk 0, chunk 0's halo straight into image 0, the halos of chunks 1 .. max(1, NS - 1) into the register sets
         for (int i = ptid; i < Cfg::BIAS_MAX + 64; i += PTHR) bias_lds[i] = (a.bias && i < a.Ntot) ? a.bias[i] : 0.f;
+        if constexpr (EK == EK_HEAD) {
+            if (ptid < 132) head_lds[ptid] = ptid < 128 ? ha.head_w[ptid] : (ha.head_b ? ha.head_b[ptid - 128] : 0.f);
+        }
         if (ptid < 48) xs[(ptid / 24) * XS_F4 + XS_PLANE(0, (ptid / 12) & 1) + NPIX + ptid % 12] = u32x4{0u, 0u, 0u, 0u};
         dma_weights(cur, 0, 0, true);
         load_halo(std::integral_constant<int, 0>{}, cur, 0);
@@ -371,7 +381,7 @@ igemm_h2s_kernel(const H2Args ha) {
     // the unrolled K loop leaves the compiler no scalar registers for them).  The layer's bias vector sits in LDS for the same reason.
     enum { E_OH, E_OW, E_DH, E_DW, E_NTOT, E_NSPLIT, E_ACT, E_POOLCS, E_CS0, E_CS1, E_MM0, E_MM1, E_AC0, E_AC1, E_DEXP, E_NBLK0, E_NBLK1,
            E_DST0, E_DST1 = E_DST0 + 2, E_MASK0 = E_DST1 + 2, E_MASK1 = E_MASK0 + 2, E_ADD = E_MASK1 + 2, E_PDST = E_ADD + 2,
-           E_PCODE = E_PDST + 2, E_BOUT = E_PCODE + 2, E_BIN0 = E_BOUT + 2, E_BIN1 = E_BIN0 + 2, E_COUNT = E_BIN1 + 2 };
+           E_PCODE = E_PDST + 2, E_BOUT = E_PCODE + 2, E_BIN0 = E_BOUT + 2, E_BIN1 = E_BIN0 + 2, E_HOUT = E_BIN1 + 2, E_HRES = E_HOUT + 2, E_COUNT = E_HRES + 2 };
     static_assert(E_COUNT <= 64, "one lane per cached argument");
     unsigned argv = 0;
     {
@@ -382,11 +392,13 @@ igemm_h2s_kernel(const H2Args ha) {
         put(E_AC0, a.accum[0]); put(E_AC1, a.accum[1]); put(E_DEXP, (unsigned)(-(se_x + se_w))); put(E_NBLK0, ha.bits_nblk[0]); put(E_NBLK1, ha.bits_nblk[1]);
         putp(E_DST0, a.dst[0]); putp(E_DST1, a.dst[1]); putp(E_MASK0, a.mask[0]); putp(E_MASK1, a.mask[1]); putp(E_ADD, a.addsrc);
         putp(E_PDST, a.pool_dst); putp(E_PCODE, a.pool_codes); putp(E_BOUT, ha.bits_out); putp(E_BIN0, ha.bits_in[0]); putp(E_BIN1, ha.bits_in[1]);
+        putp(E_HOUT, ha.head_out); putp(E_HRES, ha.head_res);
     }
     struct EpiArgs {
         int OH, OW, DH, DW, Ntot, n_split, act, pool_cs, cs0, cs1, mm0, mm1, ac0, ac1, dexp, nblk0, nblk1;
         float *dst0, *dst1, *pool_dst; const float *mask0, *mask1, *addsrc; unsigned char* pool_codes;
         unsigned* bits_out; const unsigned *bin0, *bin1;
+        float* head_out; const float* head_res;
         __device__ int dst_cs(int du) const { return du ? cs1 : cs0; }
         __device__ int mask_mode(int du) const { return du ? mm1 : mm0; }
         __device__ int accum(int du) const { return du ? ac1 : ac0; }
@@ -405,9 +417,11 @@ igemm_h2s_kernel(const H2Args ha) {
         e.dst0 = (float*)rp(E_DST0); e.dst1 = (float*)rp(E_DST1); e.mask0 = (const float*)rp(E_MASK0); e.mask1 = (const float*)rp(E_MASK1);
         e.addsrc = (const float*)rp(E_ADD); e.pool_dst = (float*)rp(E_PDST); e.pool_codes = (unsigned char*)rp(E_PCODE);
         e.bits_out = (unsigned*)rp(E_BOUT); e.bin0 = (const unsigned*)rp(E_BIN0); e.bin1 = (const unsigned*)rp(E_BIN1);
+        if constexpr (EK == EK_HEAD) { e.head_out = (float*)rp(E_HOUT); e.head_res = (const float*)rp(E_HRES); }
         return e;
     };
     float amx0 = 0.f, amx1 = 0.f;                                    // max |stored value| of this lane, per destination
+    f32x4 hw[EK == EK_HEAD ? 8 : 1];                                 // (EK_HEAD) head weights of this lane's 8 channels: [output o][16-column block jj] (loaded behind barrier 0)
 
     // ---- epilogue of tile `tl`, straight from the accumulators: x 2^dexp (undo the operand scales), bias, activation, act' mask, residual and
     // accumulation are float4 arithmetic on the accumulator registers; stores cover whole 128-byte lines (csrc/conv_x3s.hip).  The fused
@@ -642,8 +656,8 @@ igemm_h2s_kernel(const H2Args ha) {
         }
         // ---- FWD: no mask, no accumulation, no residual (every forward layer; sign bits on request);  BWD / BWDB: act' masks as float32
         // activations / as the forward kernel's bits (a destination without one requests them out of range: zeros come back, no memory traffic).
-        if constexpr (EK == EK_FWD || EK == EK_BWD || EK == EK_BWDB) {
-            constexpr bool MASKED = EK == EK_BWD, BITS = EK == EK_BWDB;
+        if constexpr (EK == EK_FWD || EK == EK_BWD || EK == EK_BWDB || EK == EK_HEAD) {
+            constexpr bool MASKED = EK == EK_BWD, BITS = EK == EK_BWDB, FWDL = EK == EK_FWD || EK == EK_HEAD;
             f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];              // [.][2 k] = what instruction 1 fetched, [.][2 k + 1] = instruction 2
             unsigned mbits[NT];
             if constexpr (MASKED) {
@@ -676,12 +690,14 @@ igemm_h2s_kernel(const H2Args ha) {
                     const int mm = ea.mask_mode(du_[k]);
                     const float msl = mm == 1 ? 0.2f : (mm == 0 ? 1.f : 0.f);      // act'(x <= 0); a destination without a mask (its requests came back as zeros): 1
                     unsigned sb = 0u;
+                    float hp[EK == EK_HEAD ? MT * 2 : 1][4];        // (EK_HEAD) this lane's partial head sums per pixel block
+                    const bool keep = EK != EK_HEAD || ea.dst0 != nullptr;      // (EK_HEAD, eval forward: the 32-channel map is not stored)
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
                             f32x4 o0, o1;
-                            if constexpr (EK == EK_FWD) {            // (backward-data has no bias: the launcher checks)
+                            if constexpr (FWDL) {                    // (backward-data has no bias: the launcher checks)
                                 o0 = take_bias(2 * i + h, 2 * k, bias4[2 * k]); o1 = take_bias(2 * i + h, 2 * k + 1, bias4[2 * k + 1]);
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { float e = o0[c]; act_sign(e, sb, aslope, act_tag); o0[c] = e; }
@@ -704,21 +720,58 @@ igemm_h2s_kernel(const H2Args ha) {
                                 for (int c = 0; c < 4; ++c) { float e = o1[c]; mask_bit(e, mbits[k], msl); o1[c] = e; }
                             }
                             track(o0); track(o1);
+                            if constexpr (EK == EK_HEAD) {
+#pragma unroll
+                                for (int o = 0; o < 4; ++o) {
+                                    float sacc = hw[2 * o].x * o0.x;
+                                    sacc = __builtin_fmaf(hw[2 * o].y, o0.y, sacc); sacc = __builtin_fmaf(hw[2 * o].z, o0.z, sacc); sacc = __builtin_fmaf(hw[2 * o].w, o0.w, sacc);
+                                    sacc = __builtin_fmaf(hw[2 * o + 1].x, o1.x, sacc); sacc = __builtin_fmaf(hw[2 * o + 1].y, o1.y, sacc);
+                                    sacc = __builtin_fmaf(hw[2 * o + 1].z, o1.z, sacc); sacc = __builtin_fmaf(hw[2 * o + 1].w, o1.w, sacc);
+                                    hp[i * 2 + h][o] = sacc;
+                                }
+                                if (!keep) continue;
+                            }
                             if constexpr (!(H2S_ABL & 1)) trade(o0, o1);
                             if constexpr (H2S_ABL & 16) { asm volatile("" :: "v"(o0), "v"(o1)); continue; }
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rd, wo[k][i][h], 0, H2S_STORE_AUX);
                             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
                         }
-                    if constexpr (EK == EK_FWD) {
+                    if constexpr (EK == EK_HEAD) {
+                        // the 4 lanes of a pixel (q = lane >> 4) add their partial sums: exchange with lane ^ 16 (each keeps two outputs), then with
+                        // lane ^ 32 (each keeps one): lane q ends with output o = 2 (q & 1) + (q >> 1) of its pixel, summed in a fixed order
+                        const int q = lane_e >> 4, a16 = (lane_e ^ 16) * 4, a32 = (lane_e ^ 32) * 4;
+                        const bool q0 = q & 1, q1 = q >> 1;
+                        const int oo = 2 * (q & 1) + (q >> 1);
+                        const float hb = head_lds[128 + oo];
+                        const int64_t plane = (int64_t)ea.OH * ea.OW;
+                        float* outp = ea.head_out + ((int64_t)b * 4 + oo) * plane;
+                        const float* resp = ea.head_res ? ea.head_res + ((int64_t)b * 4 + oo) * plane : nullptr;
+#pragma unroll
+                        for (int blk = 0; blk < MT * 2; ++blk) {
+                            const float s0 = q0 ? hp[blk][0] : hp[blk][2], s1 = q0 ? hp[blk][1] : hp[blk][3];
+                            const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, s0)));
+                            const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a16, __builtin_bit_cast(int, s1)));
+                            const float k0 = (q0 ? hp[blk][2] : hp[blk][0]) + r0, k1 = (q0 ? hp[blk][3] : hp[blk][1]) + r1;
+                            const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(a32, __builtin_bit_cast(int, q1 ? k0 : k1)));
+                            float v = (q1 ? k1 : k0) + r2 + hb;
+                            const int i = blk >> 1, h = blk & 1;
+                            if (okp[i][h]) {
+                                const int64_t off = (int64_t)(py0 + i) * ea.OW + px0 + 16 * h;
+                                if (resp) v += resp[off];
+                                outp[off] = v;
+                            }
+                        }
+                    }
+                    if constexpr (FWDL) {
                         const __amdgpu_buffer_rsrc_t rb = bits_rsrc(ea.bits_out, ea.nblk0);
-                        __builtin_amdgcn_raw_buffer_store_b32(sb, rb, (ea.bits_out && blk_[k] && !du_[k]) ? bits_off(k, ea.nblk0) : OOB, 0, 0);
+                        if (keep) __builtin_amdgcn_raw_buffer_store_b32(sb, rb, (ea.bits_out && blk_[k] && !du_[k]) ? bits_off(k, ea.nblk0) : OOB, 0, 0);
                     }
                     track_done(du_[k]);
                 }
             };
             // one wave-uniform branch per tile: with / without an activation (backward-data never has one: the launcher sends a masked layer
             // WITH an activation to the general kernel)
-            if constexpr (EK != EK_FWD) body(std::false_type{});
+            if constexpr (!FWDL) body(std::false_type{});
             else if (ea.act != 0) body(std::true_type{});
             else body(std::false_type{});
             return;
@@ -768,6 +821,10 @@ igemm_h2s_kernel(const H2Args ha) {
 #endif
     H2S_BARRIER();                                                // barrier 0
     H2S_T(t_bar)
+    if constexpr (EK == EK_HEAD) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hw[q] = *reinterpret_cast<const f32x4*>(head_lds + (q >> 1) * 32 + (q & 1) * 16 + (lane >> 4) * 4);
+    }
     for (;;) {
         const Ck n1 = chunk_at(K1{});
 #ifdef H2S_STAMPS
@@ -867,6 +924,15 @@ int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
         const unsigned* p = d ? ha.bits_in[1] : (ha.bits_in[0] ? ha.bits_in[0] : ha.bits_out);
         if (p && (ha.bits_nblk[d] <= 0 || pnnp_h2_bits_words(a.B, a.DH, a.DW, 32 * ha.bits_nblk[d]) * 4 >= (1ll << 31))) return PNNP_E_UNSUPPORTED;
     }
+    if (ha.head_out) {
+        // forward + 1x1 head (EK_HEAD): one 32-column block holds every channel of a pixel; plain single-destination forward layers only
+        if (!ha.head_w || a.Ntot != 32 || two || a.mask_mode[0] || a.accum[0] || a.addsrc || a.pool_dst || a.pool_codes || ha.bits_in[0] || ha.bits_in[1] ||
+            a.OH != a.DH || a.OW != a.DW || (((uintptr_t)ha.head_w | (uintptr_t)ha.head_out | (uintptr_t)ha.head_res | (uintptr_t)ha.head_b) & 3))
+            return PNNP_E_UNSUPPORTED;
+        if (!a.dst[0] && (ha.bits_out || ha.amax_out[0])) return PNNP_E_INVALID;     // (nothing stored: nothing to describe)
+        return launch_h2s<32, EK_HEAD>(b, s);
+    }
+    if (!a.dst[0]) return PNNP_E_INVALID;
     if (a.pool_dst || a.pool_codes) {
         // fused MaxPool2d(2): plain forward layers only (one destination, no mask / residual / accumulate), even sizes
         if (!a.pool_dst || !a.pool_codes || two || a.mask_mode[0] || a.accum[0] || a.addsrc || (a.OH & 1) || (a.OW & 1) || a.OH != a.DH ||

@@ -35,6 +35,9 @@ struct H2Args {
     unsigned* bits_out;                      // forward: sign bits of the stored (activated) output, tile-private layout (or null)
     const unsigned* bits_in[2];              // backward-data: act' mask of destination 0 / 1 as bits written by the forward kernel (or null)
     int bits_nblk[2];                        // 32-channel blocks of the tensor behind bits_out ([0]) / bits_in[du]
+    // forward layer + the network's 1x1 head in ONE kernel (csrc/conv_h2s.hip EK_HEAD; Ntot == 32): head_out NCHW [B][4][OH][OW] = head_w [4][32] . act(y) + head_b
+    // (+ head_res, NCHW like head_out); g.dst[0] may then be null (the 32-channel map is not stored).  head_out null: an ordinary launch.
+    const float* head_w; const float* head_b; const float* head_res; float* head_out;
 };
 // Tile-private bit layout: the 16-row x 32-px x 32-channel block (image b, tile row ty, tile column tx, channel block cb) of a tensor with
 // nblk 32-channel blocks is 512 words; word 64 w + l belongs to lane l of consumer wave w, bit 31 - (((i 2 + h) 2 + jj) 4 + c) = element

@@ -307,6 +307,18 @@ def conv_h2_fwd(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, amax_x2=None,
     return y
 
 
+def conv_h2_fwd_head(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, head_w, head_b, out, amax_x2=None, amax_y=None, bits_y=None, residual=None):
+    """The last 3x3 layer + activation + the 1x1 head in one kernel (archs/Unet.py:93-94): ``out`` NCHW [B,4,H,W] (+ ``residual``, NCHW);
+    ``y`` None: the 32-channel map is not stored (eval forward)."""
+    require_cuda(x1, x2, w_h2, y, amax_w, amax_x1, head_w, out, residual)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9 + 2.0 * B * H * W * cout * 4, 4.0 * B * H * W * (C1 + C2 + (cout if y is not None else 0) + 4), sub='bn32'):
+        check(_prep().pnnp_conv3x3_h2_fwd_head_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y), ptr(amax_y),
+                                                   ptr(bits_y), ptr(head_w), ptr(head_b), ptr(residual), ptr(out), B, H, W, cout, act, stream()), 'conv_h2_fwd_head')
+    return out
+
+
 def conv_h2_fwd_pool(x1, x2, w_h2, amax_w, bias, y, pooled, codes, cout, act, amax_x1, amax_x2=None, amax_y=None, bits_y=None):
     require_cuda(x1, x2, w_h2, y, pooled, codes, amax_w, amax_x1)
     B, H, W, C1 = x1.shape

@@ -263,3 +263,42 @@ def test_kernel_families_follow_the_same_training_trajectory():
         d = rel(run(pol))
         print(f'{fam} vs direct over 40 steps: worst relative loss difference {d:.2e}; one-ulp perturbation of direct: {ulp:.2e} (loss {ref[0]:.4f} -> {ref[-1]:.4f})')
         assert d <= 3 * ulp + 1e-5, (fam, d, ulp)
+
+
+@pytest.mark.parametrize('res', [False, True])
+def test_fused_head_equals_conv_then_head_kernel(res):
+    """Round 6: conv10_1 runs inside conv9_2's epilogue (csrc/conv_h2s.hip EK_HEAD, archs/Unet.py:93-94).  Against the two-kernel path
+    (`set_policy(head_fused=False)`: conv9_2, then pnnp_head_fwd_f32) on a frame whose width does not fill the 32-pixel tiles: the output
+    planes agree to float32 summation order (the head's 32-term sums: 1e-6 of the largest output), the stored 32-channel map, its sign bits and amax
+    slot are BIT-identical in a training forward, the parameter gradients of a backward pass agree, and an eval forward (which stores no
+    32-channel map at all) gives the training forward's output bit for bit."""
+    from pnnp_amd.archs import UNetSeeInDark, initialize_weights
+    torch.manual_seed(3)
+    net = UNetSeeInDark(dict(nframes=1, res=res, nf=32, in_nc=4, out_nc=4)); initialize_weights(net)
+    with torch.no_grad():
+        net.conv10_1.bias.uniform_(-0.1, 0.1)
+    net = net.cuda()
+    e = net.engine
+    g = torch.Generator(device='cuda').manual_seed(4)
+    x = torch.rand(2, 4, 48, 80, device='cuda', generator=g)
+    go = torch.randn(2, 48, 80, 8, device='cuda', generator=g); go[..., 4:] = 0
+
+    def run(fused):
+        e.set_policy(head_fused=fused)
+        out = e.forward(x, train=True).clone()
+        a = e.saved[0]
+        c9, bits = a['c9'].clone(), a['bits:conv9_2'].clone()
+        e.backward(go.clone())
+        with torch.no_grad():
+            ev = net(x).clone()
+        return out, c9, bits, e.params.grad.clone(), ev
+    o1, c1, b1, g1, ev1 = run(True)
+    o0, c0, b0, g0, ev0 = run(False)
+    assert e._head_fusable() is False
+    scale = float(o0.abs().max())
+    print(f'fused head vs conv + head kernel: max |diff| / max |out| {float((o1 - o0).abs().max()) / scale:.2e}')
+    assert float((o1 - o0).abs().max()) <= 1e-6 * scale
+    assert torch.equal(c1, c0) and torch.equal(b1, b0)
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-6
+    assert torch.equal(ev1, o1)                                  # eval forward (no 32-channel map stored) == training forward
+    assert float((ev0 - o0).abs().max()) <= 1e-6 * scale
