@@ -238,6 +238,14 @@ int pnnp_pack_jobs_add_h2(PnnpPackJob* jobs, int* n, int cap, const float* w, vo
 int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
                             const void* w_h2, const unsigned* amax_w, const float* bias, const float* residual, float* y,
                             unsigned* amax_y /*or null*/, unsigned* bits_y /*or null*/, int B, int H, int W, int Cout, int act, void* stream);
+/* Split-K for small grids (round 6; an eval forward on ONE 512 x 512 crop gives the deep layers 16-32 output tiles for 256 CUs): pnnp_h2_splitk returns the
+ * number of K slices for a layer with `chunks` = segments x ceil(C / 16) chunks of K (1 = launch as usual); with ksplit > 1 the kernel writes raw partial
+ * sums into ws ([ksplit][B][H][W][Cout] floats) and a reduce kernel adds them in a fixed order (deterministic), then bias, activation, amax_y and the sign
+ * bits exactly as pnnp_conv3x3_h2_fwd_f32 would have.  Another partition of the K sum: results differ from the unsplit launch by float32 rounding only. */
+int pnnp_h2_splitk(int B, int H, int W, int chunks, int N);
+int pnnp_conv3x3_h2_fwd_splitk_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2,
+                                   const void* w_h2, const unsigned* amax_w, const float* bias, float* y, unsigned* amax_y, unsigned* bits_y,
+                                   int B, int H, int W, int Cout, int act, int ksplit, float* ws, int64_t ws_floats, void* stream);
 /* The last 3x3 layer + LeakyReLU + the 1x1 head conv10_1 (archs/Unet.py:93-94; ResUnet: archs/ResUnet.py conv_out) in ONE kernel (round 6): Cout == 32
  * (one workgroup tile holds every channel of a pixel), head_w [4][32] / head_b [4] are the parameters as they are, head_out NCHW [B][4][H][W] float32
  * (+ head_res, NCHW like head_out: the `res` networks' input, or null).  y (the 32-channel map, with amax_y / bits_y as in pnnp_conv3x3_h2_fwd_f32) may be

@@ -221,10 +221,7 @@ class ResUnetEngine(_EngineBase):
         # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
         # tensor._version, the fused Adam kernel goes through mark_dirty()
         self._pol = self.effective_policy(H, Wd, max(self.ch[0], self.cin_pad, self.cout_pad))
-        key = (train, dev, self._dirty_epoch, self._pol.key()) + tuple(p._version for p in self.m.parameters())
-        if key != self._pack_key:
-            self.pack_weights(train)
-            self._pack_key = key
+        self._packs_ready(train, dev)
         gen = self._begin_forward((B, H, Wd, dev), train)
         bufs = self.bufs.setdefault((B, H, Wd, dev), _Bufs())
         P = dict(self.m.named_parameters())

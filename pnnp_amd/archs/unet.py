@@ -42,9 +42,10 @@ class ConvPolicy:
         self.h2_wgrad = bool(h2) and os.environ.get('PNNP_H2_WGRAD', '1') != '0'      # (host-side A/B switch: backward-weight stays on bf16x3 with 0)
         self.h2_pointwise = bool(h2) and os.environ.get('PNNP_H2_POINTWISE', '1') != '0'      # (A/B switch: ConvTranspose2d stays on bf16x3 with 0)
         self.head_fused = bool(h2) and os.environ.get('PNNP_HEAD_FUSED', '1') != '0'          # (A/B switch) conv10_1 inside conv9_2's epilogue (round 6)
+        self.splitk = bool(h2) and os.environ.get('PNNP_SPLITK', '1') != '0'                  # (A/B switch) split-K forward launches for small grids (round 6)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise, self.head_fused)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise, self.head_fused, self.splitk)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -113,12 +114,22 @@ class _EngineBase:
         self._jobs_key = None
         self._dirty_epoch = 0
 
+    def _pack_state_key(self, train, dev):
+        return (train, dev, self._dirty_epoch, self._pol.key()) + tuple(p._version for p in self.m.parameters())
+
+    def _packs_ready(self, train, dev):
+        """Start of a forward: (re-)pack the weights if the packs are not the ones this forward needs (mode, policy, parameter versions)."""
+        key = self._pack_state_key(train, dev)
+        if key != self._pack_key:
+            self.pack_weights(train)
+            self._pack_key = key
+
     def set_policy(self, policy=None, **kw):
         """``set_policy(x3=False)`` etc.: fields not named keep their current value."""
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
-            for k in ('h2_wgrad', 'h2_pointwise', 'head_fused'):   # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
+            for k in ('h2_wgrad', 'h2_pointwise', 'head_fused', 'splitk'):   # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
                 if k in kw:
                     self._h2_sub[k] = bool(kw.pop(k))
             cur.update(kw)
@@ -243,6 +254,13 @@ class _Bufs:
         if b is None or tuple(b.shape) != tuple(shape) or b.device != device:
             b = torch.empty(shape, dtype=torch.float32, device=device)
             self.t[name] = b
+        return b
+
+    def scratch(self, name, n, device):
+        """a 1-D float32 scratch buffer of at least n elements (grows, never shrinks)"""
+        b = self.t.get(name)
+        if b is None or b.numel() < n or b.device != device:
+            b = self.t[name] = torch.empty(int(n), dtype=torch.float32, device=device)
         return b
 
     # ---- fp16x2 family (csrc/h2.h): one 4-byte amax slot per tensor the kernels split, in two tables -- 'f' (activations, zeroed when a
@@ -423,10 +441,7 @@ class UNetEngine(_EngineBase):
         # packed weights are re-used while no parameter changed (eval loops); in-place torch updates bump
         # tensor._version, the fused Adam kernel goes through mark_dirty()
         self._pol = self.effective_policy(H, W, max(self.ch[0], self.cin_pad, self.cout_pad))
-        key = (train, dev, self._dirty_epoch, self._pol.key()) + tuple(p._version for p in self.m.parameters())
-        if key != self._pack_key:
-            self.pack_weights(need_dgrad=train)
-            self._pack_key = key
+        self._packs_ready(train, dev)
         gen = self._begin_forward((B, H, W, dev), train)
         bufs = self.bufs.setdefault((B, H, W, dev), _Bufs())
         P = dict(self.m.named_parameters())
@@ -453,6 +468,12 @@ class UNetEngine(_EngineBase):
                 ops.amax(t, sl(name))
             return t
 
+        def splitk(src, src2, h, w, cout):
+            """K slices of a 3x3 fp16x2 forward launch on this map (1: none)"""
+            if not self._pol.splitk:
+                return 1
+            return ops.h2_splitk(B, h, w, (2 if src2 is not None else 1) * ((src.shape[3] + 15) // 16), cout)
+
         def conv(name, src, src2, h, w, cout, act=LRELU, taps=9, out=None):
             y = out if out is not None else g(name, (B, h, w, cout))
             hp = self._h2.get(name, (None, None))[0]
@@ -460,8 +481,14 @@ class UNetEngine(_EngineBase):
                 bits = bufs.bits(name, B, h, w, cout, dev) if (train and act == LRELU) else None
                 if bits is not None:
                     a['bits:' + name] = bits
-                ops.conv_h2_fwd(src, src2, hp, self._wslot[name], P[name + '.bias'], y, cout, act, sl(src_name[id(src)]),
-                                sl(src_name[id(src2)]) if src2 is not None else None, amax_y=sl(name), bits_y=bits)
+                ks = splitk(src, src2, h, w, cout)
+                if ks > 1:                                           # a small grid: K in slices, one reduce (bias, activation, amax, sign bits)
+                    ops.conv_h2_fwd_splitk(src, src2, hp, self._wslot[name], P[name + '.bias'], y, cout, act, sl(src_name[id(src)]), ks,
+                                           bufs.scratch('splitk_ws', ks * y.numel(), dev), amax_x2=sl(src_name[id(src2)]) if src2 is not None else None,
+                                           amax_y=sl(name), bits_y=bits)
+                else:
+                    ops.conv_h2_fwd(src, src2, hp, self._wslot[name], P[name + '.bias'], y, cout, act, sl(src_name[id(src)]),
+                                    sl(src_name[id(src2)]) if src2 is not None else None, amax_y=sl(name), bits_y=bits)
                 src_name[id(y)] = name
                 return y
             if h2_on:
@@ -500,7 +527,11 @@ class UNetEngine(_EngineBase):
                 a[f'pc{i}'] = codes
             pooled = g(f'p{i}', (B, hs[lvl + 1], ws[lvl + 1], ch[lvl]))
             hp = self._h2.get(f'conv{i}_2', (None, None))[0]
-            if hp is not None and self._pol.pool_fused:
+            if hp is not None and self._pol.pool_fused and splitk(a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl]) > 1:
+                # a small grid: the split-K launch has no fused pool -- conv (slices + reduce), then the pool kernel
+                a[f'c{i}'] = conv(f'conv{i}_2', a[f'c{i}a'], None, hs[lvl], ws[lvl], ch[lvl])
+                a[f'p{i}'] = ops.maxpool_fwd(a[f'c{i}'], pooled, codes=codes)
+            elif hp is not None and self._pol.pool_fused:
                 # conv{i}_2 writes the pooled map, the codes, its amax (the pooled map is a subset) and the sign bits from its own epilogue
                 name = f'conv{i}_2'
                 bits = bufs.bits(name, B, hs[lvl], ws[lvl], ch[lvl], dev) if train else None

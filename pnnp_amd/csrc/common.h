@@ -69,6 +69,22 @@ __device__ __forceinline__ void pnnp_amax_commit(float m, unsigned* slot) {
     if ((threadIdx.x & 63) == 0 && m > 0.f && __float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
 }
 
+// ... for streaming kernels whose waves all finish at about the same time (a one-crop layout pass: 8192 waves found the slot at 0 and serialised
+// 8192 atomics on one address, 128 us for a 4 MB tensor): the block's waves reduce through LDS first and ONE thread issues the atomic.  Every thread
+// of the block must call it (it contains a barrier); blocks of at most 1024 threads.
+__device__ __forceinline__ void pnnp_amax_commit_block(float m, unsigned* slot) {
+    __shared__ float pnnp_amax_red[16];
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) m = fmaxf(m, __shfl_xor(m, sft, 64));
+    const int wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    if ((threadIdx.x & 63) == 0) pnnp_amax_red[wv] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < nw; ++i) m = fmaxf(m, pnnp_amax_red[i]);
+        if (m > 0.f && __float_as_uint(m) > __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(slot, __float_as_uint(m));
+    }
+}
+
 // Tensor.clamp / np.clip semantics: a NaN stays a NaN (fminf / fmaxf return the OTHER operand for a NaN, which would turn a diverged network's
 // output into a finite loss or PSNR).  Comparisons with a NaN are false, so it falls through both selects.
 __device__ __forceinline__ float pnnp_clampf(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

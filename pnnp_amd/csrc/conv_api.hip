@@ -250,6 +250,25 @@ int pnnp_conv3x3_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, co
     return pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
 }
 
+// small grids: K cut into `ksplit` slices (pnnp_h2_splitk), raw partial sums into ws [ksplit][B][H][W][Cout], then one reduce kernel (bias, activation,
+// amax, sign bits); ksplit <= 1: the ordinary launch
+int pnnp_conv3x3_h2_fwd_splitk_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
+                                   const void* w_h2, const unsigned* amax_w, const float* bias, float* y, unsigned* amax_y, unsigned* bits_y,
+                                   int B, int H, int W, int Cout, int act, int ksplit, float* ws, int64_t ws_floats, void* stream) {
+    if (ksplit <= 1) return pnnp_conv3x3_h2_fwd_f32(x1, C1, amax_x1, x2, C2, amax_x2, w_h2, amax_w, bias, nullptr, y, amax_y, bits_y, B, H, W, Cout, act, stream);
+    if (!x1 || !w_h2 || !y || !ws || B < 0 || H <= 0 || W <= 0 || C1 <= 0 || (x2 && C2 != C1) || (Cout & 31)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    if (ws_floats < (int64_t)ksplit * B * H * W * Cout) return PNNP_E_WORKSPACE;
+    if ((int64_t)ksplit * B >= (1 << 20)) return PNNP_E_UNSUPPORTED;
+    H2Args a{};
+    fwd_args(a.g, x1, C1, x2, C2, w_h2, nullptr, nullptr, ws, B, H, W, Cout, 0);
+    a.amax_in[0] = amax_x1; a.amax_in[1] = x2 ? amax_x2 : nullptr; a.amax_w = amax_w;
+    a.ksplit = ksplit;
+    const int rc = pnnp_igemm_h2s_launch(a, C1, as_stream(stream));
+    if (rc != PNNP_OK) return rc;
+    return pnnp_h2_splitk_reduce_launch(ws, ksplit, bias, y, bits_y, amax_y, B, H, W, Cout, act, as_stream(stream));
+}
+
 // conv3x3 + activation + the network's 1x1 head (archs/Unet.py:93-94: conv9_2, lrelu, conv10_1) in one kernel; y null: the 32-channel map is not stored
 int pnnp_conv3x3_h2_fwd_head_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2,
                                  const void* w_h2, const unsigned* amax_w, const float* bias, float* y, unsigned* amax_y, unsigned* bits_y,

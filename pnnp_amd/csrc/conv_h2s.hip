@@ -127,25 +127,35 @@ igemm_h2s_kernel(const H2Args ha) {
     // ---- the workgroup's tiles t, t + G, ...: decoded once, then stepped by mixed-radix addition (both roles walk the same sequence)
     const int tiles_x = (a.DW + 31) >> 5, tiles_y = (a.DH + TH - 1) / TH;
     const int n_tiles = (a.Ntot + BN - 1) / BN;
-    const int total = tiles_x * tiles_y * a.B * n_tiles;
+    // split-K (general epilogue only; ha.ksplit = S > 1): S workgroups share an output tile, slice ks owning chunks [ks, ks + 1) nchunks / S of K and
+    // writing its raw partial sums into image ks B + b of a [S][B][OH][OW][cs] slab tensor; h2_splitk_reduce_kernel adds the slabs in a fixed order
+    constexpr bool SPLITK = EK == EK_GEN;
+    const int KSPL = SPLITK ? ha.ksplit : 1;
+    const int total = tiles_x * tiles_y * a.B * n_tiles * KSPL;
     const int G = gridDim.x;
-    const int nchunks = a.nseg * a.chunks_per_seg;                  // 16-channel chunks of K
-    struct Tile { int b, y0, x0, n0; };
+    const int nchunks = a.nseg * a.chunks_per_seg / KSPL;           // 16-channel chunks of K a workgroup walks per tile (its slice)
+    struct Tile { int b, y0, x0, n0, ks; };
     auto decode = [&](int t) {
         Tile o;
         const int nt_i = t % n_tiles;
         int m_i = t / n_tiles;
         const int tx = m_i % tiles_x; m_i /= tiles_x;
-        o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN;
+        o.x0 = tx * 32; o.y0 = (m_i % tiles_y) * TH; o.b = m_i / tiles_y; o.n0 = nt_i * BN; o.ks = 0;
+        if constexpr (SPLITK) { o.ks = o.b / a.B; o.b -= o.ks * a.B; }
         return o;
     };
-    auto pick = [](bool c, const Tile& x, const Tile& y) { Tile o; o.b = c ? x.b : y.b; o.y0 = c ? x.y0 : y.y0; o.x0 = c ? x.x0 : y.x0; o.n0 = c ? x.n0 : y.n0; return o; };
+    auto pick = [](bool c, const Tile& x, const Tile& y) {
+        Tile o; o.b = c ? x.b : y.b; o.y0 = c ? x.y0 : y.y0; o.x0 = c ? x.x0 : y.x0; o.n0 = c ? x.n0 : y.n0; o.ks = 0;
+        if constexpr (SPLITK) o.ks = c ? x.ks : y.ks;
+        return o;
+    };
     const Tile gstep = decode(G);
     auto advance = [&](Tile o) {
         o.n0 += gstep.n0; if (o.n0 >= n_tiles * BN) { o.n0 -= n_tiles * BN; o.x0 += 32; }
         o.x0 += gstep.x0; if (o.x0 >= tiles_x * 32) { o.x0 -= tiles_x * 32; o.y0 += TH; }
         o.y0 += gstep.y0; if (o.y0 >= tiles_y * TH) { o.y0 -= tiles_y * TH; o.b += 1; }
         o.b += gstep.b;
+        if constexpr (SPLITK) { if (o.b >= a.B) { o.b -= a.B; o.ks += 1; } o.ks += gstep.ks; }
         return o;
     };
     int t = xcd_remap(blockIdx.x, G);
@@ -208,6 +218,7 @@ igemm_h2s_kernel(const H2Args ha) {
         // global loads of the halo tile of (tile, chunk gq) -> register set S: hardware zero for pixels outside the image and channels past the segment
         auto load_halo = [&](auto stag, const Tile& tl, int gq) {
             constexpr int S = decltype(stag)::value;
+            if constexpr (SPLITK) gq += tl.ks * nchunks;            // (this slice's chunks of K)
             const int si = gq / a.chunks_per_seg, cc = gq - si * a.chunks_per_seg;
             const IgemmSeg sg = a.seg[si];
             const int c0 = sg.coff + cc * 16;
@@ -244,8 +255,9 @@ igemm_h2s_kernel(const H2Args ha) {
         };
         // LDS-DMA of the weights of (tile n0, chunk gq) into stage st: per 32-channel block 18432 contiguous bytes of the pack, as 1 KB pieces
         // dealt over the 4 producer waves; past the end a wave repeats the last piece (same bytes, same place)
-        const int K16 = nchunks;
+        const int K16 = a.nseg * a.chunks_per_seg;
         auto dma_weights = [&](const Tile& tl, int gq, int st, bool valid) {
+            if constexpr (SPLITK) gq += tl.ks * nchunks;
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 const int ins = min(pw + NPW * i, Cfg::NDMA - 1);
@@ -428,7 +440,7 @@ igemm_h2s_kernel(const H2Args ha) {
     // MaxPool2d(2) takes the other pixel of a pair from the neighbouring lane (DPP) and the other row from the wave's second accumulator row.
     auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
         const EpiArgs ea = epi_args();
-        const int b = tl.b, n0 = tl.n0;
+        const int b = SPLITK ? tl.b + tl.ks * a.B : tl.b, n0 = tl.n0;     // (split-K: slab image ks B + b; the launcher allows no mask / residual / bits there)
         // the lane number as an OPAQUE value: everything the epilogue derives from it is then computed here, per tile (a dozen instructions),
         // instead of being hoisted in front of the K loop and carried through it in ~50 registers (19 of them spilled to scratch in the
         // 64-column forward kernel: cycle stamps 14 600 cycles per forward tile against 10 000 for the spill-free backward-data kernel)
@@ -867,13 +879,52 @@ igemm_h2s_kernel(const H2Args ha) {
 #endif
 }
 
+// ---- split-K reduce: y = act(sum_s slab[s] + bias) in a fixed order (s = 0, 1, ...), one float4 per thread (coalesced), max |y| into the amax slot and -- a
+// training forward -- the sign bits OR-ed into the tile-private words of csrc/h2.h (zeroed by the launcher; 8 threads share a word, no two the same bits)
+__global__ void __launch_bounds__(256)
+h2_splitk_reduce_kernel(const float* __restrict__ slab, int S, const float* __restrict__ bias, float* __restrict__ y, unsigned* __restrict__ bits,
+                        unsigned* __restrict__ amax, int B, int H, int W, int N, int act) {
+    const int tiles_x = (W + 31) >> 5, tiles_y = (H + TH - 1) / TH, nblk = N >> 5, nq = N >> 2;
+    const int64_t img = (int64_t)B * H * W * N, total = img >> 2;     // floats per slab; float4 elements
+    const float slope = act == 1 ? 0.2f : (act == 2 ? 0.f : 1.f);
+    float am = 0.f;
+    for (int64_t e4 = (int64_t)blockIdx.x * 256 + threadIdx.x; e4 < total; e4 += (int64_t)gridDim.x * 256) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(slab) + e4;
+        const int64_t st4 = img >> 2;
+        f32x4 o = p[0];
+        int sidx = 1;
+        for (; sidx + 3 < S; sidx += 4) {                           // (four independent loads in flight; the ORDER of the additions stays s = 0, 1, 2, ...)
+            const f32x4 v0 = p[sidx * st4], v1 = p[(sidx + 1) * st4], v2 = p[(sidx + 2) * st4], v3 = p[(sidx + 3) * st4];
+            o += v0; o += v1; o += v2; o += v3;
+        }
+        for (; sidx < S; ++sidx) o += p[sidx * st4];
+        const int cq = (int)(e4 % nq), ch = cq * 4;
+        if (bias) o += *reinterpret_cast<const f32x4*>(bias + ch);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] = o[c] > 0.f ? o[c] : o[c] * slope;
+        reinterpret_cast<f32x4*>(y)[e4] = o;
+        am = fmaxf(fmaxf(am, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        if (bits) {
+            int64_t px = e4 / nq;
+            const int xx = (int)(px % W); px /= W;
+            const int yy = (int)(px % H); const int b = (int)(px / H);
+            const int ty = yy / TH, wv = (yy % TH) >> 1, i = yy & 1, tx = xx >> 5, h = (xx >> 4) & 1, p16 = xx & 15;
+            const int cb = ch >> 5, jj = (ch >> 4) & 1, q = (ch >> 2) & 3;
+            const int64_t word = ((((int64_t)(b * tiles_y + ty) * tiles_x + tx) * nblk + cb) * NCW + wv) * 64 + q * 16 + p16;
+            const unsigned nib = (o.x > 0.f ? 8u : 0u) | (o.y > 0.f ? 4u : 0u) | (o.z > 0.f ? 2u : 0u) | (o.w > 0.f ? 1u : 0u);
+            atomicOr(bits + word, nib << (28 - ((i * 2 + h) * 2 + jj) * 4));
+        }
+    }
+    if (amax) pnnp_amax_commit_block(am, amax);
+}
+
 template <int BN, int EK>
 int launch_h2s(const H2Args& a, hipStream_t s) {
     using Cfg = SCfg<BN>;
     auto kern = igemm_h2s_kernel<BN, EK>;
     static PnnpPerDevice lds_once;
     if (pnnp_allow_lds(lds_once, kern, Cfg::LDS_BYTES) != PNNP_OK) return PNNP_E_LAUNCH;
-    const int tiles = ((a.g.DW + 31) / 32) * ((a.g.DH + TH - 1) / TH) * a.g.B * ((a.g.Ntot + BN - 1) / BN);
+    const int tiles = ((a.g.DW + 31) / 32) * ((a.g.DH + TH - 1) / TH) * a.g.B * ((a.g.Ntot + BN - 1) / BN) * (EK == EK_GEN && a.ksplit > 1 ? a.ksplit : 1);
     if (tiles <= 0) return PNNP_OK;
     const int wgs = pnnp_persistent_grid(tiles);
     hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHR), Cfg::LDS_BYTES, s, a);
@@ -897,6 +948,31 @@ extern "C" int pnnp_h2_tile_columns(int B, int H, int W, int N, int pool) {
     return tiles64 * 4 >= (int64_t)cus * 3 ? 64 : 32;
 }
 
+// split-K policy: how many K slices a [B][H][W] layer with `chunks` 16-channel chunks of K and N channels written should be cut into so that the grid fills
+// the chip (1 = no split): the smallest divisor of `chunks` that brings 32-column tiles x slices to 3/4 of the CUs, at least 2 chunks per slice
+extern "C" int pnnp_h2_splitk(int B, int H, int W, int chunks, int N) {
+    int cus = pnnp_device_cus();
+    if (cus < 1) cus = 256;
+    const int64_t tiles32 = (int64_t)((W + 31) / 32) * ((H + TH - 1) / TH) * B * ((N + 31) / 32);
+    if (tiles32 * 4 >= (int64_t)cus * 3 || chunks < 4) return 1;
+    int best = 1;
+    for (int sp = 2; sp * 2 <= chunks; ++sp) {
+        if (chunks % sp) continue;
+        best = sp;
+        if (tiles32 * sp * 4 >= (int64_t)cus * 3) break;
+    }
+    return best;
+}
+int pnnp_h2_splitk_reduce_launch(const float* slab, int S, const float* bias, float* y, unsigned* bits, unsigned* amax, int B, int H, int W, int N, int act, hipStream_t st) {
+    const int64_t total = (int64_t)B * H * W * N / 4;
+    if (total <= 0) return PNNP_OK;
+    if (bits && hipMemsetAsync(bits, 0, (size_t)pnnp_h2_bits_words(B, H, W, N) * 4, st) != hipSuccess) return PNNP_E_LAUNCH;
+    const int64_t blocks = (total + 255) / 256;
+    // (at most one block per CU: every block ends with ONE atomicMax on the amax slot, and blocks that finish together serialise on it -- ~15 ns each)
+    hipLaunchKernelGGL(h2_splitk_reduce_kernel, dim3((unsigned)(blocks > 256 ? 256 : blocks)), dim3(256), 0, st, slab, S, bias, y, bits, amax, B, H, W, N, act);
+    return pnnp_launch_status();
+}
+
 // Validates like pnnp_igemm_x3_launch (csrc/conv_x3.hip); a.g.w: the h2 pack of csrc/pack_jobs.hip (kind 4).
 int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
     const IgemmArgs& a = ha.g;
@@ -917,6 +993,14 @@ int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
     H2Args b = ha;
     b.g.chunks_per_seg = (chan_per_seg + 15) / 16;
     b.g.seg_channels = chan_per_seg;
+    if (b.ksplit < 1) b.ksplit = 1;
+    if (b.ksplit > 1) {
+        // split-K: raw partial sums into a slab tensor of ksplit x B images -- nothing but the sums themselves (the reduce kernel adds bias, activation, amax)
+        if ((b.g.nseg * b.g.chunks_per_seg) % b.ksplit || a.dst[1] || a.bias || a.act || a.mask_mode[0] || a.accum[0] || a.addsrc || a.pool_dst || a.pool_codes ||
+            ha.bits_out || ha.bits_in[0] || ha.bits_in[1] || ha.head_out || ha.amax_out[0]) return PNNP_E_UNSUPPORTED;
+        if ((int64_t)a.OH * a.OW * a.dst_cs[0] * 4 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+        return pnnp_h2_tile_columns(a.B * b.ksplit, a.DH, a.DW, a.Ntot, 0) == 64 ? launch_h2s<64, EK_GEN>(b, s) : launch_h2s<32, EK_GEN>(b, s);
+    }
     const int64_t wbytes = (int64_t)((a.Ntot + 31) / 32) * b.g.nseg * b.g.chunks_per_seg * WBLK;
     if (wbytes >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
     const bool two = a.dst[1] != nullptr;

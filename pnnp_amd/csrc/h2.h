@@ -38,9 +38,13 @@ struct H2Args {
     // forward layer + the network's 1x1 head in ONE kernel (csrc/conv_h2s.hip EK_HEAD; Ntot == 32): head_out NCHW [B][4][OH][OW] = head_w [4][32] . act(y) + head_b
     // (+ head_res, NCHW like head_out); g.dst[0] may then be null (the 32-channel map is not stored).  head_out null: an ordinary launch.
     const float* head_w; const float* head_b; const float* head_res; float* head_out;
+    // split-K for small grids (csrc/conv_h2s.hip): ksplit > 1 workgroups share an output tile, each walking 1 / ksplit of the K chunks and writing raw partial
+    // sums to image ks B + b of g.dst[0] = a [ksplit][B][OH][OW][cs] slab tensor (general epilogue, no bias / activation / mask / bits); 0 or 1: off
+    int ksplit;
 };
 // Tile-private bit layout: the 16-row x 32-px x 32-channel block (image b, tile row ty, tile column tx, channel block cb) of a tensor with
 // nblk 32-channel blocks is 512 words; word 64 w + l belongs to lane l of consumer wave w, bit 31 - (((i 2 + h) 2 + jj) 4 + c) = element
 // (row 2 w + i, pixel 16 h + (l & 15), channel 16 jj + 4 (l >> 4) + c) > 0.  Forward and backward-data tiles of the same tensor coincide,
 // so a lane reads back exactly the word the same lane position wrote: 4 bytes per lane instead of 8 x 16.
 int pnnp_igemm_h2s_launch(const H2Args& a, int chan_per_seg, hipStream_t s);
+int pnnp_h2_splitk_reduce_launch(const float* slab, int S, const float* bias, float* y, unsigned* bits, unsigned* amax, int B, int H, int W, int N, int act, hipStream_t st);

@@ -41,7 +41,7 @@ nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int 
         *reinterpret_cast<float4*>(dst + p * Cp + 4 * cq) = make_float4(v[0], v[1], v[2], v[3]);
         amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
     }
-    if (amax) pnnp_amax_commit(amx, amax);
+    if (amax) pnnp_amax_commit_block(amx, amax);
 }
 
 // [B][H][W][Cp] -> [B][C][H][W] (+ residual NCHW, archs/Unet.py:95-98)
@@ -204,7 +204,7 @@ maxpool_bwd_codes_kernel(const unsigned char* __restrict__ codes, const float* _
             amx = fmaxf(fmaxf(amx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
         }
     }
-    if (amax) pnnp_amax_commit(amx, amax);
+    if (amax) pnnp_amax_commit_block(amx, amax);
 }
 
 // per-channel sum over pixels of an NHWC tensor: partial[blockIdx][C] then a fixed-order finish
@@ -350,7 +350,7 @@ int pnnp_nchw_to_nhwc_reflect_f32(const float* src, float* dst, int B, int C, in
 int pnnp_nchw_to_nhwc_reflect_amax_f32(const float* src, float* dst, int B, int C, int H, int W, int Cp, int pad, unsigned* amax, void* stream) {
     if (!src || !dst || B < 0 || C <= 0 || H <= 0 || W <= 0 || Cp < C || (Cp & 3) || pad < 0 || pad >= H || pad >= W) return PNNP_E_INVALID;
     if (B == 0) return PNNP_OK;
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * (H + 2 * pad) * (W + 2 * pad) * (Cp / 4))), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid1d((int64_t)B * (H + 2 * pad) * (W + 2 * pad) * (Cp / 4), (amax && (int64_t)B * (H + 2 * pad) * (W + 2 * pad) * (Cp / 4) < (1 << 22)) ? 256 : 256 * 8)), dim3(256), 0, as_stream(stream),
                        src, dst, B, C, H, W, Cp, pad, amax);
     return pnnp_launch_status();
 }

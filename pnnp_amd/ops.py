@@ -307,6 +307,22 @@ def conv_h2_fwd(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, amax_x2=None,
     return y
 
 
+def h2_splitk(B, H, W, chunks, N):
+    """K slices for a small grid (pnnp_h2_splitk): 1 = launch as usual."""
+    return int(_prep().pnnp_h2_splitk(int(B), int(H), int(W), int(chunks), int(N)))
+
+
+def conv_h2_fwd_splitk(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, ksplit, ws, amax_x2=None, amax_y=None, bits_y=None):
+    """conv_h2_fwd with K cut into ``ksplit`` slices (small grids): partial sums into ``ws`` (>= ksplit * y.numel() floats), one fixed-order reduce."""
+    require_cuda(x1, x2, w_h2, y, amax_w, amax_x1, ws)
+    B, H, W, C1 = x1.shape
+    C2 = x2.shape[3] if x2 is not None else 0
+    with _Timed('conv9_fwd_h2', 2.0 * B * H * W * cout * (C1 + C2) * 9, 4.0 * B * H * W * (C1 + C2 + cout), sub='splitk'):
+        check(_prep().pnnp_conv3x3_h2_fwd_splitk_f32(ptr(x1), C1, ptr(amax_x1), ptr(x2), C2, ptr(amax_x2), ptr(w_h2), ptr(amax_w), ptr(bias), ptr(y), ptr(amax_y),
+                                                     ptr(bits_y), B, H, W, cout, act, int(ksplit), ptr(ws), _i64(ws.numel()), stream()), 'conv_h2_fwd_splitk')
+    return y
+
+
 def conv_h2_fwd_head(x1, x2, w_h2, amax_w, bias, y, cout, act, amax_x1, head_w, head_b, out, amax_x2=None, amax_y=None, bits_y=None, residual=None):
     """The last 3x3 layer + activation + the 1x1 head in one kernel (archs/Unet.py:93-94): ``out`` NCHW [B,4,H,W] (+ ``residual``, NCHW);
     ``y`` None: the 32-channel map is not stored (eval forward)."""

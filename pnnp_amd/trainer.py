@@ -12,6 +12,8 @@ crop index, so the noise does not depend on the number of GPUs.
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
