@@ -309,10 +309,34 @@ gemm_h2s_kernel(const H2Args ha) {
     float amx0 = 0.f;                                                // max |stored value| of this lane, destination 0 (a.amax_out[0]; the launcher refuses [1])
     auto epilogue = [&](const Tile& tl) __attribute__((always_inline)) {
         const int b = tl.b;
-        const int p16 = lane & 15, c4 = (lane >> 4) * 4;
+        // (general epilogue: the lane number as an OPAQUE value, csrc/conv_h2s.hip -- what is derived from it is computed here, per tile, instead of being
+        //  hoisted in front of the item loop and carried through it; the other two epilogues sit at exactly 168 registers without spilling as they are)
+        int lane_e = lane;
+        if constexpr (EK == EK_GEN) asm volatile("" : "+v"(lane_e));
+        const int p16 = lane_e & 15, c4 = (lane_e >> 4) * 4;
         const int py0 = tl.y0 + wm * MT, px0 = tl.x0 + p16;
         int du_[NTW], cs_[NTW], bch_[NTW]; bool blk_[NTW];
         unsigned vo[NTW][MT][2];
+        // (the general epilogue derives the offsets and the bias words of ONE 32-column block at a time, inside its own loop: its 128-column kernel
+        //  has no registers to spare; the other two keep everything up front)
+        auto block_setup = [&](int k) __attribute__((always_inline)) {
+            const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + wn * WN + k * 32);
+            const int du = nwv >= a.n_split ? 1 : 0;
+            const int subu = a.n_sub ? nwv / a.n_sub : 0;
+            const int chw = nwv - subu * a.n_sub - (du ? a.n_split : 0);
+            const int yo2 = a.out_yoff + (subu >> 1), xo2 = a.out_xoff + (subu & 1);
+            du_[k] = du; cs_[k] = a.dst_cs[du]; blk_[k] = nwv < a.Ntot; bch_[k] = nwv - subu * a.n_sub;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int py = py0 + i, px = px0 + 16 * h;
+                    const int oy = py * a.out_mul + yo2, ox = px * a.out_mul + xo2;
+                    const bool ok = blk_[k] && py < a.DH && px < a.DW && oy >= 0 && oy < a.OH && ox >= 0 && ox < a.OW;
+                    vo[k][i][h] = ok ? (unsigned)(((oy * a.OW + ox) * cs_[k] + chw + c4) * 4) : OOB;
+                }
+        };
+        if constexpr (EK != EK_GEN) {
 #pragma unroll
         for (int k = 0; k < NTW; ++k) {
             const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + wn * WN + k * 32);
@@ -331,15 +355,22 @@ gemm_h2s_kernel(const H2Args ha) {
                     vo[k][i][h] = ok ? (unsigned)(((oy * a.OW + ox) * cs_[k] + chw + c4) * 4) : OOB;
                 }
         }
+        }
         auto rsrc = [&](const float* base, int k) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (int64_t)b * a.OH * a.OW * cs_[k]), 0, a.OH * a.OW * cs_[k] * 4, 0x00020000);
         };
         const float aslope = a.act == 1 ? 0.2f : (a.act == 2 ? 0.f : 1.f);
         f32x4 bias4[NB];
+        auto bias_load = [&](int j) __attribute__((always_inline)) {
+            bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (a.bias && blk_[j >> 1]) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + bch_[j >> 1] + 16 * (j & 1) + c4);
+        };
+        if constexpr (EK != EK_GEN) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             bias4[j] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (a.bias && blk_[j >> 1]) bias4[j] = *reinterpret_cast<const f32x4*>(a.bias + bch_[j >> 1] + 16 * (j & 1) + c4);
+        }
         }
         auto act4 = [&](f32x4 o) {
             const f32x4 t = o * aslope;
@@ -445,6 +476,7 @@ gemm_h2s_kernel(const H2Args ha) {
         // the general case (residual, accumulation), branch-free: what a block does not use is requested out of range (zeros, no traffic)
 #pragma unroll
         for (int k = 0; k < NTW; ++k) {
+            block_setup(k); bias_load(2 * k); bias_load(2 * k + 1);
             const int du = du_[k], mm2 = a.mask_mode[du], acc2 = a.accum[du];
             const bool use_add2 = a.addsrc && du == 0;
             const __amdgpu_buffer_rsrc_t rd = rsrc(a.dst[du], k);
@@ -453,26 +485,27 @@ gemm_h2s_kernel(const H2Args ha) {
             const float msl = mm2 == 1 ? 0.2f : 0.f;
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                f32x4 m2[MT][2], ad2[MT][2], pr2[MT][2];
+                // (one pixel row at a time: with the mask / residual / previous-value words of BOTH rows in flight -- 48 registers -- the 128-column kernel
+                //  spilled 7 registers into a 32-byte scratch frame)
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int i = 0; i < MT; ++i) {
+                    f32x4 m2[2], ad2[2], pr2[2];
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        m2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm2 ? vo[k][i][h] : OOB, jj * 64, 0));
-                        ad2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, use_add2 ? vo[k][i][h] : OOB, jj * 64, 0));
-                        pr2[i][h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, acc2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        m2[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, mm2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        ad2[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rad, use_add2 ? vo[k][i][h] : OOB, jj * 64, 0));
+                        pr2[h] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rd, acc2 ? vo[k][i][h] : OOB, jj * 64, 0));
                     }
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj] + ad2[i][h]);
+                        f32x4 o = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj] + ad2[h]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) o[c] *= (m2[i][h][c] > 0.f || !mm2) ? 1.f : msl;
-                        o += pr2[i][h];
+                        for (int c = 0; c < 4; ++c) o[c] *= (m2[h][c] > 0.f || !mm2) ? 1.f : msl;
+                        o += pr2[h];
                         track(o, vo[k][i][h] != OOB, du);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rd, vo[k][i][h], jj * 64, 0);
                     }
+                }
             }
         }
     };

@@ -280,7 +280,7 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
     // [z][tap][m][n]: 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
     float* red = reinterpret_cast<float*>(smem);
     const int dexp = -(se_g + se_x);                                 // undo the operand scales (exact: a power of two)
-    const int64_t slab_base = (int64_t)z * a.M * a.N * 9;
+    float* const slab_z = a.slab + (int64_t)z * a.M * a.N * 9;      // this split's slab: 9 M N < 2^31 floats (the launcher checks), so the index inside it is 32-bit
 #pragma unroll
     for (int mb = 0; mb < MW; ++mb)
 #pragma unroll
@@ -302,12 +302,13 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             }
         }
         if (wk == 0) {
+            // one base index per (block, tap); the 16 rows of the accumulator layout are compile-time multiples of N behind it (with a 64-bit index per
+            // element the compiler hoisted 16 address pairs and spilled: 12 bytes of scratch in the 64 x 64 kernel)
             const int t = tr * 3 + dx;
+            const unsigned base = (unsigned)((t * a.M + m0 + (mo + mb) * 32 + 4 * half) * a.N + n0 + no * 32 + l31);
+            const unsigned n_u = (unsigned)a.N;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + no * 32 + l31, m = m0 + (mo + mb) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                a.slab[slab_base + ((int64_t)t * a.M + m) * a.N + n] = __builtin_ldexpf(v[r], dexp);
-            }
+            for (int r = 0; r < 16; ++r) slab_z[base + (unsigned)((r & 3) + 8 * (r >> 2)) * n_u] = __builtin_ldexpf(v[r], dexp);
         }
     }
     WHS_BARRIER();                                                  // (the producers' bias reduction: two more barriers for every wave)
@@ -347,6 +348,7 @@ int launch_whs(const Wh2sArgs& a, hipStream_t s) {
 int pnnp_wh2s_th(int M, int N) { return (M % 64 == 0) ? ((N % 64 == 0) ? (WH2S_MW2 ? 2 : WH2S_TH22) : WH2S_TH21) : ((N % 64 == 0) ? WH2S_TH12 : WH2S_TH11); }
 
 int pnnp_wh2s_launch(const Wh2sArgs& a, hipStream_t s) {
+    if ((int64_t)a.M * a.N * 9 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;      // the kernel indexes one slab with 32 bits
 #if WH2S_MW2                          // (measured, profiles/r5/ab_wgrad_two_blocks_per_wave.txt: 64 x 64 tiles -3 ... -6 % per layer; 64 x 32 tiles +6 %: they keep one block per wave)
     if (a.M % 64 == 0 && a.N % 64 == 0) return launch_whs<2, 2, 2, 2>(a, s);
 #endif
