@@ -9,7 +9,8 @@
 //
 // Both pieces are FLOATING-point numbers -- hi the element's top 11 significand bits, lo its next 11 -- so the scale only matters where lo leaves fp16's
 // normal range: for every element within 2^-18 of the maximum the split, the products and the result are the same numbers times a power of two
-// WHATEVER scale was used (a crop's results are bit-identical alone and beside batch-mates up to 2^18 = 2.6e5 x brighter: tests/test_gpu_dp2.py).
+// WHATEVER scale was used (a crop beside batch-mates x 100 brighter: its few pixels below 2^-18 of THEIR maximum move its output by 1e-10 relative, the
+// bright crops' outputs are bit-identical: tests/test_gpu_dp2.py).
 //
 // The scale needs max|a| of the tensor BEFORE the kernel that splits it starts: every kernel that writes a tensor the h2 kernels read also
 // writes max|.| of what it stored into a 4-byte slot (atomicMax on the float's bit pattern: non-negative floats order like unsigned

@@ -63,3 +63,21 @@ def test_strong_scaling_uneven_global_batch_and_per_rank_record():
     w = out['allreduce_ms_per_step']                                                          # default mode: one exposed collective
     assert w['mean_min_over_ranks'] >= 0.0 and w['worst_step_any_rank'] >= w['mean_max_over_ranks'] >= w['mean_min_over_ranks']
     assert w['grad_bytes'] > 0
+
+
+@pytest.mark.parametrize('global_batch', [16, 128])
+def test_world_8_strong_overlap_rehearsal(global_batch):
+    """the launch line the driver uses on an 8-GPU node -- `torch.distributed.run --nproc-per-node 8 bench.py --gpus 8` -- with
+    `--strong --overlap-allreduce`, rehearsed as EIGHT ranks sharing this box's one GPU (gloo moves the CUDA buckets; the number is meaningless, the
+    path is the driver's): global batches of 16 (2 crops per rank: SURVEY 8(d) C4's strong-scaling point) and 128 (16 per rank: the weak-scaling
+    shard), the persistent split scoped to the overlapped backward pass, eight replicas bit-identical at the end, one JSON line from rank 0."""
+    out = _run(['--strong', '--batch', str(global_batch), '--overlap-allreduce'], nproc=8)
+    assert out['scaling'] == 'strong' and out['n_gpus'] == 8
+    assert out['config']['global_batch'] == global_batch and out['config']['crops_per_gpu'] == global_batch // 8
+    assert out['config']['parallelism'] == 'dp8'
+    assert abs(out['value'] - global_batch * 3 / (out['ms_per_step'] * 3e-3)) < 1e-6 * out['value']
+    assert out['replica_checksum_spread'] == 0.0
+    assert len(out['per_rank_ms_per_step']['all']) == 8
+    w = out['allreduce_wait_ms_per_step']
+    assert w['overlap'] is True and w['grad_bytes'] > 0
+    assert out['final_loss'] == out['final_loss'] and out['final_loss'] < 1.0

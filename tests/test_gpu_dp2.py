@@ -198,9 +198,10 @@ def test_h2_scale_depends_on_the_shard_within_bound():
     item 3d)?  Both pieces of the split are FLOATING-point (hi = the top 11 significand bits of the element, lo = the next 11), so a power-of-two scale
     changes nothing while `lo` stays a normal fp16 number, i.e. for every element within 2^-18 of its tensor's maximum: the products, the fp32
     accumulation and the final 2^-(se_x + se_w) are the same numbers times a power of two.  Stated tolerance, tested here on the nf = 32 UNet:
-      (1) shards whose magnitudes differ by x 100 (the data's range: ratio 100-300, dark and bright crops): a shard's outputs are BIT-IDENTICAL alone and
-          beside the other shard, and the whole batch's parameter gradient equals the sum of the shards' gradients to 1e-5 per tensor (another pixel
-          partition of the weight-gradient sums; fixed upstream gradient, so no L1 sign flips);
+      (1) shards whose magnitudes differ by x 100 (the data's range: ratio 100-300, dark and bright crops): the bright shard's outputs are BIT-IDENTICAL alone
+          and beside the dark one; the dark shard's differ only through its few elements that fall below 2^-18 of the BRIGHT maximum (a uniform crop x 0.01
+          has 4e-4 of its pixels below 3.8e-6): relative L2 below 1e-8 (measured 1e-10); the whole batch's parameter gradient equals the sum of the shards'
+          gradients to 1e-5 per tensor (another pixel partition of the weight-gradient sums; fixed upstream gradient, so no L1 sign flips);
       (2) shards that differ by x 1e7 (beyond 2^18: the dark shard's `lo` pieces are fp16 subnormals under the whole batch's scale): its outputs differ,
           by <= 2^-40 x 1e7 x a small factor of itself -- 1e-4 relative L2, finite -- while the bright shard's stay bit-identical."""
     from pnnp_amd.archs import UNetSeeInDark, initialize_weights
@@ -208,6 +209,10 @@ def test_h2_scale_depends_on_the_shard_within_bound():
     net = UNetSeeInDark(dict(nframes=1, res=False, nf=32, in_nc=4, out_nc=4)); initialize_weights(net); net = net.cuda()
     e = net.engine
     assert e.policy.h2
+    # (what ELSE depends on the shard size is the partition of a sum, never a scale: the pixel splits of the weight gradients, and -- on grids as small as
+    #  this test's -- the split-K factor of the forward layers: float32 rounding of another summation order, 2e-6 at most, tests/test_gpu_h2.py::test_h2_splitk_*.
+    #  Switched off here so that the SCALE is the only thing that differs between the runs.)
+    e.set_policy(splitk=False)
     g = torch.Generator(device='cuda').manual_seed(12)
     base = torch.rand(2, 4, 64, 64, device='cuda', generator=g)
     xb = torch.rand(2, 4, 64, 64, device='cuda', generator=g)                 # the bright shard
@@ -229,7 +234,7 @@ def test_h2_scale_depends_on_the_shard_within_bound():
         assert torch.equal(out_all[2:], out_b)                               # the bright shard sets the scales either way
         assert torch.isfinite(out_all).all()
         if same_bits:
-            assert torch.equal(out_all[:2], out_a)
+            assert ea < 1e-8
             worst = 0.0
             for n, p in net.named_parameters():
                 o, k = e.params.slices[n]

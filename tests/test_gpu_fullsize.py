@@ -110,8 +110,15 @@ def test_batch_of_16_crops_is_16_independent_crops_and_wino_equals_direct():
         yf = _fwd(net, x, fam)
         assert _rel(yf, yd) < 2e-5, fam                         # float32 arithmetic up to summation order / transforms / the 2^-24 split remainder
         for b in (0, 7, 15):
+            # (round 6: ONE crop gives the deep layers of the fp16x2 family 16-128 output tiles, which the engine cuts along K -- another partition of the
+            #  same sums, float32 rounding: 4e-6.  With the split off the tiling per crop is identical to the batch's and the old bar holds.)
             alone = _fwd(net, x[b:b + 1].contiguous(), fam)
-            assert _rel(alone[0], yf[b]) < 1e-6, fam            # identical tiling per crop: (near) bit-equal
+            assert _rel(alone[0], yf[b]) < (4e-6 if fam == 'h2' else 1e-6), fam
+            if fam == 'h2':
+                net.engine.set_policy(splitk=False)
+                alone = net.engine.forward(x[b:b + 1].contiguous(), False).clone()
+                net.engine.set_policy(splitk=True)
+                assert _rel(alone[0], yf[b]) < 1e-6, fam        # identical tiling per crop: (near) bit-equal
 
 
 def test_full_batch_backward_wino_vs_direct_and_mean_of_single_crops():
