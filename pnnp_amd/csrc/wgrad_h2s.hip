@@ -33,6 +33,11 @@ constexpr int NCW = 12, NPW = 4, NTHR = 64 * (NCW + NPW);
 constexpr int XC = 34;
 constexpr unsigned OOB = 0x80000000u;
 #define WHS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#ifdef WHS_STAMPS                     // debug build: cycle sums per wave, dumped into the slab (tools/whs_stamps.py; the results are then garbage)
+#define WHS_T(v) { const long long now_ = clock64(); v += now_ - tlast_; tlast_ = now_; }
+#else
+#define WHS_T(v)
+#endif
 #ifndef WX3_ALT_SIGN
 #define WX3_ALT_SIGN 1                 // odd pixel splits accumulate -G * X (csrc/wgrad_x3.hip: the matrix core's accumulation rounds toward minus infinity)
 #endif
@@ -168,14 +173,29 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         stage_tile(0);
         if (z + a.Z < ntile) load_tile(z + a.Z);
         int img = 0;
+#ifdef WHS_STAMPS
+        long long t_stage = 0, t_issue = 0, t_bar = 0, tlast_ = clock64(), tall = tlast_; int ntl = 0;
+#endif
         for (int tile = z; tile < ntile; tile += a.Z) {
             WHS_BARRIER();                                          // image img is complete; every consumer is done with the other one
+            WHS_T(t_bar)
+#ifdef WHS_STAMPS
+            ++ntl;
+#endif
             if (tile + a.Z < ntile) {
                 stage_tile(img ^ 1);                                // the next tile (requested a whole tile ago)
+                WHS_T(t_stage)
                 if (tile + 2 * a.Z < ntile) load_tile(tile + 2 * a.Z);
+                WHS_T(t_issue)
             }
             img ^= 1;
         }
+#ifdef WHS_STAMPS
+        if (lane == 0) {
+            float* d = a.slab + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+            d[0] = (float)t_stage; d[1] = (float)t_issue; d[2] = (float)t_bar; d[4] = (float)(clock64() - tall); d[5] = (float)ntl;
+        }
+#endif
         // ---- (the consumers' pixel-split reduction: 2 barriers per tap of a row when WK > 1) then the bias gradient of this pixel split: add up
         // the threads that share (block, q8) through LDS (the images are dead)
         if (WK > 1) {
@@ -222,8 +242,15 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         return u32x4{a0.x, a0.y, a1.x, a1.y};
     };
     int img = 0;
+#ifdef WHS_STAMPS
+    long long t_mfma = 0, t_bar = 0, tlast_ = clock64(), tall = tlast_; int ntl = 0;
+#endif
     for (int tile = z; tile < ntile; tile += a.Z) {
         WHS_BARRIER();
+        WHS_T(t_bar)
+#ifdef WHS_STAMPS
+        ++ntl;
+#endif
         const char* gimg = smem + img * IMG_BYTES;
         const char* ximg = gimg + G_BYTES;
         // MW = 1: operand words double-buffered (the next step's are read while this step's MFMAs issue).  MW = 2: 96 accumulator registers
@@ -275,7 +302,19 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             }
         }
         img ^= 1;
+#ifdef WHS_STAMPS
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_nop 0" ::: "memory");
+#endif
+        WHS_T(t_mfma)
     }
+#ifdef WHS_STAMPS
+    if (lane == 0) {
+        float* d = a.slab + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+        d[0] = (float)t_mfma; d[1] = 0.f; d[2] = (float)t_bar; d[4] = (float)(clock64() - tall); d[5] = (float)ntl;
+    }
+    return;
+#endif
     // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one accumulator block at a time), then the slab
     // [z][tap][m][n]: 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
     float* red = reinterpret_cast<float*>(smem);
