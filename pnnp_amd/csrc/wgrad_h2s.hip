@@ -244,11 +244,14 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
     int img = 0;
 #ifdef WHS_STAMPS
     long long t_mfma = 0, t_bar = 0, tlast_ = clock64(), tall = tlast_; int ntl = 0;
+    const long long t_entry = tlast_;
+    long long t_first = 0;
 #endif
     for (int tile = z; tile < ntile; tile += a.Z) {
         WHS_BARRIER();
         WHS_T(t_bar)
 #ifdef WHS_STAMPS
+        if (!ntl) t_first = tlast_ - t_entry;                       // kernel entry -> the first tile is staged
         ++ntl;
 #endif
         const char* gimg = smem + img * IMG_BYTES;
@@ -309,11 +312,7 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
         WHS_T(t_mfma)
     }
 #ifdef WHS_STAMPS
-    if (lane == 0) {
-        float* d = a.slab + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
-        d[0] = (float)t_mfma; d[1] = 0.f; d[2] = (float)t_bar; d[4] = (float)(clock64() - tall); d[5] = (float)ntl;
-    }
-    return;
+    const long long t_loop_end = clock64();
 #endif
     // ---- the pixel splits of a (block, row) are added up through LDS (the images are dead; one accumulator block at a time), then the slab
     // [z][tap][m][n]: 32 x 32 x 16 accumulator layout: column l31, row (r & 3) + 8 (r >> 2) + 4 half
@@ -352,6 +351,13 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
     }
     WHS_BARRIER();                                                  // (the producers' bias reduction: two more barriers for every wave)
     WHS_BARRIER();
+#ifdef WHS_STAMPS
+    __builtin_amdgcn_s_waitcnt(0x0f70);                             // (the slab stores have left: what follows overwrites a corner of the slab)
+    if (lane == 0) {
+        float* d = a.slab + ((int64_t)blockIdx.x * (NCW + NPW) + wave) * 8;
+        d[0] = (float)t_mfma; d[1] = (float)t_first; d[2] = (float)t_bar; d[3] = (float)(clock64() - t_loop_end); d[4] = (float)(t_loop_end - tall); d[5] = (float)ntl;
+    }
+#endif
 }
 
 template <int MO, int NO, int TH, int MW = 1>

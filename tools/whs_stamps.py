@@ -15,9 +15,9 @@ for _ in range(3):
     ops.conv_h2_bwd_weight(g, sg, Co, x, sx, Ci, None, None, dW, db, ws)
 torch.cuda.synchronize()
 d = ws[:256 * 16 * 8].reshape(256, 16, 8).cpu()
-for wv, names in ((0, ['mfma', '-', 'barrier']), (6, None), (12, ['stage(+wait)', 'issue', 'barrier']), (13, None)):
+for wv, names in ((0, ['mfma', 'entry->first tile (total)', 'barrier', 'epilogue (total)']), (6, None), (12, ['stage(+wait)', 'issue', 'barrier']), (13, None)):
     if names: cn = names
     m = d[:, wv].mean(0); n = max(float(m[5]), 1.0)
-    print(('consumer' if wv < 12 else 'producer'), wv, ' '.join(f'{k}={float(v) / n:.0f}' for k, v in zip(cn, m)), f'total/tile={float(m[4]) / n:.0f} tiles={n:.0f}')
+    print(('consumer' if wv < 12 else 'producer'), wv, ' '.join(f'{k}={float(v) / (1.0 if "total" in k else n):.0f}' for k, v in zip(cn, m)), f'loop/tile={float(m[4]) / n:.0f} tiles={n:.0f}')
 th = {(1, 1): 4, (1, 0): 3, (0, 1): 3, (0, 0): 2}[(Co % 64 != 0, Ci % 64 != 0)] if False else None
 print(f'wgrad {S} {Ci}->{Co}')
