@@ -494,9 +494,9 @@ igemm_h2s_kernel(const H2Args ha) {
             return o;
         };
         // Undoing the operand scales: x 2^dexp (exact).  As ONE multiplier (fused with the bias add where there is one) while 2^dexp is a normal
-        // float32; tensors so small / large that it is not (|dexp| > 126: max |x| max |w| beyond 2^+-98) first take the remainder in a pass over the
+        // float32 with room for the LeakyReLU slope; tensors so small / large that it is not (|dexp| > 120: max |x| max |w| beyond 2^+-92) first take the remainder in a pass over the
         // accumulators -- a wave-uniform branch that the networks' tensors never take (tests/test_gpu_h2.py::test_h2_dynamic_range does).
-        const int dexp_c = ea.dexp < -126 ? -126 : (ea.dexp > 127 ? 127 : ea.dexp);
+        const int dexp_c = ea.dexp < -120 ? -120 : (ea.dexp > 120 ? 120 : ea.dexp);      // (|.| <= 120: 0.2 x 2^dexp_c stays a normal float32, see mask_scale)
         const float dsc = __uint_as_float((unsigned)(dexp_c + 127) << 23);
         if (ea.dexp != dexp_c) {
 #pragma unroll
@@ -549,11 +549,17 @@ igemm_h2s_kernel(const H2Args ha) {
                 asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_addc_co_u32 %0, %1, %0, %0, vcc" : "+v"(sb), "=s"(cout_) : "v"(o) : "vcc");
             }
         };
-        // one element of the bit-masked backward epilogue: the next bit of mb out (carry of mb + mb), o = bit ? o : msl o
-        auto mask_bit = [](float& o, unsigned& mb_, float msl) __attribute__((always_inline)) {
-            if constexpr (H2S_ABL & 32) return;
-            float t;
-            asm("v_add_co_u32 %1, vcc, %1, %1\n\tv_mul_f32 %2, %3, %0\n\tv_cndmask_b32 %0, %2, %0, vcc" : "+v"(o), "+v"(mb_), "=&v"(t) : "v"(msl) : "vcc");
+        // one element of the bit-masked backward epilogue, scale included: the next bit of mb out (carry of mb + mb), o = v x (bit ? 2^dexp : msl 2^dexp) --
+        // three instructions where scaling first and masking afterwards took four; bit-identical: 2^dexp is a power of two, so (v 2^dexp) msl == v (2^dexp msl)
+        auto mask_scale = [](float v, unsigned& mb_, float fpos, float fneg) __attribute__((always_inline)) {
+            float f, o;
+            asm("v_add_co_u32 %2, vcc, %2, %2\n\tv_cndmask_b32 %1, %4, %3, vcc\n\tv_mul_f32 %0, %1, %5" : "=v"(o), "=&v"(f), "+v"(mb_) : "v"(fpos), "v"(fneg), "v"(v) : "vcc");
+            return o;
+        };
+        auto take_raw = [&](int mb, int j) {                         // the accumulator block as it is (the caller scales), zeroed for the next tile
+            const f32x4 v = acc[mb][j];
+            if constexpr (!(H2S_ABL & 8)) acc[mb][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            return v;
         };
         // ---- full-line memory pattern (FWD / BWD / POOL: see csrc/conv_x3s.hip)
         const bool lo8 = p16 < 8;
@@ -715,6 +721,13 @@ igemm_h2s_kernel(const H2Args ha) {
                                 for (int c = 0; c < 4; ++c) { float e = o0[c]; act_sign(e, sb, aslope, act_tag); o0[c] = e; }
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { float e = o1[c]; act_sign(e, sb, aslope, act_tag); o1[c] = e; }
+                            } else if constexpr (BITS) {
+                                const f32x4 v0 = take_raw(2 * i + h, 2 * k), v1 = take_raw(2 * i + h, 2 * k + 1);
+                                const float fneg = dsc * msl;
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o0[c] = mask_scale(v0[c], mbits[k], dsc, fneg);
+#pragma unroll
+                                for (int c = 0; c < 4; ++c) o1[c] = mask_scale(v1[c], mbits[k], dsc, fneg);
                             } else {
                                 o0 = take(2 * i + h, 2 * k); o1 = take(2 * i + h, 2 * k + 1);
                             }
@@ -724,12 +737,6 @@ igemm_h2s_kernel(const H2Args ha) {
                                 const f32x4 t0 = o0 * msl, t1 = o1 * msl;
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
-                            }
-                            if constexpr (BITS) {
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) { float e = o0[c]; mask_bit(e, mbits[k], msl); o0[c] = e; }
-#pragma unroll
-                                for (int c = 0; c < 4; ++c) { float e = o1[c]; mask_bit(e, mbits[k], msl); o1[c] = e; }
                             }
                             track(o0); track(o1);
                             if constexpr (EK == EK_HEAD) {
