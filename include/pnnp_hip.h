@@ -299,6 +299,10 @@ int pnnp_convt2x2_h2_fwd_f32(const float* x, int Cin, const unsigned* amax_x, co
                              unsigned* amax_y /*or null*/, int B, int H, int W, int Cout, void* stream);
 int pnnp_convt2x2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,
                                   const float* mask /*or null*/, int mode, unsigned* amax_dx /*or null*/, int B, int H, int W, void* stream);
+/* ... with the act' mask as the SIGN BITS pnnp_conv3x3_h2_fwd_f32 / _fwd_pool_f32 stored for the layer's input map (round 6: the float32 activation is not read:
+ * 503 MB per UNet step); bits: pnnp_h2_bits_words(B, H, W, Cin) words, Cin % 32 == 0, mode 1 LeakyReLU(0.2)' / 2 ReLU'.  Bit-identical to the float32-mask entry. */
+int pnnp_convt2x2_h2_bwd_data_bits_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                       const unsigned* bits, int mode, unsigned* amax_dx, int B, int H, int W, void* stream);
 int pnnp_conv1x1_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2 /*or null*/, int C2, const unsigned* amax_x2, const void* w_h2,
                             const unsigned* amax_w, const float* bias /*or null*/, const float* residual /*or null*/, float* y, unsigned* amax_y /*or null*/,
                             int B, int H, int W, int Cout, int act, void* stream);

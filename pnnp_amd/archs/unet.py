@@ -43,9 +43,10 @@ class ConvPolicy:
         self.h2_pointwise = bool(h2) and os.environ.get('PNNP_H2_POINTWISE', '1') != '0'      # (A/B switch: ConvTranspose2d stays on bf16x3 with 0)
         self.head_fused = bool(h2) and os.environ.get('PNNP_HEAD_FUSED', '1') != '0'          # (A/B switch) conv10_1 inside conv9_2's epilogue (round 6)
         self.splitk = bool(h2) and os.environ.get('PNNP_SPLITK', '1') != '0'                  # (A/B switch) split-K forward launches for small grids (round 6)
+        self.convt_bits = bool(h2) and os.environ.get('PNNP_CONVT_BITS', '1') != '0'          # (A/B switch) ConvTranspose2d backward-data masks with sign bits (round 6)
 
     def key(self):
-        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise, self.head_fused, self.splitk)
+        return (self.wino, self.wino_wgrad, self.wino_mink, self.x3, self.thin, self.pool_fused, self.h2, self.h2_wgrad, self.h2_pointwise, self.head_fused, self.splitk, self.convt_bits)
 
     def use_thin_head(self, cin, cout, npix):
         return self.thin and ops.head_supported(cin, cout, npix)
@@ -129,7 +130,7 @@ class _EngineBase:
         if policy is None:
             cur = dict(wino=self.policy.wino, wino_wgrad=self.policy.wino_wgrad, wino_mink=self.policy.wino_mink, x3=self.policy.x3,
                        thin=self.policy.thin, pool_fused=self.policy.pool_fused, h2=self.policy.h2)
-            for k in ('h2_wgrad', 'h2_pointwise', 'head_fused', 'splitk'):   # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
+            for k in ('h2_wgrad', 'h2_pointwise', 'head_fused', 'splitk', 'convt_bits'):   # sub-switches of h2 (host-side A/B): not constructor arguments, kept as overrides
                 if k in kw:
                     self._h2_sub[k] = bool(kw.pop(k))
             cur.update(kw)
@@ -718,8 +719,10 @@ class UNetEngine(_EngineBase):
             if f'upv{i}' in self._h2m:
                 if id(g_u) not in gname:
                     gproduced(g_u, f'gu{i}', fused=False)
+                # the act' mask as the sign bits conv{i-1}_2's forward kernel stored (the float32 activation is not read: 503 MB per step over the four layers)
+                bits_below = a.get('bits:' + src_name.get(id(below), '?')) if self._pol.convt_bits else None
                 ops.convt_h2_bwd_data(g_u, gslot(g_u), self._h2m[f'upv{i}'][1], self._wslot[f'upv{i}'], g_cur, mask=below, mode=LRELU,
-                                      amax_dx=bufs.slot('b', f'upv{i}', dev))
+                                      amax_dx=bufs.slot('b', f'upv{i}', dev), bits=bits_below if (bits_below is not None and below.shape[3] % 32 == 0) else None)
                 gproduced(g_cur, f'upv{i}', fused=True)
             elif self._x3.get(f'upv{i}', (False, False))[1]:
                 ops.convt_x3_bwd_data(g_u, self._wx(f'upv{i}')[1], g_cur, mask=below, mode=LRELU, amax_dx=bufs.slot('b', f'upv{i}', dev) if h2_on else None)

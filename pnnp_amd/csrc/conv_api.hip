@@ -445,6 +445,18 @@ int pnnp_convt2x2_h2_bwd_data_f32(const float* g, int Cout, const unsigned* amax
     h.g.amax_out[0] = amax_dx; h.amax_in[0] = amax_g; h.amax_w = amax_w;
     return gemm_h2_go(h, Cout, as_stream(stream));
 }
+// ... with the LeakyReLU' / ReLU' mask as the sign bits the 3x3 forward kernel stored for the layer's INPUT map (bits: pnnp_h2_bits_words(B, H, W, Cin) words)
+int pnnp_convt2x2_h2_bwd_data_bits_f32(const float* g, int Cout, const unsigned* amax_g, const void* w_h2_dgrad, const unsigned* amax_w, float* dx, int Cin,
+                                       const unsigned* bits, int mode, unsigned* amax_dx, int B, int H, int W, void* stream) {
+    if (!g || !w_h2_dgrad || !dx || !amax_g || !amax_w || !bits || !mode || B < 0 || H <= 0 || W <= 0 || (Cin & 31)) return PNNP_E_INVALID;
+    if (B == 0) return PNNP_OK;
+    H2Args h{};
+    convt_bwd_args(h.g, g, Cout, w_h2_dgrad, dx, Cin, nullptr, 0, B, H, W);
+    h.g.mask_mode[0] = mode;
+    h.g.amax_out[0] = amax_dx; h.amax_in[0] = amax_g; h.amax_w = amax_w;
+    h.bits_in[0] = bits; h.bits_nblk[0] = Cin / 32;
+    return gemm_h2_go(h, Cout, as_stream(stream));
+}
 int pnnp_conv1x1_h2_fwd_f32(const float* x1, int C1, const unsigned* amax_x1, const float* x2, int C2, const unsigned* amax_x2, const void* w_h2,
                             const unsigned* amax_w, const float* bias, const float* residual, float* y, unsigned* amax_y,
                             int B, int H, int W, int Cout, int act, void* stream) {

@@ -75,7 +75,8 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #else
 #define GHS_T(v)
 #endif
-enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2 };                       // the epilogue a kernel carries: plain / act' masks / residual + accumulation
+enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_BWDB = 3 };          // the epilogue a kernel carries: plain / act' masks (float32) / residual + accumulation / act' masks as the
+                                                                   // 3x3 forward kernel's SIGN BITS (round 6: ConvTranspose2d backward-data read 503 MB of float32 activations per step as masks)
 
 template <int BN, int WN, int EK>
 __global__ void __launch_bounds__(NTHR, 1)
@@ -381,7 +382,7 @@ gemm_h2s_kernel(const H2Args ha) {
         // Undoing the operand scales: x 2^dexp (exact) as one multiplier while 2^dexp is a normal float32; tensors so small / large that it is
         // not first take the remainder in a pass over the accumulators (csrc/conv_h2s.hip)
         const int dexp = -(se_x + se_w);
-        const int dexp_c = dexp < -126 ? -126 : (dexp > 127 ? 127 : dexp);
+        const int dexp_c = dexp < -120 ? -120 : (dexp > 120 ? 120 : dexp);      // (|.| <= 120: 0.2 x 2^dexp_c stays a normal float32: mask_scale)
         const float dsc = __uint_as_float((unsigned)(dexp_c + 127) << 23);
         if (dexp != dexp_c) {
 #pragma unroll
@@ -397,8 +398,8 @@ gemm_h2s_kernel(const H2Args ha) {
             const float m = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fmaxf(fabsf(o.z), fabsf(o.w)));
             amx0 = fmaxf(amx0, (valid && !du) ? m : 0.f);
         };
-        if constexpr (EK == EK_FWD || EK == EK_BWD) {
-            constexpr bool MASKED = EK == EK_BWD;
+        if constexpr (EK == EK_FWD || EK == EK_BWD || EK == EK_BWDB) {
+            constexpr bool MASKED = EK == EK_BWD, BITS = EK == EK_BWDB;
             // FULL-LINE memory pattern (csrc/conv_x3s.hip): the two 16-column blocks of a 32-column block trade halves between lanes p and p + 8
             // of a 16-lane row, so that each 16-byte store instruction writes 8 pixels x 128 bytes (whole lines) instead of 16 x 64; the
             // act' masks come in by the same pattern and are traded back.
@@ -413,12 +414,23 @@ gemm_h2s_kernel(const H2Args ha) {
             auto sel = [&](bool c, f32x4 x, f32x4 y) { return f32x4{c ? x.x : y.x, c ? x.y : y.y, c ? x.z : y.z, c ? x.w : y.w}; };
             // this lane's byte offsets in instruction 1 (pixel p16 & 7 of the half) and 2 (eight pixels on) of block k
             unsigned wo[NTW][MT][2][2];
+            unsigned mbits[BITS ? NTW : 1];                          // (EK_BWDB) this lane's word of the tile-private sign-bit image (csrc/h2.h) per 32-column block
             const int pxl = tl.x0 + (p16 & 7);
 #pragma unroll
             for (int k = 0; k < NTW; ++k) {
                 const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + wn * WN + k * 32);
                 const int subu = a.n_sub ? nwv / a.n_sub : 0;
                 const int chw = nwv - subu * a.n_sub - (du_[k] ? a.n_split : 0);
+                if constexpr (BITS) {
+                    // The 3x3 kernel's word (16-row tile ty, tile column, 32-channel block, its consumer wave w16, lane) holds rows 2 w16 + i, pixels 16 h + (lane & 15),
+                    // channels 16 jj + 4 (lane >> 4) + c of the block -- exactly the 32 values THIS lane holds of the block (this wave's rows py0, py0 + 1: py0 even),
+                    // in the order the loop below walks them.  Plain output geometry only (the launcher checks): out pixel = tile pixel.
+                    const int tiles_x16 = (a.OW + 31) >> 5, tiles_y16 = (a.OH + 15) >> 4, nblk = ha.bits_nblk[0];
+                    const int tile_id = (b * tiles_y16 + (py0 >> 4)) * tiles_x16 + (tl.x0 >> 5);
+                    const unsigned word = (unsigned)((((tile_id * nblk + (chw >> 5)) * 8 + ((py0 & 15) >> 1)) * 64 + lane) * 4);
+                    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)ha.bits_in[0], 0, a.B * tiles_y16 * tiles_x16 * nblk * 8 * 64 * 4, 0x00020000);
+                    mbits[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, (blk_[k] && a.mask_mode[du_[k]] && !du_[k] && py0 < a.DH) ? word : OOB, 0, 0);
+                }
                 const int yo2 = a.out_yoff + (subu >> 1), xo2 = a.out_xoff + (subu & 1);
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -456,8 +468,25 @@ gemm_h2s_kernel(const H2Args ha) {
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
-                        f32x4 o0 = take(2 * i + h, 2 * k), o1 = take(2 * i + h, 2 * k + 1);
-                        if constexpr (!MASKED) { o0 = act4(o0 + bias4[2 * k]); o1 = act4(o1 + bias4[2 * k + 1]); }      // (backward-data: no bias, no activation -- the launcher checks)
+                        f32x4 o0, o1;
+                        if constexpr (BITS) {
+                            // scale and mask in three instructions per element (csrc/conv_h2s.hip mask_scale): next bit -> vcc, 2^dexp or msl 2^dexp, multiply
+                            const f32x4 v0 = acc[2 * i + h][2 * k], v1 = acc[2 * i + h][2 * k + 1];
+                            acc[2 * i + h][2 * k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * i + h][2 * k + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            const float fneg = dsc * msl;
+                            auto ms = [&](float v) __attribute__((always_inline)) {
+                                float f, o;
+                                asm("v_add_co_u32 %2, vcc, %2, %2\n\tv_cndmask_b32 %1, %4, %3, vcc\n\tv_mul_f32 %0, %1, %5" : "=v"(o), "=&v"(f), "+v"(mbits[k]) : "v"(dsc), "v"(fneg), "v"(v) : "vcc");
+                                return o;
+                            };
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o0[c] = ms(v0[c]);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) o1[c] = ms(v1[c]);
+                        } else {
+                            o0 = take(2 * i + h, 2 * k); o1 = take(2 * i + h, 2 * k + 1);
+                        }
+                        if constexpr (!MASKED && !BITS) { o0 = act4(o0 + bias4[2 * k]); o1 = act4(o1 + bias4[2 * k + 1]); }      // (backward-data: no bias, no activation -- the launcher checks)
                         if constexpr (MASKED) {
                             const f32x4 m1 = mk[2 * i + h][2 * k], m2 = mk[2 * i + h][2 * k + 1], mx = ror8(sel(lo8, m2, m1));
                             const f32x4 q0 = sel(lo8, m1, mx), q1 = sel(lo8, mx, m2);
@@ -559,6 +588,12 @@ int launch_ghs_ek(const H2Args& ha, hipStream_t s) {
     const bool plain = !b.addsrc && !b.accum[0] && !(two && b.accum[1]);
     const bool any_mask = b.mask_mode[0] || (two && b.mask_mode[1]);
     if (plain && !any_mask) return launch_ghs<BN, WN, EK_FWD>(ha, s);
+    if (ha.bits_in[0]) {
+        // sign-bit masks: one plain destination in the tile domain's own geometry (ConvTranspose2d backward-data), the bit image must fit a buffer resource
+        if (!plain || two || b.act || b.bias || !b.mask_mode[0] || b.n_sub || b.out_mul != 1 || b.out_yoff || b.out_xoff || b.OH != b.DH || b.OW != b.DW ||
+            ha.bits_nblk[0] * 32 != b.dst_cs[0] || (int64_t)b.B * ((b.OH + 15) / 16) * ((b.OW + 31) / 32) * ha.bits_nblk[0] * 2048 >= (1ll << 31)) return PNNP_E_UNSUPPORTED;
+        return launch_ghs<BN, WN, EK_BWDB>(ha, s);
+    }
     if (plain && !b.act && !b.bias) return launch_ghs<BN, WN, EK_BWD>(ha, s);
     return launch_ghs<BN, WN, EK_GEN>(ha, s);
 }
@@ -569,7 +604,7 @@ int launch_ghs_ek(const H2Args& ha, hipStream_t s) {
 // segment a multiple of 32 channels) and Ntot a multiple of 64; weights = the kind-6 pack (csrc/pack_jobs.hip), amax slots as in csrc/h2.h.
 int pnnp_gemm_h2s_launch(const H2Args& ha, hipStream_t s) {
     const IgemmArgs& b = ha.g;
-    if (!ha.amax_in[0] || !ha.amax_w || b.amax_out[1] || ha.bits_out || ha.bits_in[0] || ha.bits_in[1]) return PNNP_E_INVALID;
+    if (!ha.amax_in[0] || !ha.amax_w || b.amax_out[1] || ha.bits_out || ha.bits_in[1]) return PNNP_E_INVALID;
     if (b.Ntot % 64 || b.chunks_per_seg <= 0) return PNNP_E_UNSUPPORTED;
     if (b.Ntot % 128 == 0) return launch_ghs_ek<128, 64>(ha, s);
     return launch_ghs_ek<64, 32>(ha, s);

@@ -408,10 +408,15 @@ def convt_h2_fwd(x, amax_x, w_h2, amax_w, bias, y, cout, amax_y=None):
     return y
 
 
-def convt_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx, mask=None, mode=0, amax_dx=None):
-    require_cuda(g, w_h2_dgrad, dx, amax_g, amax_w)
+def convt_h2_bwd_data(g, amax_g, w_h2_dgrad, amax_w, dx, mask=None, mode=0, amax_dx=None, bits=None):
+    """``bits``: the act' mask as the sign bits a 3x3 fp16x2 forward kernel stored for the layer's input map (then ``mask`` is not read)."""
+    require_cuda(g, w_h2_dgrad, dx, amax_g, amax_w, bits)
     B, H, W, Cin = dx.shape
     with _Timed('convt_dgrad_h2', 8.0 * B * H * W * Cin * g.shape[3], 4.0 * B * H * W * (Cin + 4 * g.shape[3])):
+        if bits is not None and mode:
+            check(_prep().pnnp_convt2x2_h2_bwd_data_bits_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), Cin, ptr(bits), mode, ptr(amax_dx),
+                                                             B, H, W, stream()), 'convt_h2_bwd_data (bit masks)')
+            return
         check(_prep().pnnp_convt2x2_h2_bwd_data_f32(ptr(g), g.shape[3], ptr(amax_g), ptr(w_h2_dgrad), ptr(amax_w), ptr(dx), Cin, ptr(mask), mode, ptr(amax_dx),
                                                     B, H, W, stream()), 'convt_h2_bwd_data')
 

@@ -192,3 +192,32 @@ def test_pointwise_weight_gradients_h2_vs_float64():
     ops.conv1x1_h2_bwd_weight(gy, _slot(gy), C, x1, _slot(x1), C, x2, _slot(x2), dW, None, ws, accumulate=1)
     ref = base.double() + torch.einsum('bhwo,bhwi->oi', gy.double(), torch.cat([x1, x2], 3).double())
     _wgrad_check('1x1 dW (accumulated)', dW, ref)
+
+
+@pytest.mark.parametrize('shape', [(2, 24, 40, 64, 64), (1, 16, 32, 128, 128), (2, 9, 70, 64, 32)])
+def test_convt_h2_bwd_data_with_sign_bits_equals_float_masks(shape):
+    """Round 6: ConvTranspose2d backward-data takes the LeakyReLU' mask of its input map from the SIGN BITS the 3x3 forward kernel stored for that map (tile-private
+    layout, csrc/h2.h) instead of reading the float32 activation: bit-identical gradients, ragged maps included (rows / columns that do not fill the 16 x 32 tiles)."""
+    from pnnp_amd import ops
+    B, H, W, Cin, Cout = shape          # ConvTranspose2d(Cin -> Cout): dx [B,H,W,Cin] from g [B,2H,2W,Cout]; mask = an activation [B,H,W,Cin] written by a 3x3 layer
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    # the map `below` and its sign bits come out of a 3x3 fp16x2 forward layer, as in the network
+    xin = torch.randn(B, H, W, 32, device='cuda', generator=gen)
+    w3 = torch.randn(Cin, 32, 3, 3, device='cuda', generator=gen) * 0.1
+    jobs = ops.PackJobs(); f3 = torch.zeros(ops.h2_weight_bytes(32, Cin), dtype=torch.uint8, device='cuda'); s3 = jobs.add_h2(w3, f3, None, cin_pad=32); jobs.run()
+    slot = lambda t: ops.amax(t, torch.zeros(1, dtype=torch.int32, device='cuda'))
+    below = torch.empty(B, H, W, Cin, device='cuda'); bits = torch.zeros(ops.h2_bits_words(B, H, W, Cin), dtype=torch.int32, device='cuda')
+    ops.conv_h2_fwd(xin, None, f3, s3, None, below, Cin, 1, slot(xin), bits_y=bits)
+    wt = torch.randn(Cin, Cout, 2, 2, device='cuda', generator=gen) * 0.1
+    g = torch.randn(B, 2 * H, 2 * W, Cout, device='cuda', generator=gen)
+    jobs = ops.PackJobs(); fd = torch.zeros(ops.h2mat_bytes(4 * Cout, Cin), dtype=torch.uint8, device='cuda'); ff = torch.zeros(ops.h2mat_bytes(Cin, 4 * Cout), dtype=torch.uint8, device='cuda')
+    sw = jobs.add_h2_convt(wt, ff, fd); jobs.run()
+    sg = slot(g)
+    dx_f = torch.full((B, H, W, Cin), float('nan'), device='cuda'); dx_b = torch.full_like(dx_f, float('nan'))
+    a_f = torch.zeros(1, dtype=torch.int32, device='cuda'); a_b = torch.zeros(1, dtype=torch.int32, device='cuda')
+    ops.convt_h2_bwd_data(g, sg, fd, sw, dx_f, mask=below, mode=1, amax_dx=a_f)
+    ops.convt_h2_bwd_data(g, sg, fd, sw, dx_b, mask=None, mode=1, amax_dx=a_b, bits=bits)
+    assert torch.isfinite(dx_b).all()
+    assert torch.equal(dx_b, dx_f) and torch.equal(a_b, a_f)
+    frac_neg = float((below <= 0).float().mean())
+    assert 0.2 < frac_neg < 0.8                                      # the mask really selects

@@ -16,4 +16,4 @@ def test_set_policy_keeps_explicit_h2_sub_switches():
     assert not e.policy.h2_wgrad and not e.policy.h2_pointwise
     e.set_policy(h2=True, h2_wgrad=True)
     assert e.policy.h2_wgrad and not e.policy.h2_pointwise
-    assert len(e.policy.key()) == 11
+    assert len(e.policy.key()) == 12
