@@ -62,6 +62,10 @@ class ResUnetEngine(_EngineBase):
             self.packed[k] = torch.empty(n, dtype=dtype, device=dev)
         return self.packed[k]
 
+    def grad_out_channels(self, B, H, W):
+        """channels of the NHWC loss gradient backward() wants (UNetEngine.grad_out_channels)"""
+        return 4 if (self.cout == 4 and self._pol.use_thin_head(self.ch[0], self.cout, B * H * W)) else self.cout_pad
+
     def pack_weights(self, train):
         """Re-pack every layer's weights for the kernels; the job table is built once per device / mode / parameter storage
         and runs in a few launches per step (ops.PackJobs)."""

@@ -185,7 +185,7 @@ class _EngineBase:
             if isinstance(k, str) and not k.startswith(('bits:', 'pc', '_')):
                 add(k, 'act', t)
         for k, t in self.bufs[key].t.items():
-            if isinstance(k, str) and k.startswith('g_') and k != 'g_out8':
+            if isinstance(k, str) and k.startswith('g_') and k not in ('g_out8', 'g_out4'):
                 add(k, 'grad', t)
         return rows
 
@@ -397,6 +397,10 @@ class UNetEngine(_EngineBase):
         the fp16x2 kernel; reflect-padded eval frames included (the head writes the PADDED NCHW planes like head_fwd did)."""
         return (self._pol.head_fused and self.ch[0] == 32 and self.cout == 4 and self._h2.get('conv9_2', (None, None))[0] is not None
                 and self.m.conv10_1.weight.shape[1] == 32)
+
+    def grad_out_channels(self, B, H, W):
+        """channels of the NHWC loss gradient backward() wants: the streaming head kernel takes the 4 real ones (half the bytes of the zero-padded copy)"""
+        return 4 if (self.cout == 4 and self._pol.use_thin_head(self.ch[0], self.cout, B * H * W)) else self.cout_pad
 
     def _w(self, name):
         """(forward, backward-data) direct packs of a layer (ConvTranspose2d: the pair built by add_convt)."""

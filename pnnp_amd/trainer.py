@@ -324,7 +324,9 @@ class HipTrainStep:
                 scale = scale.expand(B).contiguous()
         pred = e.forward(noisy, True)
         bufs = e.bufs[(B, H, W, dev)]
-        g8 = bufs.get('g_out8', (B, H, W, e.cout_pad), dev)
+        # dL/d(out), NHWC: 4 channels when the 1x1 head's backward runs on the streaming kernel (it reads gcs >= 4), zero-padded to 8 for the GEMM kernels
+        gch = e.grad_out_channels(B, H, W) if hasattr(e, 'grad_out_channels') else e.cout_pad
+        g8 = bufs.get('g_out8' if gch == e.cout_pad else 'g_out4', (B, H, W, gch), dev)
         loss = bufs.get('loss_out', (1 + B,), dev)
         lws = bufs.get('loss_ws', (128 * B,), dev)
         # trainer_SID.py:485: the target is clamped under dst.clip, in the kernel; uneven shards of a global batch: this rank's mean
