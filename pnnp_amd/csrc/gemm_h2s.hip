@@ -483,10 +483,17 @@ gemm_h2s_kernel(const H2Args ha) {
                             for (int c = 0; c < 4; ++c) o0[c] = ms(v0[c]);
 #pragma unroll
                             for (int c = 0; c < 4; ++c) o1[c] = ms(v1[c]);
+                        } else if constexpr (!MASKED) {
+                            // forward: scale and bias in ONE fma per element; the activation only where the layer has one (ConvTranspose2d has none: it used to pay a
+                            // multiply and a maximum per element for max(o, 1.0 o))
+                            const f32x4 v0 = acc[2 * i + h][2 * k], v1 = acc[2 * i + h][2 * k + 1];
+                            acc[2 * i + h][2 * k] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[2 * i + h][2 * k + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { o0[c] = __builtin_fmaf(v0[c], dsc, bias4[2 * k][c]); o1[c] = __builtin_fmaf(v1[c], dsc, bias4[2 * k + 1][c]); }
+                            if (a.act) { o0 = act4(o0); o1 = act4(o1); }
                         } else {
                             o0 = take(2 * i + h, 2 * k); o1 = take(2 * i + h, 2 * k + 1);
                         }
-                        if constexpr (!MASKED && !BITS) { o0 = act4(o0 + bias4[2 * k]); o1 = act4(o1 + bias4[2 * k + 1]); }      // (backward-data: no bias, no activation -- the launcher checks)
                         if constexpr (MASKED) {
                             const f32x4 m1 = mk[2 * i + h][2 * k], m2 = mk[2 * i + h][2 * k + 1], mx = ror8(sel(lo8, m2, m1));
                             const f32x4 q0 = sel(lo8, m1, mx), q1 = sel(lo8, mx, m2);
