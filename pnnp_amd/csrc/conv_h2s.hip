@@ -622,7 +622,7 @@ igemm_h2s_kernel(const H2Args ha) {
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int i = 0; i < 2; ++i) {
-                            wn[jj][i] = act4(take(2 * i + h, 2 * k + jj) + bias4[2 * k + jj]);
+                            wn[jj][i] = act4(take_bias(2 * i + h, 2 * k + jj, bias4[2 * k + jj]));      // (one fma for scale + bias: bit-identical, v 2^dexp is exact)
                             track(wn[jj][i]);
                             sb |= signs4(wn[jj][i], ((i * 2 + h) * 2 + jj) * 4);
                         }
