@@ -474,8 +474,10 @@ class UNetEngine(_EngineBase):
             return t
 
         def splitk(src, src2, h, w, cout):
-            """K slices of a 3x3 fp16x2 forward launch on this map (1: none)"""
-            if not self._pol.splitk:
+            """K slices of a 3x3 fp16x2 forward launch on this map (1: none).  Eval forwards only: in a training forward the split launch gives up the fused
+            max-pool and pays for the sign bits in its reduce -- measured neutral at B = 1 and 5 % slower at B = 2 (profiles/r6/small_batch.txt), where the step
+            is bound by the host's ~110 launches anyway."""
+            if not self._pol.splitk or train:
                 return 1
             return ops.h2_splitk(B, h, w, (2 if src2 is not None else 1) * ((src.shape[3] + 15) // 16), cout)
 
