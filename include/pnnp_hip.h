@@ -274,7 +274,7 @@ int pnnp_conv3x3_h2_bwd_data_res_f32(const float* g, int Cout, const unsigned* a
  * power-of-two scale from 4-byte amax slots, two fp16 pieces per operand, three products per multiply instead of bf16x3's six.  Contracts of the
  * _x3_ entries below + the slots: amax_x / amax_g of the tensor that is split on the fly, amax_w of the weight tensor (the kind-6 packs of
  * pnnp_pack_jobs_add_h2_convt / _1x1 / _s2 were scaled with it; pnnp_h2mat_bytes(K, N) bytes), amax_y / amax_dx (or null) raised to max |stored|.
- * K (channels per segment) % 32 == 0, N (GEMM columns: 4 Cout for ConvTranspose2d forward) % 64 == 0: pnnp_gemm_h2_supported. */
+ * K (channels per segment) % 32 == 0, N (GEMM columns: 4 Cout for ConvTranspose2d forward) % 32 == 0 (round 6; was 64): pnnp_gemm_h2_supported. */
 int pnnp_gemm_h2_supported(int K, int N);
 int64_t pnnp_h2mat_bytes(int K, int N);
 int pnnp_pack_jobs_add_h2_convt(PnnpPackJob* jobs, int* n, int cap, const float* w, void* fwd /*or null*/, void* dgrad /*or null*/, int Cin, int Cout, const unsigned* amax);

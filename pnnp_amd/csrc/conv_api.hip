@@ -415,7 +415,7 @@ int pnnp_conv3x3s2_x3_bwd_data_amax_f32(const float* g, int Cout, const void* w_
 // ---------------------------------------------------------------- pointwise layers on the fp16 matrix cores (csrc/gemm_h2s.hip, csrc/h2.h)
 // Contracts of the _x3_ entries above + the amax slots of the fp16x2 family; weights: the kind-6 packs of pnnp_pack_jobs_add_h2_convt / _1x1.
 // K (channels of a segment) in multiples of 32, N (GEMM columns: 4 Cout for ConvTranspose2d forward) in multiples of 64.
-int pnnp_gemm_h2_supported(int K, int N) { return (K > 0 && N > 0 && K % 32 == 0 && N % 64 == 0) ? 1 : 0; }
+int pnnp_gemm_h2_supported(int K, int N) { return (K > 0 && N > 0 && K % 32 == 0 && N % 32 == 0) ? 1 : 0; }      // (round 6: 32-column tiles for N = 32 mod 64)
 namespace {
 int gemm_h2_go(H2Args& h, int chan_per_seg, hipStream_t st) {
     const int rc = pnnp_gemm_x3_check(h.g, chan_per_seg);

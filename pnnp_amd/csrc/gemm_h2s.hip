@@ -14,7 +14,8 @@
 //     (csrc/pack_jobs.hip kind 6), scaled with the weight tensor's amax slot; the activations' scale comes from the amax slots of the K
 //     segments' tensors; the epilogue multiplies by 2^-(se_x + se_w) first;
 //   * an item carries twice the bytes of a bf16x3 item at the same matrix-pipe time, so the lookahead is 3 items (96 KB per CU in flight).
-// Tiles: 256 px x 128 columns (4 x 2 consumer waves of 64 px x 64) and 256 px x 64 (4 x 2 waves of 64 px x 32).
+// Tiles: 256 px x 128 columns (4 x 2 consumer waves of 64 px x 64), 256 px x 64 (4 x 2 waves of 64 px x 32) and, for GEMMs with 32 (mod 64) columns, 256 px x 32
+// (4 x 1 waves of 64 px x 32; the other four consumer waves only keep the barriers -- these layers move 32 KB per item for 384 matrix-pipe cycles: HBM-bound).
 #include "h2.h"
 #include <type_traits>
 
@@ -37,7 +38,8 @@ constexpr unsigned OOB = 0x80000000u;
 
 template <int BN, int WN_> struct GCfg {
     static constexpr int WN = WN_;                                 // columns per consumer wave: 64 or 32
-    static constexpr int NWN = BN / WN, NWM = NCW / NWN;           // consumer waves along N (2) and along the pixels (4)
+    static constexpr int NWN = BN / WN, NWM = BN == 32 ? 4 : NCW / NWN;      // consumer waves along N (2; 1 for the 32-column tile) and along the pixels (4)
+    static constexpr int NACT = NWN * NWM;                         // consumer waves that compute (the 32-column tile: 4 of the 8 -- its layers are HBM-bound several times over)
     static constexpr int TH = NWM * MT, PT = TH * 32;              // tile: 8 rows of 32 px = 256 pixels
     static constexpr int NB = WN / 16, NTW = WN / 32;              // 16-column accumulator blocks / 32-column blocks per wave
     static constexpr int XS_F4 = 2 * 4 * PT, XS_BYTES = XS_F4 * 16; // one image: [piece 2][octet 4][pixel] 16-byte words: 32768
@@ -47,7 +49,7 @@ template <int BN, int WN_> struct GCfg {
     static constexpr int A = 3;                                    // items of lookahead (= register sets of the producers); ring of A + 1 weight stages
     static constexpr int NSTAGE = A + 1;
     static constexpr int LDS_BYTES = 2 * XS_BYTES + NSTAGE * WS_STAGE;
-    static_assert(NWN * WN == BN && NWN == 2 && PT == 256, "tile shapes");
+    static_assert(NWN * WN == BN && PT == 256 && NACT <= NCW, "tile shapes");
     static_assert(LDS_BYTES <= 160 * 1024, "a workgroup's LDS");
     static_assert(A * 2 * NSL + (A - 1) * DPW <= 63, "the producers' vmcnt");
 };
@@ -268,6 +270,17 @@ gemm_h2s_kernel(const H2Args ha) {
     }
 
     // =============================================== CONSUMER ===============================================
+    if constexpr (Cfg::NACT < NCW) {
+        if (wave >= Cfg::NACT) {                                     // (32-column tile) a consumer wave without a share: the barriers of the item loop, nothing else
+            GHS_BARRIER();
+            for (;;) {
+                step(cu);
+                if (!cu.ok) break;
+                GHS_BARRIER();
+            }
+            return;
+        }
+    }
     const int wn = wave % Cfg::NWN, wm = wave / Cfg::NWN;             // this wave's column group / pixel-row pair
     constexpr int MB = 2 * MT;
     f32x4 acc[MB][NB];
@@ -612,7 +625,8 @@ int launch_ghs_ek(const H2Args& ha, hipStream_t s) {
 int pnnp_gemm_h2s_launch(const H2Args& ha, hipStream_t s) {
     const IgemmArgs& b = ha.g;
     if (!ha.amax_in[0] || !ha.amax_w || b.amax_out[1] || ha.bits_out || ha.bits_in[1]) return PNNP_E_INVALID;
-    if (b.Ntot % 64 || b.chunks_per_seg <= 0) return PNNP_E_UNSUPPORTED;
+    if (b.Ntot % 32 || b.chunks_per_seg <= 0) return PNNP_E_UNSUPPORTED;
     if (b.Ntot % 128 == 0) return launch_ghs_ek<128, 64>(ha, s);
-    return launch_ghs_ek<64, 32>(ha, s);
+    if (b.Ntot % 64 == 0) return launch_ghs_ek<64, 32>(ha, s);
+    return launch_ghs_ek<32, 32>(ha, s);                            // (round 6) 256 px x 32 columns: ResUnet's 32-column layers at 512 x 512 (pool1 backward-data, sc9, upv9 beside them)
 }
