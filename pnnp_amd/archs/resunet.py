@@ -392,6 +392,14 @@ class ResUnetEngine(_EngineBase):
                 ops.conv_x3_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
             elif taps == 9 and self._pol.use_wino_wgrad(gpre.shape[1], gpre.shape[2], cout, c1, c2, gpre.shape[3], x1.shape[3]):
                 ops.conv_wino_bwd_weight(gpre, cout, x1, c1, x2, G(pname), G(bias) if bias else None, wsf, accumulate=acc)
+            elif (taps == 1 and h2_on and self._pol.h2_pointwise and self._pol.x3 and not self._pol.use_x3g_wgrad(ops.X3G_PW, cout, c1 + c2, gpre.shape[0], gpre.shape[1],
+                                                                                                                    gpre.shape[2], gpre.shape[1], gpre.shape[2], max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0))
+                  and ops.h2g_wgrad_supported(ops.X3G_PW, cout, c1 + c2) and id(gpre) in gname and id(x1) in src_name and (x2 is None or id(x2) in src_name)
+                  and ops.x3_wgrad_fits(gpre.shape[0], gpre.shape[1], gpre.shape[2], max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0))
+                  and wsf.numel() >= ops.h2g_wgrad_workspace_floats(ops.X3G_PW, gpre.shape[0], gpre.shape[1], gpre.shape[2], cout, c1 + c2)):
+                # a shape only the fp16x2 kernel has a tile for (sc9: 32 x 64, round 6; it ran on the fp32-MFMA kernel)
+                ops.conv1x1_h2_bwd_weight(gpre, gslot(gpre), cout, x1, slf(x1), c1, x2, slf(x2) if x2 is not None else None, G(pname), G(bias) if bias else None,
+                                          wsf, accumulate=acc)
             elif taps == 1 and self._pol.use_x3g_wgrad(ops.X3G_PW, cout, c1 + c2, gpre.shape[0], gpre.shape[1], gpre.shape[2], gpre.shape[1], gpre.shape[2],
                                                        max(gpre.shape[3], x1.shape[3], x2.shape[3] if x2 is not None else 0)):
                 if h2_on and self._pol.h2_pointwise and id(gpre) in gname and id(x1) in src_name and (x2 is None or id(x2) in src_name):

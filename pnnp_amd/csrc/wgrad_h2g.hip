@@ -387,13 +387,14 @@ using S2A = WhgLaunch<GEO_S2, 1, 1, 4, 1, 2, 32, 1>;
 using S2B = WhgLaunch<GEO_S2, 1, 1, 2, 1, 4, 32, 2>;          // 64 x 32 (64 px; M = Cout = 64: pool1 of the ResUnet -- no bf16x3 twin, it ran on fp32 MFMA)
 using PwA = WhgLaunch<GEO_PW, 2, 2, 2, 2, 2, 32, 1>;
 using PwB = WhgLaunch<GEO_PW, 1, 2, 2, 2, 2, 32, 1>;
+using PwC = WhgLaunch<GEO_PW, 1, 1, 1, 2, 4, 32, 2>;          // 32 x 64 (64 px; M = Cout = 32: sc9 of the ResUnet -- round 6: it ran on fp32 MFMA)
 
 // which configuration a (geometry, M, N) runs on: 0 = not supported
 int wxg_config(int geo, int M, int N) {
     if (M <= 0 || N <= 0 || (M & 31) || (N & 31)) return 0;
     if (geo == GEO_CT) return (M % 256 == 0 && N % 64 == 0) ? 1 : ((M % 128 == 0 && N % 64 == 0) ? 2 : ((M % 64 == 0) ? 3 : 0));
     if (geo == GEO_S2) return (M % 128 == 0) ? 4 : ((M % 64 == 0) ? 7 : 0);
-    if (geo == GEO_PW) return (N % 128 == 0) ? ((M % 128 == 0) ? 5 : ((M % 64 == 0) ? 6 : 0)) : 0;
+    if (geo == GEO_PW) return (N % 128 == 0 && M % 64 == 0) ? ((M % 128 == 0) ? 5 : 6) : ((N % 64 == 0) ? 8 : 0);
     return 0;
 }
 template <class F> auto wxg_dispatch(int cfg, F&& f) {
@@ -404,6 +405,7 @@ template <class F> auto wxg_dispatch(int cfg, F&& f) {
         case 4: return f(S2A{});
         case 5: return f(PwA{});
         case 7: return f(S2B{});
+        case 8: return f(PwC{});
         default: return f(PwB{});
     }
 }

@@ -193,6 +193,16 @@ def test_pointwise_weight_gradients_h2_vs_float64():
     ops.conv1x1_h2_bwd_weight(gy, _slot(gy), C, x1, _slot(x1), C, x2, _slot(x2), dW, None, ws, accumulate=1)
     ref = base.double() + torch.einsum('bhwo,bhwi->oi', gy.double(), torch.cat([x1, x2], 3).double())
     _wgrad_check('1x1 dW (accumulated)', dW, ref)
+    # ... and the 32 x 64 tile only the fp16x2 kernel has (ResUnet's sc9: cat(2 x 32) -> 32 at 512^2; round 6), ragged map, with the bias gradient
+    B, H, W, C = 2, 33, 70, 32
+    x1 = torch.randn(B, H, W, C, device='cuda', generator=g); x2 = torch.randn(B, H, W, C, device='cuda', generator=g) * 5
+    gy = torch.randn(B, H, W, C, device='cuda', generator=g)
+    assert ops.h2g_wgrad_supported(ops.X3G_PW, C, 2 * C) and not ops.x3g_wgrad_supported(ops.X3G_PW, C, 2 * C)
+    ws = torch.empty(ops.h2g_wgrad_workspace_floats(ops.X3G_PW, B, H, W, C, 2 * C), device='cuda')
+    dW = torch.full((C, 2 * C), float('nan'), device='cuda'); db = torch.full((C,), float('nan'), device='cuda')
+    ops.conv1x1_h2_bwd_weight(gy, _slot(gy), C, x1, _slot(x1), C, x2, _slot(x2), dW, db, ws)
+    _wgrad_check('1x1 dW (32 x 64 tile)', dW, torch.einsum('bhwo,bhwi->oi', gy.double(), torch.cat([x1, x2], 3).double()))
+    _wgrad_check('1x1 dbias (32 x 64 tile)', db, gy.double().sum((0, 1, 2)))
 
 
 @pytest.mark.parametrize('shape', [(2, 24, 40, 64, 64), (1, 16, 32, 128, 128), (2, 9, 70, 64, 32)])
