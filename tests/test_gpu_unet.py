@@ -284,7 +284,9 @@ def test_fused_head_equals_conv_then_head_kernel(res):
     go = torch.randn(2, 48, 80, 8, device='cuda', generator=g); go[..., 4:] = 0
 
     def run(fused):
-        e.set_policy(head_fused=fused)
+        # (split-K off: this small frame's EVAL forward would otherwise cut its deep layers along K -- another partition of the same sums -- and the
+        #  eval-vs-training comparison below is about the head, bit for bit)
+        e.set_policy(head_fused=fused, splitk=False)
         out = e.forward(x, train=True).clone()
         a = e.saved[0]
         c9, bits = a['c9'].clone(), a['bits:conv9_2'].clone()
