@@ -324,25 +324,34 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         f32x16 v = acc[mb][dx];
-        if (WK > 1) {
+        const int t = tr * 3 + dx;
+        if constexpr (WK > 1) {
+            // Through LDS in the accumulator layout, back out ROW-major: a lane of the storing wave takes 4 consecutive columns of rows (lane >> 3) + 8 i, adds the WK
+            // partial sums in the order k = 0, 1, ... (as before: bit-identical) and stores 16 bytes -- 4 store instructions of 8 rows x 128 bytes per (block, tap) where the
+            // accumulator layout needed 16 of 2 x 128 bytes (the epilogue was ~13 000 cycles per workgroup, most of it these stores: profiles/r6/wgrad_stamps.txt)
             WHS_BARRIER();
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(wave * 16 + r) * 64 + lane] = v[r];
             WHS_BARRIER();
             if (wk == 0) {
+                const int c4 = (lane & 7) * 4;
+                const unsigned n_u = (unsigned)a.N;
+                const unsigned base = (unsigned)((t * a.M + m0 + (mo + mb) * 32) * a.N + n0 + no * 32 + c4);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    const int row = (lane >> 3) + 8 * i;             // row (r & 3) + 8 (r >> 2) + 4 half of the 32 x 32 block
+                    const int r = ((row >> 3) << 2) | (row & 3), hf = (row >> 2) & 1;
+                    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int k = 0; k < WK; ++k) s += red[((wave + 3 * k) * 16 + r) * 64 + lane];      // (the split index steps the wave number by 3)
-                    v[r] = s;
+                    for (int k = 0; k < WK; ++k) sum += *reinterpret_cast<const f32x4*>(red + ((wave + 3 * k) * 16 + r) * 64 + hf * 32 + c4);      // (the split index steps the wave number by 3)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sum[c] = __builtin_ldexpf(sum[c], dexp);
+                    *reinterpret_cast<f32x4*>(slab_z + base + (unsigned)row * n_u) = sum;
                 }
             }
-        }
-        if (wk == 0) {
+        } else if (wk == 0) {
             // one base index per (block, tap); the 16 rows of the accumulator layout are compile-time multiples of N behind it (with a 64-bit index per
             // element the compiler hoisted 16 address pairs and spilled: 12 bytes of scratch in the 64 x 64 kernel)
-            const int t = tr * 3 + dx;
             const unsigned base = (unsigned)((t * a.M + m0 + (mo + mb) * 32 + 4 * half) * a.N + n0 + no * 32 + l31);
             const unsigned n_u = (unsigned)a.N;
 #pragma unroll
