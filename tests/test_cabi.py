@@ -43,3 +43,30 @@ def test_product_has_no_cpu_fallback():
     for f in pathlib.Path(REPO, 'pnnp_amd').rglob('*.py'):
         src = f.read_text()
         assert 'import oracle' not in src and 'from oracle' not in src, f
+
+
+def test_abi_version_and_shape_policies_without_a_gpu():
+    """Round 6: the ABI version / PnnpPackJob size the Python bindings check, and the pure shape policies of the fp16x2 family (which tile width a layer runs on,
+    how many K slices a small grid is cut into, which pointwise shapes have a tile) -- host-side functions that need no device (without one the library assumes
+    the MI355X's 256 compute units)."""
+    so = os.path.join(REPO, 'pnnp_amd', 'libpnnp_hip.so')
+    lib = ctypes.CDLL(so)
+    from pnnp_amd import ops
+    assert lib.pnnp_abi_version() == ops.ABI_VERSION
+    assert lib.pnnp_pack_job_bytes() == ctypes.sizeof(ops.PackJob)
+    if lib.pnnp_device_cus() != 256:
+        pytest.skip('policies below are stated for 256 compute units')
+    tc = lambda B, H, W, N, pool=0: lib.pnnp_h2_tile_columns(B, H, W, N, pool)
+    assert tc(16, 512, 512, 32) == 32 and tc(16, 256, 256, 64) == 64 and tc(16, 32, 32, 512) == 64      # config 3's layers
+    assert tc(1, 32, 32, 512) == 32 and tc(1, 64, 64, 256) == 32                                          # one crop: 64-column tiles would leave CUs idle
+    assert tc(1, 32, 32, 512, 1) == 64                                                                     # the pooled forward keeps 64 whenever the layer has them
+    sk = lambda B, H, W, chunks, N: lib.pnnp_h2_splitk(B, H, W, chunks, N)
+    assert sk(16, 32, 32, 32, 512) == 1                                                                    # a full batch fills the chip: no split
+    assert sk(1, 32, 32, 32, 512) == 8 and sk(1, 64, 64, 16, 256) == 4 and sk(1, 128, 128, 8, 128) == 2    # one crop: 32 / 64 / 128 tiles -> 256 workgroups
+    assert sk(1, 256, 256, 4, 64) == 1 and sk(1, 32, 32, 2, 512) == 1                                      # enough tiles / too few chunks
+    for chunks in (4, 6, 8, 12, 16, 32):
+        s = sk(1, 32, 32, chunks, 512)
+        assert chunks % s == 0 and chunks // s >= 2                                                        # whole slices of at least two chunks
+    assert lib.pnnp_gemm_h2_supported(64, 32) and lib.pnnp_gemm_h2_supported(32, 128) and not lib.pnnp_gemm_h2_supported(48, 64) and not lib.pnnp_gemm_h2_supported(64, 48)
+    X3G_PW = ops.X3G_PW
+    assert lib.pnnp_h2g_wgrad_supported(X3G_PW, 32, 64) and not lib.pnnp_x3g_wgrad_supported(X3G_PW, 32, 64)     # sc9's 32 x 64 tile exists on fp16x2 only
