@@ -88,7 +88,12 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #endif
 // the epilogue a kernel carries (one straight-line path each): forward (no mask, no accumulation, no residual; writes sign bits when asked),
 // masked backward-data with float32 masks / with bit masks, the general one, forward + MaxPool2d(2)
-enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3, EK_BWDB = 4, EK_HEAD = 5 };
+enum { EK_FWD = 0, EK_BWD = 1, EK_GEN = 2, EK_POOL = 3, EK_BWDB = 4, EK_HEAD = 5, EK_RES = 6 };
+// EK_RES (round 6): a plain layer + a residual tensor of the destination's geometry, no activation, no mask (ResUnet: the second convolution of every
+// ResidualBlock, forward `conv + bias + shortcut` and backward-data `dgrad + g`, archs/modules.py:176-197) -- the general epilogue took 3.2 x the
+// forward epilogue's cycles for them (16-pixel x 64-byte stores, three loads per block: profiles/r6/gen_epilogue_stamps.txt).  Here: the residual
+// words are requested up front in the full-line pattern the stores use and added BEHIND the line trade; scale + bias in one fma (bias from LDS).
+// ((v 2^dexp + bias) + res in this order, as the general epilogue computes it: bit-identical.)
 // EK_HEAD (32-column kernel only): the forward epilogue + the network's 1x1 head (archs/Unet.py:94: conv10_1, 32 -> 4 channels, no activation) computed from
 // the activated accumulators -- a lane holds 8 of a pixel's 32 channels, the 4 lanes of a pixel add their partial sums through two butterfly exchanges --
 // and written as the NCHW output planes (+ the `res` networks' input residual).  The 32-channel map itself is stored only when the caller asks for it
@@ -674,15 +679,16 @@ igemm_h2s_kernel(const H2Args ha) {
         }
         // ---- FWD: no mask, no accumulation, no residual (every forward layer; sign bits on request);  BWD / BWDB: act' masks as float32
         // activations / as the forward kernel's bits (a destination without one requests them out of range: zeros come back, no memory traffic).
-        if constexpr (EK == EK_FWD || EK == EK_BWD || EK == EK_BWDB || EK == EK_HEAD) {
+        if constexpr (EK == EK_FWD || EK == EK_BWD || EK == EK_BWDB || EK == EK_HEAD || EK == EK_RES) {
+            constexpr bool RES = EK == EK_RES;
             constexpr bool MASKED = EK == EK_BWD, BITS = EK == EK_BWDB, FWDL = EK == EK_FWD || EK == EK_HEAD;
-            f32x4 mk[MASKED ? MB : 1][MASKED ? NB : 1];              // [.][2 k] = what instruction 1 fetched, [.][2 k + 1] = instruction 2
+            f32x4 mk[(MASKED || RES) ? MB : 1][(MASKED || RES) ? NB : 1];      // [.][2 k] = what instruction 1 fetched, [.][2 k + 1] = instruction 2 (EK_RES: the residual words)
             unsigned mbits[NT];
-            if constexpr (MASKED) {
+            if constexpr (MASKED || RES) {
 #pragma unroll
                 for (int k = 0; k < NT; ++k) {
-                    const int mm = ea.mask_mode(du_[k]);
-                    const __amdgpu_buffer_rsrc_t rm = rsrc(mm ? ea.mask(du_[k]) : ea.dst(du_[k]), k);
+                    const int mm = RES ? 1 : ea.mask_mode(du_[k]);
+                    const __amdgpu_buffer_rsrc_t rm = rsrc(RES ? ea.addsrc : (mm ? ea.mask(du_[k]) : ea.dst(du_[k])), k);
 #pragma unroll
                     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -721,6 +727,10 @@ igemm_h2s_kernel(const H2Args ha) {
                                 for (int c = 0; c < 4; ++c) { float e = o0[c]; act_sign(e, sb, aslope, act_tag); o0[c] = e; }
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { float e = o1[c]; act_sign(e, sb, aslope, act_tag); o1[c] = e; }
+                            } else if constexpr (RES) {
+                                // (bias from LDS at its use: the 16 registers of bias4 are what this kernel does not have beside the 64 residual words)
+                                o0 = take_bias(2 * i + h, 2 * k, *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * k + c4));
+                                o1 = take_bias(2 * i + h, 2 * k + 1, *reinterpret_cast<const f32x4*>(bias_lds + n0 + 32 * k + 16 + c4));
                             } else if constexpr (BITS) {
                                 const f32x4 v0 = take_raw(2 * i + h, 2 * k), v1 = take_raw(2 * i + h, 2 * k + 1);
                                 const float fneg = dsc * msl;
@@ -737,6 +747,14 @@ igemm_h2s_kernel(const H2Args ha) {
                                 const f32x4 t0 = o0 * msl, t1 = o1 * msl;
 #pragma unroll
                                 for (int c = 0; c < 4; ++c) { o0[c] = q0[c] > 0.f ? o0[c] : t0[c]; o1[c] = q1[c] > 0.f ? o1[c] : t1[c]; }
+                            }
+                            if constexpr (RES) {                       // trade first, then add what the two store instructions' addresses hold of the residual
+                                trade(o0, o1);
+                                o0 += mk[2 * i + h][2 * k]; o1 += mk[2 * i + h][2 * k + 1];
+                                track(o0); track(o1);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rd, wo[k][i][h], 0, H2S_STORE_AUX);
+                                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rd, wo2(k, i, h), 0, H2S_STORE_AUX);
+                                continue;
                             }
                             track(o0); track(o1);
                             if constexpr (EK == EK_HEAD) {
@@ -1040,6 +1058,7 @@ int pnnp_igemm_h2s_launch(const H2Args& ha, int chan_per_seg, hipStream_t s) {
     if ((f0 || f1) && (b0 || b1)) return PNNP_E_UNSUPPORTED;                   // one kind per launch
     if ((b0 || b1) && (!plain || a.act || a.bias)) return PNNP_E_UNSUPPORTED;  // bit masks: the masked backward-data epilogue only
     if (ha.bits_out && (m0 || m1 || !plain || two)) return PNNP_E_UNSUPPORTED; // sign bits: plain single-destination forward layers
+    if (a.addsrc && !two && !a.accum[0] && !a.act && !m0 && !ha.bits_out) return wide ? launch_h2s<64, EK_RES>(b, s) : launch_h2s<32, EK_RES>(b, s);
     if (plain && !m0 && !m1) return wide ? launch_h2s<64, EK_FWD>(b, s) : launch_h2s<32, EK_FWD>(b, s);
     if (plain && !a.act && !a.bias) {
         if (b0 || b1) return wide ? launch_h2s<64, EK_BWDB>(b, s) : launch_h2s<32, EK_BWDB>(b, s);

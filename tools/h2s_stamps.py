@@ -1,5 +1,5 @@
 """With a library built with -DH2S_STAMPS (tools/build_variant.sh h2st conv_h2s.hip -DH2S_STAMPS; PNNP_LIB=...): per-wave cycle sums of
-igemm_h2s_kernel on one 3x3 layer (B = 16), per chunk.   usage: h2s_stamps.py S Cin Cout [fwd|dgrad|dgradf]   (dgradf: float32 masks)"""
+igemm_h2s_kernel on one 3x3 layer (B = 16), per chunk.   usage: h2s_stamps.py S Cin Cout [fwd|fwdres|dgrad|dgradf]   (fwdres: forward with a residual = the general epilogue; dgradf: float32 masks)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,10 +10,11 @@ x = torch.randn(B, S, S, Ci, device='cuda'); w = torch.randn(Co, Ci, 3, 3, devic
 wx = torch.empty(ops.h2_weight_bytes(Ci, Co), dtype=torch.uint8, device='cuda'); wd = torch.empty(ops.h2_weight_bytes(Co, Ci), dtype=torch.uint8, device='cuda')
 jobs = ops.PackJobs(); sw = jobs.add_h2(w, wx, wd, cin_pad=(Ci + 15) // 16 * 16); jobs.run()
 slot = lambda t: ops.amax(t, torch.zeros(1, dtype=torch.int32, device='cuda'))
-if mode == 'fwd':
+if mode in ('fwd', 'fwdres'):
     y = torch.empty(B, S, S, Co, device='cuda'); sx = slot(x); sy = torch.zeros(1, dtype=torch.int32, device='cuda')
     bits = torch.zeros(ops.h2_bits_words(B, S, S, Co), dtype=torch.int32, device='cuda')
-    run = lambda: ops.conv_h2_fwd(x, None, wx, sw, b, y, Co, 1, sx, amax_y=sy, bits_y=bits); out = y; N = Co
+    res = torch.randn(B, S, S, Co, device='cuda') if mode == 'fwdres' else None
+    run = lambda: ops.conv_h2_fwd(x, None, wx, sw, b, y, Co, 1 if res is None else 0, sx, amax_y=sy, bits_y=bits if res is None else None, residual=res); out = y; N = Co
 else:
     g = torch.randn(B, S, S, Co, device='cuda'); dx = torch.empty(B, S, S, Ci, device='cuda'); mask = torch.randn(B, S, S, Ci, device='cuda')
     sg = slot(g); sd = torch.zeros(1, dtype=torch.int32, device='cuda')
