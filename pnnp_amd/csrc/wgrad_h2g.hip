@@ -34,6 +34,9 @@ struct WhgArgs {
     const unsigned* amax_u; const unsigned* amax_s[2];   // amax slots of U and of the S segment(s) ([1] null without a second one)
 };
 
+#ifndef WHG_ROLL
+#define WHG_ROLL 1                     // rolling refill of the staging registers (see stage_piece; 0 = round 5's order)
+#endif
 constexpr int NTHR = 512, NWAVE = 8;
 enum { GEO_PW = 0, GEO_CT = 1, GEO_S2 = 2 };
 
@@ -153,29 +156,40 @@ wgrad_h2g_kernel(const WhgArgs a) {
         return f32x4{__uint_as_float(__float_as_uint(v.x) ^ sflip), __uint_as_float(__float_as_uint(v.y) ^ sflip),
                      __uint_as_float(__float_as_uint(v.z) ^ sflip), __uint_as_float(__float_as_uint(v.w) ^ sflip)};
     };
-    auto load_tile = [&](int tile) {
+    // one tile's scalars, then one request per staging slot (global -> registers)
+    struct TileSc { int uso, sso0, sso1, rlim, clim, sy0, sx0, dead; };      // dead: -1 = no such tile (every request out of range: zeros, no traffic), else 0
+    auto tile_sc = [&](int tile, bool exists) {
         int q = tile;
         const int tx = q % tiles_x; q /= tiles_x;
         const int ty = q % tiles_y;
         const int b = q / tiles_y;
         const int x0 = tx * TW, y0 = ty * TR;
-        const int uso = ((b * a.UH + y0) * a.UW + x0) * a.Ucs * 4;
-        const int sy0 = SM * y0 - P, sx0 = SM * x0 - P;
-        const int sso0 = (((b * a.SH + sy0) * a.SW + sx0) * a.Scs[0] + sshift0) * 4, sso1 = (((b * a.SH + sy0) * a.SW + sx0) * a.Scs[1] + sshift1) * 4;
-        const int rlim = a.UH - y0, clim = a.UW - x0;
+        TileSc t;
+        t.uso = ((b * a.UH + y0) * a.UW + x0) * a.Ucs * 4;
+        t.sy0 = SM * y0 - P; t.sx0 = SM * x0 - P;
+        t.sso0 = (((b * a.SH + t.sy0) * a.SW + t.sx0) * a.Scs[0] + sshift0) * 4; t.sso1 = (((b * a.SH + t.sy0) * a.SW + t.sx0) * a.Scs[1] + sshift1) * 4;
+        t.rlim = a.UH - y0; t.clim = a.UW - x0;
+        t.dead = exists ? 0 : -1;
+        if (!exists) { t.uso = 0; t.sso0 = 0; t.sso1 = 0; }
+        return t;
+    };
+    auto load_u = [&](int k, const TileSc& t) {
+        const int bad = (t.rlim - 1 - u_r[k]) | (t.clim - 1 - u_c[k]) | (u_blk[k] ? 0 : -1) | t.dead;      // sign bit set <=> outside
+        ru[k] = bload(rsu, bad < 0 ? OOB : u_off[k], t.uso);
+    };
+    auto load_s = [&](int k, const TileSc& t) {
+        const int yy = t.sy0 + s_r[k], xx = t.sx0 + s_x[k];
+        const int bad = yy | (a.SH - 1 - yy) | xx | (a.SW - 1 - xx) | (s_blk[k] ? 0 : -1) | t.dead;
+        const unsigned vo = bad < 0 ? OOB : s_off[k];
+        if (GEO == GEO_PW && __builtin_amdgcn_readfirstlane(s_seg[k])) rs[k] = bload(rss1, vo, t.sso1);
+        else rs[k] = bload(rss0, vo, t.sso0);
+    };
+    auto load_tile = [&](int tile) {
+        const TileSc t = tile_sc(tile, true);
 #pragma unroll
-        for (int k = 0; k < NU; ++k) {
-            const int bad = (rlim - 1 - u_r[k]) | (clim - 1 - u_c[k]) | (u_blk[k] ? 0 : -1);      // sign bit set <=> outside
-            ru[k] = bload(rsu, bad < 0 ? OOB : u_off[k], uso);
-        }
+        for (int k = 0; k < NU; ++k) load_u(k, t);
 #pragma unroll
-        for (int k = 0; k < NS; ++k) {
-            const int yy = sy0 + s_r[k], xx = sx0 + s_x[k];
-            const int bad = yy | (a.SH - 1 - yy) | xx | (a.SW - 1 - xx) | (s_blk[k] ? 0 : -1);
-            const unsigned vo = bad < 0 ? OOB : s_off[k];
-            if (GEO == GEO_PW && __builtin_amdgcn_readfirstlane(s_seg[k])) rs[k] = bload(rss1, vo, sso1);
-            else rs[k] = bload(rss0, vo, sso0);
-        }
+        for (int k = 0; k < NS; ++k) load_s(k, t);
     };
     // one staging slice as a whole (prologue) ...
     float bmul = 1.f;                                             // 0 while there is no next tile: the pieces then run on stale registers, branch-free
@@ -198,12 +212,16 @@ wgrad_h2g_kernel(const WhgArgs a) {
     };
     // ... and as dependent pieces (step 0: hi; 1: bias sums; 2: lo) and the stores (step 3, 4), dealt over the MFMA gaps
     f32x4 pv; unsigned ph[2], pl[2];
-    auto stage_piece = [&](int sl, int step, int img) {
+    // ROLLING refill (WHG_ROLL, round 6; csrc/wgrad_h2s.hip roll_tile): a slot's registers are re-requested for the tile after next as soon as step 2 has
+    // used them last, so that every load is in flight for a whole tile (requesting the whole tile behind the last MFMA left them the barrier wait only)
+    auto stage_piece = [&](int sl, int step, int img, const TileSc& t2) {
         const bool isu = sl < NU;
         const int ku = isu ? sl : 0, ks = isu ? 0 : sl - NU;
         const float sc = isu ? scu : scs;
         switch (step) {
-        case 0: pv = isu ? usign(ru[ku]) : rs[ks]; ph[0] = h2_hi(pv.x, pv.y, sc); ph[1] = h2_hi(pv.z, pv.w, sc); break;
+        case 0:
+            pv = isu ? usign(ru[ku]) : rs[ks]; ph[0] = h2_hi(pv.x, pv.y, sc); ph[1] = h2_hi(pv.z, pv.w, sc);
+            break;
         case 1:
             if (isu) { bsu[ku][0] = fmaf(pv.x, bmul, bsu[ku][0]); bsu[ku][1] = fmaf(pv.y, bmul, bsu[ku][1]); bsu[ku][2] = fmaf(pv.z, bmul, bsu[ku][2]); bsu[ku][3] = fmaf(pv.w, bmul, bsu[ku][3]); }
             else if (GEO == GEO_CT) {
@@ -212,7 +230,12 @@ wgrad_h2g_kernel(const WhgArgs a) {
                 bss[GEO == GEO_CT ? ks : 0][2] = fmaf(pv.z, sm, bss[GEO == GEO_CT ? ks : 0][2]); bss[GEO == GEO_CT ? ks : 0][3] = fmaf(pv.w, sm, bss[GEO == GEO_CT ? ks : 0][3]);
             }
             break;
-        case 2: pl[0] = h2_lo(pv.x, pv.y, sc, ph[0]); pl[1] = h2_lo(pv.z, pv.w, sc, ph[1]); break;
+        case 2:
+            pl[0] = h2_lo(pv.x, pv.y, sc, ph[0]); pl[1] = h2_lo(pv.z, pv.w, sc, ph[1]);
+            // (behind the LAST use of the slot's value: the request can then land in the same registers -- issued at step 0 the compiler had to give it
+            // others and copy them at the end of the loop, which waits for every load)
+            if constexpr (WHG_ROLL) { if (isu) load_u(ku, t2); else load_s(ks, t2); }
+            break;
         default: {
             char* ib = smem + img * Cfg::IMG_BYTES;
             const int dst = isu ? u_dst[ku] : s_dst[ks];
@@ -255,7 +278,9 @@ wgrad_h2g_kernel(const WhgArgs a) {
     if (z + a.Z < ntile) load_tile(z + a.Z);
     int img = 0;
     for (int tile = z; tile < ntile; tile += a.Z) {
-        __syncthreads();                                            // image `img` is complete; every wave is done with the other one
+        // image `img` is complete; every wave is done with the other one.  (Not __syncthreads(): its fence waits for vmcnt(0) -- the loads in flight for the
+        // tile after next -- where only the LDS writes have to be visible.)
+        if constexpr (WHG_ROLL) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); else __syncthreads();
         const char* uimg = smem + img * Cfg::IMG_BYTES;
         const char* simg = uimg + Cfg::U_BYTES;
         const bool have_next = tile + a.Z < ntile, have_next2 = tile + 2 * a.Z < ntile;
@@ -274,7 +299,8 @@ wgrad_h2g_kernel(const WhgArgs a) {
             for (int p = 0; p < 2; ++p) av[mb][p] = tr_read(u_addr(mb) + p * UPIX * 64);
 #pragma unroll
         for (int p = 0; p < 2; ++p) bv[0][p] = tr_read(s_addr(0, 0) + p * SPIX * 64);
-        __builtin_amdgcn_s_waitcnt(0x0f70);                         // the next tile's loads were issued a full tile ago
+        if constexpr (!WHG_ROLL) __builtin_amdgcn_s_waitcnt(0x0f70);  // (rolling: the compiler's own vmcnt in front of every slot's step 0)
+        const TileSc t2 = tile_sc(have_next2 ? tile + 2 * a.Z : tile, WHG_ROLL && have_next2);
         __builtin_amdgcn_sched_barrier(0);
         // groups: B-step bs = (N block, tap), M block innermost; the next B-step's operand is read in the first two gaps of a B-step's
         // first group; the staging units (slice, step) are dealt evenly over all gaps
@@ -286,10 +312,10 @@ wgrad_h2g_kernel(const WhgArgs a) {
             if constexpr (mb == 0 && G < 2 && bs + 1 < NB * TAPS)
                 bv[cur ^ 1][G] = tr_read(s_addr((bs + 1) / TAPS, (bs + 1) % TAPS) + G * SPIX * 64);
             constexpr int n0u = (gi * Cfg::UNITS + Cfg::GAPS - 1) / Cfg::GAPS, n1u = ((gi + 1) * Cfg::UNITS + Cfg::GAPS - 1) / Cfg::GAPS;
-            static_for<n0u, (n1u < Cfg::UNITS ? n1u : Cfg::UNITS)>([&](auto UI) { constexpr int u = decltype(UI)::value; stage_piece(u / Cfg::NSTEP, u % Cfg::NSTEP, img ^ 1); });
+            static_for<n0u, (n1u < Cfg::UNITS ? n1u : Cfg::UNITS)>([&](auto UI) { constexpr int u = decltype(UI)::value; stage_piece(u / Cfg::NSTEP, u % Cfg::NSTEP, img ^ 1, t2); });
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (have_next2) load_tile(tile + 2 * a.Z);                  // registers are free again: the tile after next
+        if constexpr (!WHG_ROLL) { if (have_next2) load_tile(tile + 2 * a.Z); }      // registers are free again: the tile after next
         img ^= 1;
     }
 
