@@ -78,6 +78,9 @@ __device__ __forceinline__ void split_h2(float a0, float a1, float s, unsigned& 
 #ifndef H2S_ABL
 #define H2S_ABL 0                    // timing ablations of the FWD / BWDB epilogue (results are WRONG with any bit set; tools/scratch builds only):
 #endif                               // 1 no line trade, 2 no sign bits, 4 no amax tracking, 8 accumulators not zeroed, 16 no stores, 32 no activation / mask
+#ifndef H2S_PREBITS
+#define H2S_PREBITS 1                // backward-data with bit masks: the tile's mask words are requested in front of its last chunk (see prefetch_bits)
+#endif
 #ifndef H2S_NSETS
 #define H2S_NSETS 2                  // producer register sets for the halo tile: 1 = a chunk's halo is requested at the END of the period before the one that splits it (round 5),
 #endif                               // 2 / 3 = at the START of that period / a period earlier still (profiles/r6/ab_producer_sets.txt)
@@ -440,6 +443,25 @@ igemm_h2s_kernel(const H2Args ha) {
     float amx0 = 0.f, amx1 = 0.f;                                    // max |stored value| of this lane, per destination
     f32x4 hw[EK == EK_HEAD ? 8 : 1];                                 // (EK_HEAD) head weights of this lane's 8 channels: [output o][16-column block jj] (loaded behind barrier 0)
 
+    // (EK_BWDB) the tile's mask words, requested in FRONT of its last chunk (H2S_PREBITS, round 6): requested at the start of the epilogue, the first
+    // mask_scale waited a memory latency for them with the matrix pipe idle -- per tile, ~2 000 cycles of a 13 000 ... 40 000-cycle tile on the shallow layers
+    unsigned mbits_pre[EK == EK_BWDB ? NT : 1];
+    auto prefetch_bits = [&](const Tile& tl) __attribute__((always_inline)) {
+        const EpiArgs ea = epi_args();
+        int lane_p = lane;
+        asm volatile("" : "+v"(lane_p));
+        const int tile_id = (tl.b * tiles_y + tl.y0 / TH) * tiles_x + (tl.x0 >> 5);
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            const int nwv = __builtin_amdgcn_readfirstlane(tl.n0 + k * 32);
+            const int du = nwv >= ea.n_split ? 1 : 0, chw = nwv - (du ? ea.n_split : 0), nblk = ea.nblk(du);
+            const unsigned* bp = ea.bits_in(du);
+            const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)(bp ? bp : ea.bin0), 0, a.B * tiles_y * tiles_x * nblk * NCW * 64 * 4, 0x00020000);
+            const unsigned off = (unsigned)((((tile_id * nblk + (chw >> 5)) * NCW + wave) * 64 + lane_p) * 4);
+            mbits_pre[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, (ea.mask_mode(du) && bp && nwv < ea.Ntot) ? off : OOB, 0, 0);
+        }
+    };
+
     // ---- epilogue of tile `tl`, straight from the accumulators: x 2^dexp (undo the operand scales), bias, activation, act' mask, residual and
     // accumulation are float4 arithmetic on the accumulator registers; stores cover whole 128-byte lines (csrc/conv_x3s.hip).  The fused
     // MaxPool2d(2) takes the other pixel of a pair from the neighbouring lane (DPP) and the other row from the wave's second accumulator row.
@@ -704,7 +726,8 @@ igemm_h2s_kernel(const H2Args ha) {
                     const int mm = ea.mask_mode(du_[k]);
                     const unsigned* bp = ea.bits_in(du_[k]);
                     const __amdgpu_buffer_rsrc_t rb = bits_rsrc(bp ? bp : ea.bin0, ea.nblk(du_[k]));
-                    mbits[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, (mm && bp && blk_[k]) ? bits_off(k, ea.nblk(du_[k])) : OOB, 0, 0);
+                    if constexpr (H2S_PREBITS) mbits[k] = mbits_pre[k];
+                    else mbits[k] = __builtin_amdgcn_raw_buffer_load_b32(rb, (mm && bp && blk_[k]) ? bits_off(k, ea.nblk(du_[k])) : OOB, 0, 0);
                 }
             }
             auto body = [&](auto act_tag) __attribute__((always_inline)) {
@@ -867,6 +890,7 @@ igemm_h2s_kernel(const H2Args ha) {
 #ifdef H2S_STAMPS
         ++nch;
 #endif
+        if constexpr (EK == EK_BWDB && H2S_PREBITS) { if (g == nchunks - 1) prefetch_bits(cur); }
         mfma_chunk(st, img);
         H2S_T(t_mfma)
         // Experiment (H2S_TURNS, off): the two consumer waves of a SIMD (w, w + 4) TAKE TURNS with the epilogue of a tile -- waves 4-7 run it in
