@@ -217,7 +217,15 @@ __device__ __forceinline__ void amax_job(const PnnpPackJob& j, int64_t blk, int 
     for (int64_t i = n4 * 4 + blk * 256 + threadIdx.x; i < n; i += (int64_t)nblk * 256) upd(x[i]);
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)m, sft, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(reinterpret_cast<unsigned*>(j.dst), m);
+    // ONE atomic per block (round 6: one per wave -- up to 4 096 on one slot for a 512 x 512 x 9 tensor, ~15 ns each and serialised: the launch that held
+    // the deep layers' slots took 84 us, most of it this queue; csrc/common.h pnnp_amax_commit_block tells the same story for the activations)
+    __shared__ unsigned amax_red[4];
+    if ((threadIdx.x & 63) == 0) amax_red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) m = amax_red[i] > m ? amax_red[i] : m;
+        if (m) atomicMax(reinterpret_cast<unsigned*>(j.dst), m);
+    }
 }
 
 __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
@@ -236,7 +244,7 @@ __global__ void __launch_bounds__(256) pack_jobs_kernel(const JobTable tb) {
 }
 
 int job_blocks(const PnnpPackJob& j) {
-    if (j.kind == 5) { const int64_t b5 = (j.sk + 256 * 16 - 1) / (256 * 16); return (int)(b5 > 1024 ? 1024 : (b5 < 1 ? 1 : b5)); }
+    if (j.kind == 5) { const int64_t b5 = (j.sk + 256 * 16 - 1) / (256 * 16); return (int)(b5 > 128 ? 128 : (b5 < 1 ? 1 : b5)); }      // (<= 128 atomics per slot)
     const int64_t total = j.kind == 1 ? (int64_t)j.K * j.N : j.kind == 3 ? (int64_t)((j.K + 7) / 8 * 8) * j.N : j.kind == 6 ? (int64_t)(j.K / 8) * j.N : (j.kind == 2 ? (int64_t)j.Kvalid * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (j.kind == 4 ? (int64_t)j.Kvalid / 8 * (((j.T ? j.N : j.K) + 31) / 32 * 32) * 9 : (int64_t)j.T * j.K * j.N));
     int64_t b = (total + 255) / 256;
     const int64_t cap = j.kind == 1 ? 4096 : 2048;
