@@ -14,6 +14,9 @@ COMMON = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-
           '-I', os.path.join(REPO, 'include')] + os.environ.get('PNNP_HIPCC_EXTRA', '').split()     # A/B experiments (-DWINO_FENCED=0 ...)
 # per-file extra flags: the sampler keeps every float32 rounding explicit (matches oracle/pnnp_oracle.c)
 EXTRA = {'wino.hip': ['-fno-slp-vectorize'], 'conv_igemm.hip': ['-fno-slp-vectorize'], 'conv_x3.hip': ['-fno-slp-vectorize'], 'conv_x3s.hip': ['-fno-slp-vectorize'], 'conv_h2s.hip': ['-fno-slp-vectorize'], 'wgrad_x3.hip': ['-fno-slp-vectorize'], 'wgrad_x3s.hip': ['-fno-slp-vectorize'], 'wgrad_x3g.hip': ['-fno-slp-vectorize'], 'gemm_x3.hip': ['-fno-slp-vectorize'], 'gemm_x3s.hip': ['-fno-slp-vectorize'], 'gemm_h2s.hip': ['-fno-slp-vectorize'], 'wgrad_h2g.hip': ['-fno-slp-vectorize'],      # measured: +0.5 % / +0.7 % on the step each
+         # wgrad_h2s: with the SLP vectoriser on, the producers' rolling refill ends in register copies that wait for the loads it has just issued: step -2.1 % where
+         # the same source without it gains 1.05 % (profiles/r6/ab_wgrad_rolling.txt, part 4); round 5's source was indifferent to the flag
+         'wgrad_h2s.hip': ['-fno-slp-vectorize'],
          'noise.hip': ['-ffp-contract=off'], 'pack.hip': ['-ffp-contract=off'], 'cropaug.hip': ['-ffp-contract=off'],
          # the Winograd backward-weight kernel's source order is its schedule (slots fenced with sched_barrier)
          # (-fno-slp-vectorize: its stride-2 transforms vectorise into packed ops fed by 84 register moves per chunk; scalar is 44 fewer)
@@ -31,12 +34,19 @@ def build(verbose=True, force=False):
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, s[:-4] + '.o')
-        if force or newer(o, [os.path.join(SRC, s)] + hdrs):
-            jobs.append([HIPCC] + COMMON + EXTRA.get(s, []) + ['-c', os.path.join(SRC, s), '-o', o])
+        cmd = [HIPCC] + COMMON + EXTRA.get(s, []) + ['-c', os.path.join(SRC, s), '-o', o]
+        # an object is stale when its source or a header is newer -- or when it was compiled with OTHER FLAGS (kept beside it in <object>.flags)
+        stamp = o + '.flags'
+        same_flags = os.path.exists(stamp) and open(stamp).read() == ' '.join(cmd)
+        if force or not same_flags or newer(o, [os.path.join(SRC, s)] + hdrs):
+            jobs.append(cmd)
     def run(cmd):
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)
+        if '-c' in cmd:
+            with open(cmd[-1] + '.flags', 'w') as f:
+                f.write(' '.join(cmd))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s[:-4] + '.o') for s in srcs]

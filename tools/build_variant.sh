@@ -10,8 +10,8 @@ V=tools/scratch/variants; mkdir -p $V/obj_$TAG
 OBJS=$(ls pnnp_amd/csrc/_build/*.o)
 while [ $# -gt 0 ]; do
   F="$1"; FL="$2"; shift 2
-  EXTRA=""
-  case "$F" in conv_x3.hip|conv_x3s.hip|conv_h2s.hip|wgrad_h2s.hip|gemm_h2s.hip|wgrad_h2g.hip|wgrad_x3.hip|wgrad_x3s.hip|wgrad_x3g.hip|gemm_x3.hip|gemm_x3s.hip|conv_igemm.hip|wino.hip) EXTRA="-fno-slp-vectorize";; esac
+  # the file's own flags: tools/build.py's EXTRA table (ONE source: round 6 found this script adding -fno-slp-vectorize to a file the product built without it)
+  EXTRA=$(python -c "import sys; sys.path.insert(0, 'tools'); import build; print(' '.join(build.EXTRA.get('$F', [])))")
   O=$V/obj_$TAG/${F%.hip}.o
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -I include $EXTRA $FL -c pnnp_amd/csrc/$F -o $O
   OBJS=$(echo "$OBJS" | grep -v "/${F%.hip}.o"); OBJS="$OBJS $O"
