@@ -27,6 +27,11 @@ def newer(a, deps):
     return not os.path.exists(a) or any(os.path.getmtime(d) > os.path.getmtime(a) for d in deps)
 
 
+def flags_of(cmd):
+    """A compile command as the stamp keeps it: independent of where the repository lies (the GPU box sees it under another path and must not rebuild)."""
+    return ' '.join(a.replace(REPO, '.') for a in cmd[1:])
+
+
 def build(verbose=True, force=False):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(SRC) if f.endswith('.hip'))
@@ -37,7 +42,7 @@ def build(verbose=True, force=False):
         cmd = [HIPCC] + COMMON + EXTRA.get(s, []) + ['-c', os.path.join(SRC, s), '-o', o]
         # an object is stale when its source or a header is newer -- or when it was compiled with OTHER FLAGS (kept beside it in <object>.flags)
         stamp = o + '.flags'
-        same_flags = os.path.exists(stamp) and open(stamp).read() == ' '.join(cmd)
+        same_flags = os.path.exists(stamp) and open(stamp).read() == flags_of(cmd)
         if force or not same_flags or newer(o, [os.path.join(SRC, s)] + hdrs):
             jobs.append(cmd)
     def run(cmd):
@@ -46,7 +51,7 @@ def build(verbose=True, force=False):
         subprocess.check_call(cmd)
         if '-c' in cmd:
             with open(cmd[-1] + '.flags', 'w') as f:
-                f.write(' '.join(cmd))
+                f.write(flags_of(cmd))
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
     objs = [os.path.join(OBJ, s[:-4] + '.o') for s in srcs]
