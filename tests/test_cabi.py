@@ -70,3 +70,17 @@ def test_abi_version_and_shape_policies_without_a_gpu():
     assert lib.pnnp_gemm_h2_supported(64, 32) and lib.pnnp_gemm_h2_supported(32, 128) and not lib.pnnp_gemm_h2_supported(48, 64) and not lib.pnnp_gemm_h2_supported(64, 48)
     X3G_PW = ops.X3G_PW
     assert lib.pnnp_h2g_wgrad_supported(X3G_PW, 32, 64) and not lib.pnnp_x3g_wgrad_supported(X3G_PW, 32, 64)     # sc9's 32 x 64 tile exists on fp16x2 only
+
+
+def test_build_flags_have_one_source():
+    """Round 6: tools/build_variant.sh (the A/B builds) added -fno-slp-vectorize to csrc/wgrad_h2s.hip while tools/build.py (the product) did not, and the
+    adopted rolling refill was 2.1 % SLOWER in the product than the source it replaced (profiles/r6/ab_wgrad_rolling.txt, part 4).  The per-file flags live in
+    tools/build.py's EXTRA table only; the file that needs the flag has it; a stamp beside every object names the flags it was compiled with."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('pnnp_build', os.path.join(REPO, 'tools', 'build.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    assert '-fno-slp-vectorize' in b.EXTRA['wgrad_h2s.hip'] and '-fno-slp-vectorize' in b.EXTRA['wgrad_h2g.hip'] and '-fno-slp-vectorize' in b.EXTRA['conv_h2s.hip']
+    variant = open(os.path.join(REPO, 'tools', 'build_variant.sh')).read()
+    assert 'build.EXTRA.get' in variant and 'wgrad_h2s.hip|' not in variant
+    cmd = [b.HIPCC] + b.COMMON + ['-c', os.path.join(b.SRC, 'misc.hip'), '-o', os.path.join(b.OBJ, 'misc.o')]
+    assert REPO not in b.flags_of(cmd)                               # (the GPU box sees the repository under another path and must not rebuild)
