@@ -232,3 +232,23 @@ def test_convt_h2_bwd_data_with_sign_bits_equals_float_masks(shape):
     assert torch.equal(dx_b, dx_f) and torch.equal(a_b, a_f)
     frac_neg = float((below <= 0).float().mean())
     assert 0.2 < frac_neg < 0.8                                      # the mask really selects
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 5, 9])
+def test_convt_h2_bwd_weight_tiles_per_workgroup(B):
+    """Round 6: wgrad_h2g_kernel re-requests a staging slot for the tile after next behind its last staging step (rolling refill).  128 -> 64 channels on a
+    32 x 64 map: the batch sets the pixel tiles per workgroup (one, two, a few, uneven shares) -- against float64 sums."""
+    from pnnp_amd import ops
+    Ci, Co, H, W = 128, 64, 32, 64
+    gen = torch.Generator(device='cuda').manual_seed(B * 3 + 1)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen); g = torch.randn(B, 2 * H, 2 * W, Co, device='cuda', generator=gen)
+    # dW[ci][co][a][b] = sum over pixels of x[p][ci] g[2 y + a][2 x + b][co]
+    gd = g.double().view(B, H, 2, W, 2, Co)
+    ref = torch.einsum('bhwi,bhawco->ioac', x.double(), gd)
+    slot = lambda t: ops.amax(t, torch.zeros(1, dtype=torch.int32, device='cuda'))
+    ws = torch.zeros(ops.h2g_wgrad_workspace_floats(ops.X3G_CT, B, H, W, Ci, Co), device='cuda')
+    dW = torch.full((Ci, Co, 2, 2), float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.convt_h2_bwd_weight(x, slot(x), g, slot(g), dW, ws, dbias=db)
+    err = (dW.double() - ref).norm() / ref.norm()
+    assert err < 2e-6, (B, float(err))
+    assert (db.double() - g.double().sum((0, 1, 2))).abs().max() < 1e-5 * g.double().abs().sum((0, 1, 2)).max()

@@ -568,3 +568,25 @@ def test_splitk_engine_forward_and_step_on_one_crop():
     print(f'engine, one 256 x 256 crop: eval forward split-K vs not: {d:.2e}; losses {losses}')
     assert d < 1e-5
     assert all(abs(p - q) < 1e-6 * max(1.0, abs(q)) for p, q in zip(*losses))
+
+
+@pytest.mark.parametrize('B', [1, 2, 4, 5, 6, 11])
+@pytest.mark.parametrize('chan', [(64, 64), (32, 32), (32, 64)])
+def test_h2_bwd_weight_tiles_per_workgroup(B, chan):
+    """Round 6: the producers of wgrad_h2s_kernel re-request a staging slot for the tile AFTER NEXT as soon as it is staged (rolling refill), with the round-5
+    order left for a workgroup's last two tiles.  One output tile of 64 x 64 / 32 x 32 / 32 x 64 channels on a 64 x 128 map = one slab per CU, so the batch
+    sets the pixel tiles per workgroup: 1 (no loop), 2 (no rolling iteration), 3-4 (one or two), uneven shares, many -- against float64 sums."""
+    from pnnp_amd import ops
+    from test_gpu_x3 import _f64_wgrad
+    Co, Ci = chan
+    H, W = 64, 128
+    gen = torch.Generator(device='cuda').manual_seed(B * 7 + Co)
+    x = torch.randn(B, H, W, Ci, device='cuda', generator=gen); g = torch.randn(B, H, W, Co, device='cuda', generator=gen)
+    ref = _f64_wgrad(g, x)
+    ws = torch.empty(ops.x3_wgrad_workspace_floats(B, H, W, Co, Ci), device='cuda')
+    dW = torch.full((Co, Ci, 3, 3), float('nan'), device='cuda'); db = torch.full((Co,), float('nan'), device='cuda')
+    ops.conv_h2_bwd_weight(g, _slot(g), Co, x, _slot(x), Ci, None, None, dW, db, ws)
+    err = (dW.double() - ref).norm() / ref.norm()
+    assert err < 2e-6, (B, chan, float(err))
+    bref = g.double().sum((0, 1, 2))
+    assert (db.double() - bref).abs().max() < 1e-5 * g.double().abs().sum((0, 1, 2)).max()
