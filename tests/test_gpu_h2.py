@@ -590,3 +590,26 @@ def test_h2_bwd_weight_tiles_per_workgroup(B, chan):
     assert err < 2e-6, (B, chan, float(err))
     bref = g.double().sum((0, 1, 2))
     assert (db.double() - bref).abs().max() < 1e-5 * g.double().abs().sum((0, 1, 2)).max()
+
+
+@pytest.mark.parametrize('shape', [(32, 32), (512, 512), (96, 48)])
+def test_weight_amax_job_one_atomic_per_block(shape):
+    """Round 6: the weight tensors' amax job (pack_jobs kind 5) reduces a block's four waves through LDS and issues ONE atomic (every wave queued its own: up to
+    4 096 on one slot).  The slot is max |w| as a bit pattern; a NaN anywhere flags the tensor (its pattern orders above inf), whichever block holds it."""
+    from pnnp_amd import ops
+    Co, Ci = shape
+    w = (_rand(Co, Ci, 3, 3, seed=11, scale=0.3)).cuda()
+    w[Co // 2, Ci // 3, 1, 2] = -7.25                                   # the maximum, negative, somewhere in the middle
+    jobs = ops.PackJobs()
+    f = torch.zeros(ops.h2_weight_bytes((Ci + 15) // 16 * 16, Co), dtype=torch.uint8, device='cuda')
+    slot = jobs.add_h2(w, f, None)
+    jobs.run()
+    assert slot.view(torch.float32).item() == 7.25
+    jobs.run()                                                          # (the slots are zeroed per run: the same answer, not an accumulation)
+    assert slot.view(torch.float32).item() == 7.25
+    w[-1, -1, 2, 2] = float('nan')                                      # the last element: the last block's last wave
+    jobs.run()
+    assert slot.view(torch.float32).isnan().item()
+    w[-1, -1, 2, 2] = float('inf')
+    jobs.run()
+    assert slot.view(torch.float32).isinf().item()
