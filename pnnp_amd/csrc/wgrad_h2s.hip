@@ -38,6 +38,9 @@ constexpr unsigned OOB = 0x80000000u;
 #else
 #define WHS_T(v)
 #endif
+#ifndef WHS_G_AUX
+#define WHS_G_AUX 2                    // cache-policy bits of the producers' G loads: 2 = nt -- G is read exactly once by this kernel (X's halo rows are shared between
+#endif                                 // tiles and keep the default): step +0.3 % on two boxes, config 5 equal (profiles/r6/ab_stream_load_policy.txt)
 #ifndef WHS_ROLL
 #define WHS_ROLL 1                     // producers: rolling refill of the staging registers (see roll_tile; 0 = round 5's order)
 #endif
@@ -151,7 +154,7 @@ wgrad_h2s_kernel(const Wh2sArgs a) {
             constexpr int k = decltype(ktag)::value;
             const int gr = (GSTEP * k) >> 5, gc = gp0 + ((GSTEP * k) & 31);
             const int bad = (t.rlim - 1 - gr) | (t.clim - 1 - gc);                             // sign bit set <=> pixel outside the image
-            rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, bad < 0 ? OOB : g_base, t.gso + (gr * a.W + ((GSTEP * k) & 31)) * a.Gcs * 4, 0));
+            rg[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsg, bad < 0 ? OOB : g_base, t.gso + (gr * a.W + ((GSTEP * k) & 31)) * a.Gcs * 4, WHS_G_AUX));
         };
         auto load_x = [&](auto ktag, const TileSc& t) {
             constexpr int k = decltype(ktag)::value;
